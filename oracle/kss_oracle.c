@@ -1,0 +1,760 @@
+/*
+ * oracle/kss_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ *
+ * Plain-C restatement of the reference registration hot path.  See kss_oracle.h for the
+ * parity-pin status.  Build: oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
+ * -ffp-contract=off is REQUIRED: the reference arithmetic (MSVC /fp:precise, FLANN
+ * L2_Simple<float>) never fuses multiply-add.
+ *
+ * Citations: path:line under /root/reference/PS_AIS_Simplification/.
+ */
+#include "kss_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+void ko_free(void *p) { free(p); }
+
+/* ------------------------------------------------------------------------------------ */
+/* KSS pre-shape -- initRegistrationKSS.hpp:144-220                                      */
+/* ------------------------------------------------------------------------------------ */
+static void centroid_and_radius(const double *P, int64_t n, double c[3], double *r) {
+    /* :146-157 serial sums then divide by size */
+    double xs = 0, ys = 0, zs = 0;
+    for (int64_t i = 0; i < n; i++) {
+        xs = xs + P[3 * i + 0];
+        ys = ys + P[3 * i + 1];
+        zs = zs + P[3 * i + 2];
+    }
+    xs = xs / (double)n; ys = ys / (double)n; zs = zs / (double)n;
+    /* :160-171 mean distance to the centroid (the max variant is commented out there) */
+    double acc = 0;
+    for (int64_t i = 0; i < n; i++) {
+        double xl = P[3 * i + 0] - xs, yl = P[3 * i + 1] - ys, zl = P[3 * i + 2] - zs;
+        acc = acc + sqrt(xl * xl + yl * yl + zl * zl);
+    }
+    c[0] = xs; c[1] = ys; c[2] = zs;
+    *r = acc / (double)n;
+}
+
+void ko_preshape_stats(const double *S, int64_t ns, const double *T, int64_t nt, ko_preshape *o) {
+    centroid_and_radius(S, ns, o->c_src, &o->r_src);
+    centroid_and_radius(T, nt, o->c_tgt, &o->r_tgt);
+    for (int k = 0; k < 3; k++) o->shift[k] = o->c_tgt[k] - o->c_src[k]; /* :190-192 */
+    o->scale = o->r_tgt / o->r_src;                                     /* :209 */
+}
+
+void ko_similarity_apply(const double *in, int64_t n, const ko_preshape *ps, double *out) {
+    /* :212-219 (and :77-84, :95-102): p += shift; p = c_T + (p - c_T) * scale */
+    for (int64_t i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) {
+            double v = in[3 * i + k] + ps->shift[k];
+            out[3 * i + k] = ps->c_tgt[k] + (v - ps->c_tgt[k]) * ps->scale;
+        }
+}
+
+void ko_axis_rotate(int cord, double angle, double *p, int64_t n) {
+    /* :365-404; the reference re-evaluates cos/sin per point, the value is the same */
+    const double c = cos(angle), s = sin(angle);
+    if (cord == 1) {
+        for (int64_t i = 0; i < n; i++) {
+            double y = p[3 * i + 1], z = p[3 * i + 2];
+            p[3 * i + 1] = y * c - z * s;
+            p[3 * i + 2] = y * s + z * c;
+        }
+    } else if (cord == 2) {
+        for (int64_t i = 0; i < n; i++) {
+            double x = p[3 * i + 0], z = p[3 * i + 2];
+            p[3 * i + 0] = z * s + x * c;
+            p[3 * i + 2] = z * c - x * s;
+        }
+    } else {
+        for (int64_t i = 0; i < n; i++) {
+            double x = p[3 * i + 0], y = p[3 * i + 1];
+            p[3 * i + 0] = x * c - y * s;
+            p[3 * i + 1] = x * s + y * c;
+        }
+    }
+}
+
+void ko_pose_apply(const double *in, int64_t n, const ko_preshape *ps, const double angle[3], double *out) {
+    /* :75-109 */
+    ko_similarity_apply(in, n, ps, out);
+    ko_axis_rotate(1, angle[0], out, n);
+    ko_axis_rotate(2, angle[1], out, n);
+    ko_axis_rotate(3, angle[2], out, n);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* exact float 1-NN                                                                      */
+/* ------------------------------------------------------------------------------------ */
+static inline float dist2(const float *a, const float *b, int fma) {
+    float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    if (fma) return fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+    return (dx * dx + dy * dy) + dz * dz; /* FLANN L2_Simple: result += diff*diff, in order */
+}
+
+void ko_nn_brute(const float *q, int64_t nq, const float *t, int64_t nt, int fma, int32_t *idx, float *d2) {
+#pragma omp parallel for schedule(static) if (nq >= 1024)
+    for (int64_t i = 0; i < nq; i++) {
+        float best = INFINITY; int32_t bi = -1;
+        for (int64_t j = 0; j < nt; j++) {
+            float d = dist2(q + 3 * i, t + 3 * j, fma);
+            if (d < best) { best = d; bi = (int32_t)j; } /* strict <: lowest index wins ties */
+        }
+        idx[i] = bi; d2[i] = best;
+    }
+}
+
+/* ---- kd-tree (role of FLANN KDTreeSingleIndex, leaf 15, exact search) ---- */
+typedef struct { int32_t left, right; /* children, or for a leaf: left=-1, lo/hi below */
+                 int32_t lo, hi; int32_t dim; float divlow, divhigh; } kd_node;
+struct ko_kdtree {
+    int64_t n; int leaf;
+    float *pts; int32_t *orig;
+    kd_node *nodes; int32_t nnodes, capnodes;
+    float bbox[6];
+};
+
+static void kd_select(int32_t *perm, const float *t, int dim, int64_t lo, int64_t hi, int64_t k) {
+    /* quickselect so that perm[k] holds the k-th smallest coordinate in [lo,hi) */
+    hi--;
+    while (lo < hi) {
+        float pivot = t[3 * (int64_t)perm[(lo + hi) / 2] + dim];
+        int64_t i = lo, j = hi;
+        while (i <= j) {
+            while (t[3 * (int64_t)perm[i] + dim] < pivot) i++;
+            while (t[3 * (int64_t)perm[j] + dim] > pivot) j--;
+            if (i <= j) { int32_t tmp = perm[i]; perm[i] = perm[j]; perm[j] = tmp; i++; j--; }
+        }
+        if (k <= j) hi = j; else if (k >= i) lo = i; else return;
+    }
+}
+
+static int32_t kd_build_rec(ko_kdtree *kt, int32_t *perm, const float *t, int64_t lo, int64_t hi) {
+    if (kt->nnodes == kt->capnodes) {
+        kt->capnodes = kt->capnodes * 2 + 16;
+        kt->nodes = (kd_node *)realloc(kt->nodes, sizeof(kd_node) * (size_t)kt->capnodes);
+    }
+    int32_t id = kt->nnodes++;
+    kd_node nd; memset(&nd, 0, sizeof nd);
+    nd.lo = (int32_t)lo; nd.hi = (int32_t)hi; nd.left = nd.right = -1;
+    if (hi - lo <= kt->leaf) { kt->nodes[id] = nd; return id; }
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = lo; i < hi; i++)
+        for (int k = 0; k < 3; k++) {
+            float v = t[3 * (int64_t)perm[i] + k];
+            if (v < mn[k]) mn[k] = v;
+            if (v > mx[k]) mx[k] = v;
+        }
+    int dim = 0; float span = mx[0] - mn[0];
+    for (int k = 1; k < 3; k++) if (mx[k] - mn[k] > span) { span = mx[k] - mn[k]; dim = k; }
+    int64_t mid = (lo + hi) / 2;
+    kd_select(perm, t, dim, lo, hi, mid);
+    float dl = -INFINITY, dh = INFINITY;
+    for (int64_t i = lo; i < mid; i++) { float v = t[3 * (int64_t)perm[i] + dim]; if (v > dl) dl = v; }
+    for (int64_t i = mid; i < hi; i++) { float v = t[3 * (int64_t)perm[i] + dim]; if (v < dh) dh = v; }
+    nd.dim = dim; nd.divlow = dl; nd.divhigh = dh;
+    int32_t l = kd_build_rec(kt, perm, t, lo, mid);
+    int32_t r = kd_build_rec(kt, perm, t, mid, hi);
+    nd.left = l; nd.right = r;
+    kt->nodes[id] = nd;
+    return id;
+}
+
+ko_kdtree *ko_kdtree_build(const float *t, int64_t nt, int leaf_size) {
+    ko_kdtree *kt = (ko_kdtree *)calloc(1, sizeof *kt);
+    kt->n = nt; kt->leaf = leaf_size > 0 ? leaf_size : 15;
+    int32_t *perm = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nt > 0 ? nt : 1));
+    for (int64_t i = 0; i < nt; i++) perm[i] = (int32_t)i;
+    for (int k = 0; k < 3; k++) { kt->bbox[k] = INFINITY; kt->bbox[3 + k] = -INFINITY; }
+    for (int64_t i = 0; i < nt; i++)
+        for (int k = 0; k < 3; k++) {
+            float v = t[3 * i + k];
+            if (v < kt->bbox[k]) kt->bbox[k] = v;
+            if (v > kt->bbox[3 + k]) kt->bbox[3 + k] = v;
+        }
+    if (nt > 0) kd_build_rec(kt, perm, t, 0, nt);
+    kt->pts = (float *)malloc(sizeof(float) * 3 * (size_t)(nt > 0 ? nt : 1));
+    for (int64_t i = 0; i < nt; i++) memcpy(kt->pts + 3 * i, t + 3 * (int64_t)perm[i], 3 * sizeof(float));
+    kt->orig = perm;
+    return kt;
+}
+
+void ko_kdtree_free(ko_kdtree *kt) {
+    if (!kt) return;
+    free(kt->pts); free(kt->orig); free(kt->nodes); free(kt);
+}
+
+typedef struct { const ko_kdtree *kt; const float *q; int fma; float best; int32_t bi; } kd_query;
+
+static void kd_search(kd_query *Q, int32_t node, float off[3]) {
+    const kd_node *nd = &Q->kt->nodes[node];
+    if (nd->left < 0) {
+        const float *p = Q->kt->pts + 3 * (int64_t)nd->lo;
+        for (int32_t i = nd->lo; i < nd->hi; i++, p += 3) {
+            float d = dist2(Q->q, p, Q->fma);
+            int32_t oi = Q->kt->orig[i];
+            if (d < Q->best || (d == Q->best && oi < Q->bi)) { Q->best = d; Q->bi = oi; }
+        }
+        return;
+    }
+    int dim = nd->dim;
+    float val = Q->q[dim];
+    float d1 = val - nd->divlow, d2 = val - nd->divhigh;
+    int32_t nearc, farc; float cut;
+    if (d1 + d2 < 0) { nearc = nd->left; farc = nd->right; cut = d2 * d2; }
+    else { nearc = nd->right; farc = nd->left; cut = d1 * d1; }
+    kd_search(Q, nearc, off);
+    float save = off[dim];
+    off[dim] = cut;
+    /* canonical-order lower bound: every point p of the far child has
+       fl((q-p)_d^2) >= off[d] per dimension, and float addition is monotone, so
+       (off0+off1)+off2 <= (dx2+dy2)+dz2.  '<=' keeps equal-distance (tie) candidates. */
+    float mind = (off[0] + off[1]) + off[2];
+    if (Q->fma) mind *= 0.99999f; /* fused form rounds differently: relax the bound */
+    if (mind <= Q->best) kd_search(Q, farc, off);
+    off[dim] = save;
+}
+
+static void kd_nn_one(const ko_kdtree *kt, const float *q, int fma, int32_t *idx, float *d2) {
+    kd_query Q; Q.kt = kt; Q.q = q; Q.fma = fma; Q.best = INFINITY; Q.bi = INT32_MAX;
+    float off[3];
+    for (int k = 0; k < 3; k++) {
+        float o = 0.f;
+        if (q[k] < kt->bbox[k]) o = q[k] - kt->bbox[k];
+        else if (q[k] > kt->bbox[3 + k]) o = q[k] - kt->bbox[3 + k];
+        off[k] = o * o;
+    }
+    if (kt->n > 0) kd_search(&Q, 0, off);
+    *idx = kt->n > 0 ? Q.bi : -1; *d2 = Q.best;
+}
+
+void ko_kdtree_nn(const ko_kdtree *kt, const float *q, int64_t nq, int fma, int nthreads, int32_t *idx, float *d2) {
+    if (nthreads <= 1) {
+        for (int64_t i = 0; i < nq; i++) kd_nn_one(kt, q + 3 * i, fma, idx + i, d2 + i);
+    } else {
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads)
+        for (int64_t i = 0; i < nq; i++) kd_nn_one(kt, q + 3 * i, fma, idx + i, d2 + i);
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* rotation search -- initRegistrationKSS.hpp:222-296, :430-450, :481-522               */
+/* ------------------------------------------------------------------------------------ */
+int ko_grid_angles(double step, double *angles, int cap) {
+    /* :245 for (double i = 0; i < 6.3; i = i + 6.3 / step): double accumulation */
+    int g = 0;
+    for (double a = 0; a < 6.3; a = a + 6.3 / step) {
+        if (g >= cap) return -1;
+        angles[g++] = a;
+    }
+    return g;
+}
+
+double ko_error_ave(const double *cloud, int64_t n, const float *tf, int64_t nt, const ko_kdtree *tree) {
+    /* :430-450: searchPoint.x = (float)pointS[i][0]; K=2 asked, [0] used; sqrt in double */
+    double sum = 0;
+    for (int64_t i = 0; i < n; i++) {
+        float q[3] = {(float)cloud[3 * i], (float)cloud[3 * i + 1], (float)cloud[3 * i + 2]};
+        int32_t id; float d;
+        if (tree) kd_nn_one(tree, q, 0, &id, &d);
+        else ko_nn_brute(q, 1, tf, nt, 0, &id, &d);
+        double di = sqrt((double)d);
+        sum = sum + di;
+    }
+    return sum / (double)n;
+}
+
+int ko_local_min(const double *value, int g, int i, int j, int k, int r) {
+    /* :481-522: clamped (non-periodic) window, fails iff a strictly smaller value exists */
+    double c = value[((int64_t)i * g + j) * g + k];
+    int id = i - r < 0 ? 0 : i - r, iu = i + r >= g ? g - 1 : i + r;
+    int jd = j - r < 0 ? 0 : j - r, ju = j + r >= g ? g - 1 : j + r;
+    int kd = k - r < 0 ? 0 : k - r, ku = k + r >= g ? g - 1 : k + r;
+    for (int ii = id; ii <= iu; ii++)
+        for (int jj = jd; jj <= ju; jj++)
+            for (int kk = kd; kk <= ku; kk++)
+                if (c > value[((int64_t)ii * g + jj) * g + kk]) return 0;
+    return 1;
+}
+
+int ko_rotation_search(const double *Sp, int64_t ns, const double *T, int64_t nt, double step,
+                       double *value, int cap_g, double best_angle[3],
+                       double *angle_list, int *n_list, int cap_list) {
+    double ang[256];
+    int g = ko_grid_angles(step, ang, 256);
+    if (g < 0 || g > cap_g) return -1;
+    /* :224-236 target narrowed to float PointXYZ, kd-tree built once */
+    float *tf = (float *)malloc(sizeof(float) * 3 * (size_t)nt);
+    for (int64_t i = 0; i < 3 * nt; i++) tf[i] = (float)T[i];
+    ko_kdtree *tree = ko_kdtree_build(tf, nt, 15);
+    double *px = (double *)malloc(sizeof(double) * 3 * (size_t)ns);
+    double *pxy = (double *)malloc(sizeof(double) * 3 * (size_t)ns);
+    double *pxyz = (double *)malloc(sizeof(double) * 3 * (size_t)ns);
+    double errorT = 9999; /* :239 */
+    double iG = 0, jG = 0, kG = 0;
+    for (int a = 0; a < g; a++) {
+        memcpy(px, Sp, sizeof(double) * 3 * (size_t)ns);
+        ko_axis_rotate(1, ang[a], px, ns);                         /* :247 */
+        for (int b = 0; b < g; b++) {
+            memcpy(pxy, px, sizeof(double) * 3 * (size_t)ns);
+            ko_axis_rotate(2, ang[b], pxy, ns);                    /* :250 */
+            for (int c = 0; c < g; c++) {
+                memcpy(pxyz, pxy, sizeof(double) * 3 * (size_t)ns);
+                ko_axis_rotate(3, ang[c], pxyz, ns);               /* :253 */
+                double e = ko_error_ave(pxyz, ns, tf, nt, tree);   /* :255 */
+                value[((int64_t)a * g + b) * g + c] = e;
+                if (e < errorT) { iG = ang[a]; jG = ang[b]; kG = ang[c]; errorT = e; } /* :258 strict */
+            }
+        }
+    }
+    int nl = 0;
+    for (int a = 0; a < g; a++)
+        for (int b = 0; b < g; b++)
+            for (int c = 0; c < g; c++)
+                if (ko_local_min(value, g, a, b, c, 2)) {           /* :279, r = 2 (:35) */
+                    if (nl >= cap_list) { nl = -1; goto done; }
+                    angle_list[3 * nl + 0] = (double)a * 6.3 / (double)step; /* :282-284 */
+                    angle_list[3 * nl + 1] = (double)b * 6.3 / (double)step;
+                    angle_list[3 * nl + 2] = (double)c * 6.3 / (double)step;
+                    nl++;
+                }
+done:
+    best_angle[0] = iG; best_angle[1] = jG; best_angle[2] = kG;     /* :291-293 */
+    *n_list = nl;
+    free(px); free(pxy); free(pxyz); free(tf); ko_kdtree_free(tree);
+    return nl < 0 ? -2 : g;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* float Matrix4f helpers (Eigen evaluation order: columns accumulated k = 0..3, no fma)  */
+/* ------------------------------------------------------------------------------------ */
+void ko_mat4_mul(const float A[16], const float B[16], float C[16]) {
+    float R[16];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            float acc = A[4 * i + 0] * B[0 * 4 + j];
+            acc = acc + A[4 * i + 1] * B[1 * 4 + j];
+            acc = acc + A[4 * i + 2] * B[2 * 4 + j];
+            acc = acc + A[4 * i + 3] * B[3 * 4 + j];
+            R[4 * i + j] = acc;
+        }
+    memcpy(C, R, sizeof R);
+}
+
+void ko_transform_points_f32(const float T[16], const float *in, int64_t n, float *out) {
+    /* pcl IterativeClosestPoint::transformCloud: pt_t = tr * (x,y,z,1) */
+    for (int64_t i = 0; i < n; i++) {
+        float x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+        for (int r = 0; r < 3; r++) {
+            float acc = T[4 * r + 0] * x;
+            acc = acc + T[4 * r + 1] * y;
+            acc = acc + T[4 * r + 2] * z;
+            acc = acc + T[4 * r + 3];
+            out[3 * i + r] = acc;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* 3x3 SVD (Jacobi on A^T A) and Umeyama-without-scaling                                  */
+/* ------------------------------------------------------------------------------------ */
+static double det3(const double M[9]) {
+    return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+static void jacobi_eig3(double S[9], double V[9]) {
+    /* cyclic Jacobi for a symmetric 3x3; on exit S ~ diag, V columns = eigenvectors */
+    for (int i = 0; i < 9; i++) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 64; sweep++) {
+        double offn = fabs(S[1]) + fabs(S[2]) + fabs(S[5]);
+        double dn = fabs(S[0]) + fabs(S[4]) + fabs(S[8]);
+        if (offn <= 1e-300 || offn <= 1e-18 * dn) break;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                double apq = S[3 * p + q];
+                if (apq == 0.0) continue;
+                double app = S[3 * p + p], aqq = S[3 * q + q];
+                double theta = (aqq - app) / (2.0 * apq);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; k++) { /* S <- S * J */
+                    double skp = S[3 * k + p], skq = S[3 * k + q];
+                    S[3 * k + p] = c * skp - s * skq;
+                    S[3 * k + q] = s * skp + c * skq;
+                }
+                for (int k = 0; k < 3; k++) { /* S <- J^T * S */
+                    double spk = S[3 * p + k], sqk = S[3 * q + k];
+                    S[3 * p + k] = c * spk - s * sqk;
+                    S[3 * q + k] = s * spk + c * sqk;
+                }
+                for (int k = 0; k < 3; k++) {
+                    double vkp = V[3 * k + p], vkq = V[3 * k + q];
+                    V[3 * k + p] = c * vkp - s * vkq;
+                    V[3 * k + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+}
+
+void ko_svd3(const double A[9], double U[9], double s[3], double V[9]) {
+    double AtA[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double acc = 0;
+            for (int k = 0; k < 3; k++) acc += A[3 * k + i] * A[3 * k + j];
+            AtA[3 * i + j] = acc;
+        }
+    double Vv[9];
+    jacobi_eig3(AtA, Vv);
+    double ev[3] = {AtA[0], AtA[4], AtA[8]};
+    int ord[3] = {0, 1, 2};
+    for (int a = 0; a < 2; a++)
+        for (int b = a + 1; b < 3; b++)
+            if (ev[ord[b]] > ev[ord[a]]) { int tmp = ord[a]; ord[a] = ord[b]; ord[b] = tmp; }
+    for (int c = 0; c < 3; c++) {
+        for (int r = 0; r < 3; r++) V[3 * r + c] = Vv[3 * r + ord[c]];
+        s[c] = sqrt(ev[ord[c]] > 0 ? ev[ord[c]] : 0.0);
+    }
+    /* U columns = A v_c / s_c; complete rank-deficient columns orthonormally */
+    double u[3][3];
+    int ok[3];
+    for (int c = 0; c < 3; c++) {
+        double n2 = 0;
+        for (int r = 0; r < 3; r++) {
+            double acc = 0;
+            for (int k = 0; k < 3; k++) acc += A[3 * r + k] * V[3 * k + c];
+            u[c][r] = acc; n2 += acc * acc;
+        }
+        double nn = sqrt(n2);
+        ok[c] = nn > 1e-13 * (s[0] > 0 ? s[0] : 1.0) && nn > 0;
+        if (ok[c]) for (int r = 0; r < 3; r++) u[c][r] /= nn;
+    }
+    if (!ok[0]) { u[0][0] = 1; u[0][1] = 0; u[0][2] = 0; ok[0] = 1; }
+    if (!ok[1]) {
+        /* any unit vector orthogonal to u0 */
+        double a[3] = {0, 0, 0};
+        int m = fabs(u[0][0]) < fabs(u[0][1]) ? (fabs(u[0][0]) < fabs(u[0][2]) ? 0 : 2) : (fabs(u[0][1]) < fabs(u[0][2]) ? 1 : 2);
+        a[m] = 1;
+        double d = a[0] * u[0][0] + a[1] * u[0][1] + a[2] * u[0][2], n2 = 0;
+        for (int r = 0; r < 3; r++) { u[1][r] = a[r] - d * u[0][r]; n2 += u[1][r] * u[1][r]; }
+        n2 = sqrt(n2);
+        for (int r = 0; r < 3; r++) u[1][r] /= n2;
+        ok[1] = 1;
+    }
+    if (!ok[2]) {
+        u[2][0] = u[0][1] * u[1][2] - u[0][2] * u[1][1];
+        u[2][1] = u[0][2] * u[1][0] - u[0][0] * u[1][2];
+        u[2][2] = u[0][0] * u[1][1] - u[0][1] * u[1][0];
+    }
+    for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) U[3 * r + c] = u[c][r];
+}
+
+void ko_rigid_from_sums(const double sums[20], float Tk[16]) {
+    /* pcl::registration::TransformationEstimationSVD -> Eigen umeyama(src, dst, false):
+       sigma = (1/n) sum (dst-mu_d)(src-mu_s)^T ; R = U S V^T ; t = mu_d - R mu_s.
+       Accumulated here in double (PCL: float).  */
+    double n = sums[0];
+    double ms[3] = {sums[1] / n, sums[2] / n, sums[3] / n};
+    double md[3] = {sums[4] / n, sums[5] / n, sums[6] / n};
+    double sigma[9];
+    for (int i = 0; i < 3; i++)      /* dst index (row) */
+        for (int j = 0; j < 3; j++)  /* src index (col) */
+            sigma[3 * i + j] = sums[7 + 3 * j + i] / n - md[i] * ms[j];
+    double U[9], s[3], V[9];
+    ko_svd3(sigma, U, s, V);
+    double S[3] = {1, 1, 1};
+    if (det3(U) * det3(V) < 0) S[2] = -1; /* Eq. (39) */
+    double R[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double acc = 0;
+            for (int k = 0; k < 3; k++) acc += U[3 * i + k] * S[k] * V[3 * j + k];
+            R[3 * i + j] = acc;
+        }
+    double t[3];
+    for (int i = 0; i < 3; i++) t[i] = md[i] - (R[3 * i] * ms[0] + R[3 * i + 1] * ms[1] + R[3 * i + 2] * ms[2]);
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) Tk[4 * i + j] = (float)R[3 * i + j];
+        Tk[4 * i + 3] = (float)t[i];
+    }
+    Tk[12] = Tk[13] = Tk[14] = 0.f; Tk[15] = 1.f;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* ICP -- pcl::IterativeClosestPoint::computeTransformation (PCL 1.8.1 icp.hpp),          */
+/*        CorrespondenceEstimation::determineCorrespondences,                             */
+/*        DefaultConvergenceCriteria::hasConverged, Registration::getFitnessScore         */
+/* ------------------------------------------------------------------------------------ */
+void ko_icp_default_params(ko_icp_params *p) {
+    memset(p, 0, sizeof *p);
+    p->max_iterations = 1000;             /* Main_KSS_ICP.cpp:81 */
+    p->max_corr_dist = 1.0;               /* KSS_ICP.hpp:156 */
+    p->transformation_epsilon = 1e-10;    /* :157 */
+    p->euclidean_fitness_epsilon = 0.001; /* :158 */
+    p->abs_mse_epsilon = 1e-12;
+    p->min_correspondences = 3;
+    p->use_kdtree = 1;
+    p->nthreads = 1;
+    p->compute_fitness = 1;
+}
+
+static void nn_pass(const ko_kdtree *tree, const float *q, int64_t nq, const float *t, int64_t nt,
+                    const ko_icp_params *p, int32_t *idx, float *d2, double *acc) {
+    double t0 = now_s();
+    if (tree) ko_kdtree_nn(tree, q, nq, p->fma, p->nthreads, idx, d2);
+    else ko_nn_brute(q, nq, t, nt, p->fma, idx, d2);
+    *acc += now_s() - t0;
+}
+
+int ko_icp(const float *src, int64_t ns, const float *tgt, int64_t nt,
+           const ko_icp_params *p, ko_icp_result *res, ko_icp_trace *trace) {
+    memset(res, 0, sizeof *res);
+    double t_start = now_s();
+    float *cur = (float *)malloc(sizeof(float) * 3 * (size_t)(ns > 0 ? ns : 1));
+    int32_t *idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ns > 0 ? ns : 1));
+    float *d2 = (float *)malloc(sizeof(float) * (size_t)(ns > 0 ? ns : 1));
+    memcpy(cur, src, sizeof(float) * 3 * (size_t)ns); /* *input_transformed = *input_ (identity guess) */
+    ko_kdtree *tree = NULL;
+    if (p->use_kdtree) { double t0 = now_s(); tree = ko_kdtree_build(tgt, nt, 15); res->build_seconds = now_s() - t0; }
+
+    float final[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    float Tk[16];
+    const double max_dist_sqr = p->max_corr_dist * p->max_corr_dist;
+    const double rotation_threshold = 1.0 - p->transformation_epsilon; /* setRotationThreshold */
+    const double translation_threshold = p->transformation_epsilon;
+    double prev_mse = DBL_MAX; /* correspondences_prev_mse_ initial value */
+    int iterations = 0, converged = 0, state = KO_STATE_NOT_CONVERGED;
+    if (trace) trace->n = 0;
+
+    do {
+        nn_pass(tree, cur, ns, tgt, nt, p, idx, d2, &res->nn_seconds);
+        double sums[20];
+        memset(sums, 0, sizeof sums);
+        for (int64_t i = 0; i < ns; i++) {
+            double dd = (double)d2[i];
+            sums[17] += dd;
+            sums[18] += sqrt(dd);
+            if (dd > max_dist_sqr) continue; /* determineCorrespondences: distance[0] > max_dist_sqr */
+            const float *a = cur + 3 * i, *b = tgt + 3 * (int64_t)idx[i];
+            sums[0] += 1.0;
+            for (int k = 0; k < 3; k++) { sums[1 + k] += (double)a[k]; sums[4 + k] += (double)b[k]; }
+            for (int k = 0; k < 3; k++)
+                for (int l = 0; l < 3; l++) sums[7 + 3 * k + l] += (double)a[k] * (double)b[l];
+            sums[16] += dd;
+        }
+        if ((int)sums[0] < p->min_correspondences) { /* "Not enough correspondences found" */
+            state = KO_STATE_NO_CORRESPONDENCES; converged = 0;
+            break;
+        }
+        ko_rigid_from_sums(sums, Tk);
+        ko_transform_points_f32(Tk, cur, ns, cur);  /* transformCloud(*input_transformed, ..) */
+        ko_mat4_mul(Tk, final, final);              /* final = transformation_ * final */
+        ++iterations;
+        double mse = sums[16] / sums[0];            /* calculateMSE(correspondences_) */
+        res->last_mse = mse;
+        if (trace && trace->n < trace->cap) {
+            memcpy(trace->sums + 20 * (size_t)trace->n, sums, sizeof sums);
+            memcpy(trace->Tk + 16 * (size_t)trace->n, Tk, sizeof Tk);
+            trace->n++;
+        }
+        /* --- DefaultConvergenceCriteria::hasConverged --- */
+        converged = 0; state = KO_STATE_NOT_CONVERGED;
+        if (iterations >= p->max_iterations) { converged = 1; state = KO_STATE_ITERATIONS; }
+        else if (!p->fixed_iterations) {
+            float tr = Tk[0] + Tk[5] + Tk[10] - 1;                     /* float sum, as Matrix4f coeffs */
+            double cos_angle = 0.5 * tr;
+            float tsq = Tk[3] * Tk[3] + Tk[7] * Tk[7] + Tk[11] * Tk[11];
+            double translation_sqr = tsq;
+            if (cos_angle >= rotation_threshold && translation_sqr <= translation_threshold) {
+                converged = 1; state = KO_STATE_TRANSFORM;  /* max_iterations_similar_transforms_ = 0 */
+            } else if (fabs(mse - prev_mse) < p->abs_mse_epsilon) {
+                converged = 1; state = KO_STATE_ABS_MSE;
+            } else if (fabs(mse - prev_mse) / prev_mse < p->euclidean_fitness_epsilon) {
+                converged = 1; state = KO_STATE_REL_MSE;
+            } else {
+                prev_mse = mse;
+            }
+        }
+    } while (!converged);
+
+    memcpy(res->T, final, sizeof final);
+    res->iterations = iterations; res->converged = converged; res->state = state;
+    if (p->compute_fitness) {
+        /* getFitnessScore(): transform the ORIGINAL input by final, mean NN d2 over all points */
+        ko_transform_points_f32(final, src, ns, cur);
+        nn_pass(tree, cur, ns, tgt, nt, p, idx, d2, &res->nn_seconds);
+        double f = 0;
+        for (int64_t i = 0; i < ns; i++) f += (double)d2[i];
+        res->fitness = ns > 0 ? f / (double)ns : DBL_MAX;
+    }
+    ko_kdtree_free(tree);
+    free(cur); free(idx); free(d2);
+    res->total_seconds = now_s() - t_start;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* PCR_QM -- registrationMeasure.hpp:47-98                                                */
+/* ------------------------------------------------------------------------------------ */
+void ko_pcr_qm(const double *A, int64_t na, const double *T, int64_t nt, double out[3]) {
+    float *tf = (float *)malloc(sizeof(float) * 3 * (size_t)(nt > 0 ? nt : 1));
+    for (int64_t i = 0; i < 3 * nt; i++) tf[i] = (float)T[i]; /* :59-61 */
+    ko_kdtree *tree = ko_kdtree_build(tf, nt, 15);
+    double mse = 0, mae = 0;
+    for (int64_t i = 0; i < na; i++) {
+        float q[3] = {(float)A[3 * i], (float)A[3 * i + 1], (float)A[3 * i + 2]}; /* :75-78 */
+        int32_t id; float d;
+        kd_nn_one(tree, q, 0, &id, &d);
+        double di = (double)d;    /* :80 */
+        mse = mse + di;
+        mae = mae + sqrt(di);     /* :81 */
+    }
+    mse = mse / (double)na; mae = mae / (double)na;
+    out[0] = mse; out[1] = sqrt(mse); out[2] = mae; /* :85-97 */
+    ko_kdtree_free(tree); free(tf);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* KSSICP orchestration -- KSS_ICP.hpp:86-131 + :185-233 (down-sampled clouds given)      */
+/* ------------------------------------------------------------------------------------ */
+static void to_f32(const double *in, int64_t n3, float *out) { for (int64_t i = 0; i < n3; i++) out[i] = (float)in[i]; }
+
+static void euler_matrix(const double a[3], double R[9]) {
+    /* R0 = Rz(a2) * Ry(a1) * Rx(a0) with the reference's axis conventions (:365-404) */
+    double cx = cos(a[0]), sx = sin(a[0]), cy = cos(a[1]), sy = sin(a[1]), cz = cos(a[2]), sz = sin(a[2]);
+    double Rx[9] = {1, 0, 0, 0, cx, -sx, 0, sx, cx};
+    double Ry[9] = {cy, 0, sy, 0, 1, 0, -sy, 0, cy};
+    double Rz[9] = {cz, -sz, 0, sz, cz, 0, 0, 0, 1};
+    double tmp[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        double acc = 0; for (int k = 0; k < 3; k++) acc += Ry[3 * i + k] * Rx[3 * k + j]; tmp[3 * i + j] = acc; }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        double acc = 0; for (int k = 0; k < 3; k++) acc += Rz[3 * i + k] * tmp[3 * k + j]; R[3 * i + j] = acc; }
+}
+
+int ko_kssicp_register(const double *Ssub, int64_t nss, const double *Tsub, int64_t nts,
+                       const double *Sfull, int64_t nsf, double accurate, int iter,
+                       int use_kdtree, double *pointAlign, ko_kssicp_result *res) {
+    memset(res, 0, sizeof *res);
+    ko_preshape ps;
+    ko_preshape_stats(Ssub, nss, Tsub, nts, &ps);                       /* :62 via :87 */
+    double *Sp = (double *)malloc(sizeof(double) * 3 * (size_t)nss);
+    ko_similarity_apply(Ssub, nss, &ps, Sp);
+    int capg = 64;
+    double *value = (double *)malloc(sizeof(double) * (size_t)capg * capg * capg);
+    int cap_list = capg * capg * capg;
+    double *alist = (double *)malloc(sizeof(double) * 3 * (size_t)cap_list);
+    double best[3]; int nl = 0;
+    int g = ko_rotation_search(Sp, nss, Tsub, nts, accurate, value, capg, best, alist, &nl, cap_list);
+    if (g < 0) { free(Sp); free(value); free(alist); return -1; }
+    res->n_angle_list = nl; res->scale = ps.scale;
+
+    ko_icp_params ip; ko_icp_default_params(&ip);
+    ip.max_iterations = iter; ip.use_kdtree = use_kdtree;
+    float *tf = (float *)malloc(sizeof(float) * 3 * (size_t)nts);
+    to_f32(Tsub, 3 * nts, tf);
+    double *P = (double *)malloc(sizeof(double) * 3 * (size_t)nss);
+    float *pf = (float *)malloc(sizeof(float) * 3 * (size_t)nss);
+    ko_icp_result ir;
+
+    ko_pose_apply(Ssub, nss, &ps, best, P);                              /* :92 */
+    to_f32(P, 3 * nss, pf);
+    ko_icp(pf, nss, tf, nts, &ip, &ir, NULL);                            /* :93 Judge */
+    res->E_d_init = ir.fitness;
+    double chosen[3] = {best[0], best[1], best[2]};
+    if (res->E_d_init > 0.0005) {                                        /* :99 */
+        double Q = 9999; int angleIndex = 0;                             /* :100-101 */
+        for (int i = 0; i < nl; i++) {
+            ko_pose_apply(Ssub, nss, &ps, alist + 3 * i, P);             /* :103 */
+            to_f32(P, 3 * nss, pf);
+            ko_icp(pf, nss, tf, nts, &ip, &ir, NULL);                    /* :104 */
+            double ri = ir.fitness;
+            if (ri < Q && ri >= 0) { Q = ri; angleIndex = i; }           /* :113-116 */
+        }
+        res->used_angle_list = 1; res->angle_index = angleIndex;
+        if (nl > 0) for (int k = 0; k < 3; k++) chosen[k] = alist[3 * angleIndex + k]; /* :119-120 */
+    }
+    for (int k = 0; k < 3; k++) res->R0_angle[k] = chosen[k];
+    ko_pose_apply(Ssub, nss, &ps, chosen, P);
+    double *full = (double *)malloc(sizeof(double) * 3 * (size_t)(nsf > 0 ? nsf : 1));
+    ko_pose_apply(Sfull, nsf, &ps, chosen, full);                        /* :120 / :124 ; :127-129 */
+    to_f32(P, 3 * nss, pf);
+    ko_icp(pf, nss, tf, nts, &ip, &ir, NULL);                            /* :130 -> :185-233 */
+    res->final_fitness = ir.fitness;
+    res->icp_iterations = ir.iterations; res->icp_converged = ir.converged;
+    memcpy(res->T_icp, ir.T, sizeof ir.T);
+    for (int64_t i = 0; i < nsf; i++) {                                  /* :224-230 float coeff x double coord */
+        double x = full[3 * i], y = full[3 * i + 1], z = full[3 * i + 2];
+        for (int r = 0; r < 3; r++)
+            pointAlign[3 * i + r] = ir.T[4 * r + 0] * x + ir.T[4 * r + 1] * y + ir.T[4 * r + 2] * z + ir.T[4 * r + 3];
+    }
+    /* composite similarity, SURVEY.md section 3.1 */
+    double R0[9]; euler_matrix(chosen, R0);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        double acc = 0; for (int k = 0; k < 3; k++) acc += (double)ir.T[4 * i + k] * R0[3 * k + j]; res->R[3 * i + j] = acc; }
+    double v[3];
+    for (int k = 0; k < 3; k++) v[k] = ps.c_tgt[k] - ps.scale * ps.c_src[k];
+    for (int i = 0; i < 3; i++)
+        res->t[i] = res->R[3 * i] * v[0] + res->R[3 * i + 1] * v[1] + res->R[3 * i + 2] * v[2] + (double)ir.T[4 * i + 3];
+    free(Sp); free(value); free(alist); free(tf); free(P); free(pf); free(full);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* ASCII PLY vertex reader -- CPLYLoader::LoadModel parse rules, PlyLoad.cpp:10-114       */
+/* ------------------------------------------------------------------------------------ */
+int64_t ko_ply_load(const char *path, double **pts) {
+    *pts = NULL;
+    if (!strstr(path, ".ply")) return -10;           /* :13-15 extension test */
+    FILE *f = fopen(path, "r");
+    if (!f) return -11;                              /* :18-22 */
+    char buf[1000];
+    int nv = -1, nf = -1;
+    if (!fgets(buf, 300, f)) { fclose(f); return -12; }
+    /* :59-65 scan forward for "element vertex" */
+    while (strncmp("element vertex", buf, strlen("element vertex")) != 0)
+        if (!fgets(buf, 300, f)) { fclose(f); return -13; }
+    sscanf(buf + strlen("element vertex"), "%i", &nv);
+    /* :68-75 rewind, scan for "element face" (the reference spins forever if absent) */
+    fseek(f, 0, SEEK_SET);
+    while (strncmp("element face", buf, strlen("element face")) != 0)
+        if (!fgets(buf, 300, f)) { fclose(f); return -14; }
+    sscanf(buf + strlen("element face"), "%i", &nf);
+    /* :78-82 */
+    while (strncmp("end_header", buf, strlen("end_header")) != 0)
+        if (!fgets(buf, 300, f)) { fclose(f); return -15; }
+    if (nv < 0) { fclose(f); return -16; }
+    double *P = (double *)malloc(sizeof(double) * 3 * (size_t)(nv > 0 ? nv : 1));
+    for (int i = 0; i < nv; i++) {
+        float x = 0, y = 0, z = 0;                   /* :93-96: parsed as float, widened (:101-103) */
+        if (!fgets(buf, 300, f)) { free(P); fclose(f); return -17; }
+        sscanf(buf, "%f %f %f", &x, &y, &z);
+        P[3 * i] = x; P[3 * i + 1] = y; P[3 * i + 2] = z;
+    }
+    fclose(f);
+    *pts = P;
+    return nv;
+}
+
+/* ------------------------------------------------------------------------------------ */
+uint64_t ko_splitmix64(uint64_t seed, uint64_t counter) {
+    uint64_t z = seed + (counter + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}

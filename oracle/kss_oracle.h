@@ -1,0 +1,167 @@
+/*
+ * oracle/kss_oracle.h -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ *
+ * A plain-C restatement of the reference's registration hot path.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ * The shipped library (kss-icp_amd/csrc) never links, imports or calls anything here.
+ *
+ * PARITY PIN STATUS (see DESIGN.md "Oracle"):
+ *   - First-party arithmetic (pre-shape, Euler rotations, rotation search, 5^3 local
+ *     minimum, PCR_QM) is restated line by line from the reference headers cited at each
+ *     function and is pinned by the reference's own data fixtures (tests/golden/ref_data:
+ *     the .gird/.wlop pairs + transfer.txt known rotations + ICP.txt success/fail list).
+ *   - The ICP inner loop is PCL 1.8.1 (pcl::IterativeClosestPoint, FLANN 1-NN,
+ *     Eigen umeyama).  PCL is NOT vendored in /root/reference and is absent from this
+ *     image, and the reference has no tests / golden vectors at that boundary, so the ICP
+ *     restatement follows PCL 1.8.1's published algorithm and is
+ *     "parity unpinned" numerically beyond the qualitative ICP.txt success/fail list.
+ *
+ * All citations are path:line under /root/reference/PS_AIS_Simplification/.
+ */
+#ifndef KSS_ORACLE_H_
+#define KSS_ORACLE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- KSS pre-shape: initRegistration_MiddleAlign, initRegistrationKSS.hpp:144-220 ---- */
+typedef struct {
+    double c_src[3];      /* centroid of S                       :150-157 */
+    double c_tgt[3];      /* centroid of T  = x_middle_S..       :177-188 */
+    double shift[3];      /* c_T - c_S      = x_middle..         :190-192 */
+    double r_src;         /* mean |p - c_S|                      :160-171 */
+    double r_tgt;         /* mean |q - c_T|                      :195-207 */
+    double scale;         /* r_tgt / r_src                       :209     */
+} ko_preshape;
+
+/* stats only */
+void ko_preshape_stats(const double *S, int64_t ns, const double *T, int64_t nt, ko_preshape *out);
+/* shift + scale-about-c_T of a cloud (:212-219 and :77-84); out may alias in */
+void ko_similarity_apply(const double *in, int64_t n, const ko_preshape *ps, double *out);
+/* initRegistration_Transfer(cord, angle, cloud), :365-404; in place; cord 1:x 2:y else:z */
+void ko_axis_rotate(int cord, double angle, double *pts, int64_t n);
+/* initRegistration_Rotation / _Rotation_Angle, :75-109: similarity then Rx, Ry, Rz */
+void ko_pose_apply(const double *in, int64_t n, const ko_preshape *ps, const double angle[3], double *out);
+
+/* ---- exact 1-NN in float (stands for pcl::KdTreeFLANN<PointXYZ>::nearestKSearch, K=1) ----
+ * distance = (dx*dx + dy*dy) + dz*dz in float WITHOUT fma (FLANN L2_Simple<float>);
+ * ties resolved to the lowest target index (documented deviation: FLANN's tie order is
+ * traversal dependent). fma!=0 selects d = fma(dx,dx, fma(dy,dy, dz*dz)) ("fast" mode). */
+void ko_nn_brute(const float *q, int64_t nq, const float *t, int64_t nt, int fma, int32_t *idx, float *d2);
+
+typedef struct ko_kdtree ko_kdtree;
+ko_kdtree *ko_kdtree_build(const float *t, int64_t nt, int leaf_size /* PCL uses 15 */);
+void ko_kdtree_free(ko_kdtree *);
+/* nthreads<=1: serial (faithful to PCL 1.8.1's serial correspondence loop) */
+void ko_kdtree_nn(const ko_kdtree *, const float *q, int64_t nq, int fma, int nthreads, int32_t *idx, float *d2);
+
+/* ---- rotation search: initRegistration_Rotation(), initRegistrationKSS.hpp:222-296 ---- */
+/* number of loop trips of for(double a=0; a<6.3; a+=6.3/step) and the accumulated angles */
+int ko_grid_angles(double step, double *angles, int cap);
+/* initRegistration_Error_Ave :430-450: mean over cloud of sqrt(float d2 of NN) */
+double ko_error_ave(const double *cloud, int64_t n, const float *tgt_f32, int64_t nt, const ko_kdtree *tree_or_null);
+/* initRegistration_kernel :481-522 on value[g][g][g] (row-major i,j,k), radius r (=2) */
+int ko_local_min(const double *value, int g, int i, int j, int k, int r);
+/* full search on an already pre-shaped source S' and target T (doubles).
+ * value: g^3 doubles (caller allocates >= cap_g^3); best_angle: accumulated doubles (:259-261);
+ * angle_list: 3*n_list doubles = idx*6.3/step (:282-284).  returns g, or <0 on overflow */
+int ko_rotation_search(const double *Sp, int64_t ns, const double *T, int64_t nt, double step,
+                       double *value, int cap_g, double best_angle[3],
+                       double *angle_list, int *n_list, int cap_list);
+
+/* ---- ICP: pcl::IterativeClosestPoint<PointXYZ,PointXYZ>::align as configured at
+ *      KSS_ICP.hpp:155-162 (x5 sites); algorithm per PCL 1.8.1 ---- */
+typedef struct {
+    int    max_iterations;            /* setMaximumIterations(iter)         KSS_ICP.hpp:159 */
+    double max_corr_dist;             /* setMaxCorrespondenceDistance(1)    :156 */
+    double transformation_epsilon;    /* setTransformationEpsilon(1e-10)    :157 */
+    double euclidean_fitness_epsilon; /* setEuclideanFitnessEpsilon(0.001)  :158 -> relative MSE */
+    double abs_mse_epsilon;           /* PCL default 1e-12 */
+    int    min_correspondences;       /* PCL default 3 */
+    int    fixed_iterations;          /* !=0: run exactly max_iterations (tests 2,3 off): benchmark mode */
+    int    fma;                       /* NN distance form, see ko_nn_brute */
+    int    use_kdtree;                /* 0: brute force NN, 1: kd-tree (same results) */
+    int    nthreads;                  /* kd-tree query threads */
+    int    compute_fitness;           /* getFitnessScore() after align */
+} ko_icp_params;
+
+void ko_icp_default_params(ko_icp_params *p);
+
+enum { KO_STATE_NOT_CONVERGED = 0, KO_STATE_ITERATIONS = 1, KO_STATE_TRANSFORM = 2,
+       KO_STATE_ABS_MSE = 3, KO_STATE_REL_MSE = 4, KO_STATE_NO_CORRESPONDENCES = 5 };
+
+typedef struct {
+    float  T[16];        /* final_transformation_, row-major 4x4 (Matrix4f) */
+    int    iterations;   /* nr_iterations_ */
+    int    converged;    /* hasConverged() */
+    int    state;        /* convergence state */
+    double fitness;      /* getFitnessScore(): mean NN d2 of final*input over all source pts */
+    double last_mse;     /* mean d2 of the last iteration's correspondences */
+    double nn_seconds;   /* time spent in NN queries (baseline reporting) */
+    double build_seconds;/* kd-tree build time */
+    double total_seconds;
+} ko_icp_result;
+
+/* per-iteration trace (optional, may be NULL): for step-by-step parity tests */
+typedef struct {
+    int     cap;         /* capacity in iterations */
+    int     n;           /* iterations recorded */
+    double *sums;        /* cap * 20 doubles: [0]=count, [1..3]=sum src, [4..6]=sum tgt,
+                            [7..15]=sum src_i*tgt_j (i major), [16]=sum d2 kept,
+                            [17]=sum d2 all, [18]=sum sqrt(d2) all, [19]=0 */
+    float  *Tk;          /* cap * 16 floats: per-iteration transformation_ */
+} ko_icp_trace;
+
+int ko_icp(const float *src, int64_t ns, const float *tgt, int64_t nt,
+           const ko_icp_params *p, ko_icp_result *res, ko_icp_trace *trace);
+
+/* rigid fit from the 20 sums (Umeyama without scaling, Eigen/src/Geometry/Umeyama.h as used
+ * by pcl::registration::TransformationEstimationSVD): out Tk row-major float 4x4 */
+void ko_rigid_from_sums(const double sums[20], float Tk[16]);
+/* 3x3 SVD helper exposed for tests: A = U diag(s) V^T (row-major) */
+void ko_svd3(const double A[9], double U[9], double s[3], double V[9]);
+/* float Matrix4f helpers with Eigen's evaluation order, no fma */
+void ko_mat4_mul(const float A[16], const float B[16], float C[16]);
+void ko_transform_points_f32(const float T[16], const float *in, int64_t n, float *out);
+
+/* ---- PCR_QM: registrationMeasure.hpp:47-98 -> {MSE, RMSE, MAE} ---- */
+void ko_pcr_qm(const double *aligned, int64_t na, const double *tmpl, int64_t nt, double out[3]);
+
+/* ---- KSSICP orchestration on already down-sampled clouds: KSS_ICP.hpp:86-131,185-233 ----
+ * Ssub/Tsub: the down-sampled S', T' (AIVS output in the reference, :72-81);
+ * Sfull: full-resolution source whose aligned copy is pointAlign. */
+typedef struct {
+    double scale;            /* s */
+    double R0_angle[3];      /* chosen Euler angles */
+    int    used_angle_list;  /* E_d_init > 0.0005 branch taken (:99) */
+    int    angle_index;      /* chosen index in angleList (:113-116) */
+    int    n_angle_list;
+    double E_d_init;         /* :93 */
+    double final_fitness;    /* :130 */
+    float  T_icp[16];        /* final ICP Matrix4f (:222) */
+    double R[9], t[3];       /* composite similarity: p' = s*R*p + t */
+    int    icp_iterations;
+    int    icp_converged;
+} ko_kssicp_result;
+
+int ko_kssicp_register(const double *Ssub, int64_t nss, const double *Tsub, int64_t nts,
+                       const double *Sfull, int64_t nsf, double accurate, int iter,
+                       int use_kdtree, double *pointAlign /* nsf*3 */, ko_kssicp_result *res);
+
+/* ---- ASCII PLY vertex reader with CPLYLoader::LoadModel parse rules, PlyLoad.cpp:10-114 ----
+ * returns number of vertices (>=0) and mallocs *pts (n*3 doubles, widened from float),
+ * or <0 on error.  Unlike the reference it fails (instead of looping forever) when the
+ * 'element face' line is missing. */
+int64_t ko_ply_load(const char *path, double **pts);
+void ko_free(void *p);
+
+/* ---- synthetic clouds (portable counter-based RNG) ---- */
+uint64_t ko_splitmix64(uint64_t seed, uint64_t counter);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
