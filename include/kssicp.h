@@ -1,0 +1,208 @@
+/*
+ * kssicp.h -- C-ABI of the MI355X-native KSS-ICP registration core (libkssicp.so).
+ *
+ * This is the drop-in boundary UNDER the reference's C++ class surface: the mirror classes in
+ * include/KSS_ICP.hpp, include/initRegistrationKSS.hpp and include/registrationMeasure.hpp
+ * (same class / method / field names as the reference) call only these entry points.  The
+ * reference has no FFI of its own; each entry point below cites the
+ * reference code it replaces, as path:line under PS_AIS_Simplification/.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.  Every call returns an int
+ *     status (KSS_OK == 0, errors < 0) and never throws across the ABI.
+ *   - Clouds are packed xyz triples: float[n][3] ("f32") or double[n][3] ("f64").
+ *   - `*_dev` variants take DEVICE pointers (hipMalloc'd, or a torch tensor's data_ptr());
+ *     the un-suffixed variants take HOST pointers and stage through the context's workspace.
+ *   - One context per host thread / GPU.  Calls on one context are serialised on its HIP
+ *     stream; distinct contexts are independent (matches the reference's "objects are
+ *     independent" threading rule).
+ *   - There is NO CPU fallback: every compute entry point fails with KSS_ERR_NODEVICE /
+ *     KSS_ERR_HIP when no gfx950 device is usable.
+ */
+#ifndef KSSICP_H_
+#define KSSICP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KSS_VERSION 100 /* 0.1.0 */
+
+enum {
+    KSS_OK = 0,
+    KSS_ERR_ARG = -1,      /* null pointer, negative size, n == 0 where a cloud is required */
+    KSS_ERR_HIP = -2,      /* a HIP runtime call failed; see kss_last_error() */
+    KSS_ERR_NOMEM = -3,
+    KSS_ERR_NODEVICE = -4, /* no usable GPU */
+    KSS_ERR_CAPACITY = -5, /* caller-provided output buffer too small */
+    KSS_ERR_RCCL = -6
+};
+
+enum { KSS_F32 = 0, KSS_F64 = 1 };
+
+typedef struct kss_ctx kss_ctx;
+
+int         kss_version(void);
+const char *kss_status_string(int status);
+/* human-readable detail of the last failure on this context ("" if none) */
+const char *kss_last_error(const kss_ctx *ctx);
+
+/* ---- context ---------------------------------------------------------------------------- */
+int   kss_ctx_create(int device_id, kss_ctx **out);                 /* owns its HIP stream */
+/* borrow an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) */
+int   kss_ctx_create_on_stream(int device_id, void *hip_stream, kss_ctx **out);
+int   kss_ctx_destroy(kss_ctx *ctx);
+int   kss_ctx_synchronize(kss_ctx *ctx);
+void *kss_ctx_stream(kss_ctx *ctx);
+
+/* per-kernel timing with HIP events recorded on the context's stream around every launch of
+ * the named kernel class (used by bench.py for the roofline object). */
+enum { KSS_K_NN_SWEEP = 0, KSS_K_CORR_REDUCE = 1, KSS_K_PRESHAPE = 2, KSS_K_ROT_SEARCH = 3,
+       KSS_K_POSE_APPLY = 4, KSS_K_COUNT = 5 };
+int kss_profile_enable(kss_ctx *ctx, int on);
+int kss_profile_reset(kss_ctx *ctx);
+/* synchronises the stream; total_ms = sum of event-timed durations, launches = count */
+int kss_profile_get(kss_ctx *ctx, int kernel_class, double *total_ms, int64_t *launches);
+
+/* ---- (a2) KSS pre-shape: initRegistration_MiddleAlign, initRegistrationKSS.hpp:144-207 ----
+ * centroid (mean of points) and mean distance to the centroid, accumulated in f64 with a
+ * wavefront/LDS block reduce.  scale = r_tgt / r_src is formed by the caller (:209). */
+int kss_preshape_stats(kss_ctx *ctx, const void *xyz, int dtype, int64_t n,
+                       double centroid[3], double *mean_radius);
+int kss_preshape_stats_dev(kss_ctx *ctx, const void *d_xyz, int dtype, int64_t n,
+                           double centroid[3], double *mean_radius);
+
+/* ---- (a3,a7) pose application: initRegistration_Rotation[_Angle], :75-109 + :365-404 ----
+ * p += shift; p = center + (p - center) * scale; then Rx(angle[0]), Ry(angle[1]), Rz(angle[2])
+ * about the WORLD ORIGIN, all in f64 without fused multiply-add (reference arithmetic). */
+typedef struct {
+    double shift[3];   /* x_middle..   = c_T - c_S   (:190-192) */
+    double center[3];  /* x_middle_S.. = c_T         (:186-188) */
+    double scale;      /*                             (:209)     */
+    double angle[3];   /* Euler angles about x, y, z              */
+} kss_pose;
+int kss_pose_apply(kss_ctx *ctx, const double *in, int64_t n, const kss_pose *pose, double *out);
+int kss_pose_apply_dev(kss_ctx *ctx, const double *d_in, int64_t n, const kss_pose *pose, double *d_out);
+
+/* ---- (a8) exact 1-NN correspondence: replaces pcl::KdTreeFLANN<PointXYZ>::nearestKSearch
+ *      (call sites initRegistrationKSS.hpp:236,443; registrationMeasure.hpp:63,79; PCL ICP) ----
+ * Brute-force LDS-tiled source x target sweep in f32.  d2 = (dx*dx + dy*dy) + dz*dz without
+ * fma (FLANN L2_Simple<float>), ties -> lowest target index.  idx/d2 may be NULL. */
+int kss_nn(kss_ctx *ctx, const float *src, int64_t ns, const float *tgt, int64_t nt,
+           int32_t *idx, float *d2);
+int kss_nn_dev(kss_ctx *ctx, const float *d_src, int64_t ns, const float *d_tgt, int64_t nt,
+               int32_t *d_idx, float *d_d2);
+
+/* ---- (a10) correspondence sums for TransformationEstimationSVD / umeyama (inside PCL ICP) ----
+ * sums[0]=n kept (d2 <= max_d2), [1..3]=sum src, [4..6]=sum tgt[idx], [7..15]=sum src_i*tgt_j
+ * (i major), [16]=sum d2 kept, [17]=sum d2 all, [18]=sum sqrt(d2) all, [19]=0.  f64, reduced
+ * in a fixed order (bitwise reproducible run to run). */
+#define KSS_NSUMS 20
+int kss_cov(kss_ctx *ctx, const float *src, const float *tgt, const int32_t *idx, int64_t n,
+            int64_t nt, double max_d2, double sums[KSS_NSUMS]);
+int kss_cov_dev(kss_ctx *ctx, const float *d_src, const float *d_tgt, const int32_t *d_idx, int64_t n,
+                int64_t nt, double max_d2, double sums[KSS_NSUMS]);
+/* host-side: rigid transform (Umeyama without scaling, 3x3 SVD) from the sums; row-major 4x4 */
+int kss_rigid_from_sums(const double sums[KSS_NSUMS], float T[16]);
+
+/* ---- (a4,a5) rotation search: initRegistration_Rotation(), :222-296 + :430-450 ----
+ * src_preshaped: S' after the similarity of kss_pose_apply with angle = 0 (f64);
+ * err receives value[g][g][g] (i-major), g = trip count of for(a=0; a<6.3; a+=6.3/step). */
+int kss_rotation_search(kss_ctx *ctx, const double *src_preshaped, int64_t ns,
+                        const double *tgt, int64_t nt, double step,
+                        double *err, int64_t err_capacity, int *g_out);
+int kss_rotation_search_dev(kss_ctx *ctx, const double *d_src_preshaped, int64_t ns,
+                            const double *d_tgt, int64_t nt, double step,
+                            double *err /* host */, int64_t err_capacity, int *g_out);
+/* host-side (a6): accumulated grid angles (:245), global arg-min (:258-265, :291-293) and the
+ * 5^3 clamped local-minimum list (:276-289, :481-522).  angle_list = idx*6.3/step triples. */
+int kss_grid_angles(double step, double *angles, int capacity);
+int kss_rotation_candidates(const double *err, int g, double step, double best_angle[3],
+                            double *angle_list, int list_capacity, int *n_list);
+
+/* ---- (a9,a11,a12) ICP driver: pcl::IterativeClosestPoint::align as configured at
+ *      KSS_ICP.hpp:155-162 (x5), PCL 1.8.1 semantics ---- */
+typedef struct {
+    int    max_iterations;             /* setMaximumIterations            KSS_ICP.hpp:159 */
+    double max_corr_dist;              /* setMaxCorrespondenceDistance(1) :156 */
+    double transformation_epsilon;     /* setTransformationEpsilon(1e-10) :157 */
+    double euclidean_fitness_epsilon;  /* setEuclideanFitnessEpsilon(1e-3):158 */
+    double abs_mse_epsilon;            /* PCL default 1e-12 */
+    int    min_correspondences;        /* PCL default 3 */
+    int    fixed_iterations;           /* run exactly max_iterations (benchmark mode) */
+    int    nn_fma;                     /* 0: reference arithmetic; 1: fused d2 (fast, not bit-parity) */
+    int    compute_fitness;            /* getFitnessScore() after align (:164) */
+    int    nn_sources_per_thread;      /* tuning, 0 = auto */
+    int    nn_target_splits;           /* tuning, 0 = auto */
+    /* optional per-iteration trace for parity tests (host pointers, may be NULL) */
+    double *trace_sums;                /* trace_cap * KSS_NSUMS */
+    float  *trace_Tk;                  /* trace_cap * 16 */
+    int     trace_cap;
+    int    *trace_n;
+} kss_icp_params;
+
+enum { KSS_STATE_NOT_CONVERGED = 0, KSS_STATE_ITERATIONS = 1, KSS_STATE_TRANSFORM = 2,
+       KSS_STATE_ABS_MSE = 3, KSS_STATE_REL_MSE = 4, KSS_STATE_NO_CORRESPONDENCES = 5 };
+
+typedef struct {
+    float   T[16];       /* getFinalTransformation(), row-major Matrix4f  (:222) */
+    double  fitness;     /* getFitnessScore()                             (:164) */
+    double  last_mse;
+    int32_t iterations;
+    int32_t converged;   /* hasConverged() */
+    int32_t state;
+    int32_t pair_id;     /* index of the pair in a batch (global id after a gather) */
+} kss_icp_result;       /* 96 bytes: the record gathered over RCCL */
+
+int kss_icp_default_params(kss_icp_params *p);
+int kss_icp(kss_ctx *ctx, const float *src, int64_t ns, const float *tgt, int64_t nt,
+            const kss_icp_params *p, kss_icp_result *res);
+int kss_icp_dev(kss_ctx *ctx, const float *d_src, int64_t ns, const float *d_tgt, int64_t nt,
+                const kss_icp_params *p, kss_icp_result *res);
+/* batch of independent registrations (KSS_ICP.hpp:102-118 candidate loop; configs C3/C5).
+ * src_off/tgt_off: npairs+1 HOST offsets (in points) into the packed clouds. */
+int kss_icp_batch(kss_ctx *ctx, const float *src_all, const int64_t *src_off,
+                  const float *tgt_all, const int64_t *tgt_off, int npairs,
+                  const kss_icp_params *p, kss_icp_result *results);
+int kss_icp_batch_dev(kss_ctx *ctx, const float *d_src_all, const int64_t *src_off,
+                      const float *d_tgt_all, const int64_t *tgt_off, int npairs,
+                      const kss_icp_params *p, kss_icp_result *results);
+
+/* ---- (a13) apply the ICP Matrix4f to a full-resolution f64 cloud, KSS_ICP.hpp:224-230 ---- */
+int kss_transform_apply(kss_ctx *ctx, const float T[16], const double *in, int64_t n, double *out);
+int kss_transform_apply_dev(kss_ctx *ctx, const float T[16], const double *d_in, int64_t n, double *d_out);
+
+/* ---- PCR_QM: registrationMeasure.hpp:47-98 -> out = {MSE, RMSE, MAE} ---- */
+int kss_pcr_qm(kss_ctx *ctx, const double *aligned, int64_t na, const double *tmpl, int64_t nt,
+               double out[3]);
+
+/* ---- (a16) KSSICP_Registration on already down-sampled clouds, KSS_ICP.hpp:86-131 + :185-233 */
+typedef struct {
+    double  scale;
+    double  angle[3];         /* chosen Euler angles */
+    double  R[9], t[3];       /* composite similarity p' = scale*R*p + t */
+    float   T_icp[16];
+    double  E_d_init;         /* :93 */
+    double  final_fitness;    /* :130 */
+    int32_t used_angle_list;  /* :99 branch */
+    int32_t angle_index;
+    int32_t n_angle_list;
+    int32_t icp_iterations;
+    int32_t icp_converged;
+    int32_t grid;             /* g */
+} kss_register_result;
+int kss_register(kss_ctx *ctx, const double *src_sub, int64_t nss, const double *tgt_sub, int64_t nts,
+                 const double *src_full, int64_t nsf, double accurate, int iter,
+                 double *point_align /* nsf*3, may be NULL */, kss_register_result *res);
+
+/* ---- (8e) gather of per-pair result records over RCCL (ncclComm_t passed as void*) ----
+ * all must hold world_size * n_local records; every rank receives every record. */
+int kss_gather_results(kss_ctx *ctx, void *rccl_comm, int world_size,
+                       const kss_icp_result *local, int n_local, kss_icp_result *all);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KSSICP_H_ */

@@ -1,0 +1,964 @@
+// kss_api.hip -- C-ABI (include/kssicp.h) and host-side drivers of the registration core.
+//
+// Host code only orchestrates: per ICP iteration it launches the NN sweep + correspondence reduce,
+// copies 20 doubles per pair back, solves the 3x3 SVD (kss_host_math.hpp) and evaluates the PCL
+// convergence criteria.  There is no CPU compute fallback anywhere in this file.
+#pragma clang fp contract(off)
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kss_internal.hpp"
+
+using namespace kss;
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct kss_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // grow-only device workspace
+    DevBuf tgt4, src0, cur[2], keys, partials, sums, nn_work, red_work, pair_red, state, cs, scratch_a,
+        scratch_b, scratch_c, stage_src, stage_tgt, stage_idx, stage_d2, stage_out;
+    // pinned host staging
+    void* h_sums = nullptr;  size_t h_sums_cap = 0;
+    void* h_state = nullptr; size_t h_state_cap = 0;
+
+    // profiling
+    bool prof = false;
+    struct EvPair { hipEvent_t a, b; };
+    std::vector<EvPair> ev[KSS_K_COUNT];
+    double prof_ms[KSS_K_COUNT] = {0};
+    int64_t prof_n[KSS_K_COUNT] = {0};
+};
+
+static int set_err(kss_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
+    if (c) {
+        c->err = what;
+        if (e != hipSuccess) { c->err += ": "; c->err += hipGetErrorString(e); }
+    }
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                        \
+    do {                                                                         \
+        hipError_t e_ = (call);                                                  \
+        if (e_ != hipSuccess) return set_err((ctx), KSS_ERR_HIP, #call, e_);     \
+    } while (0)
+
+static int ensure(kss_ctx* c, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return KSS_OK;
+    if (b.p) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(b.p));
+        b.p = nullptr; b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) { b.p = nullptr; return set_err(c, KSS_ERR_NOMEM, "hipMalloc", e); }
+    b.cap = want;
+    return KSS_OK;
+}
+
+static int ensure_pinned(kss_ctx* c, void*& p, size_t& cap, size_t bytes) {
+    if (bytes <= cap) return KSS_OK;
+    if (p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipHostFree(p)); p = nullptr; cap = 0; }
+    size_t want = bytes * 2 + 256;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e != hipSuccess) { p = nullptr; return set_err(c, KSS_ERR_NOMEM, "hipHostMalloc", e); }
+    cap = want;
+    return KSS_OK;
+}
+
+#define KCHK(expr)                     \
+    do {                               \
+        int rc_ = (expr);              \
+        if (rc_ != KSS_OK) return rc_; \
+    } while (0)
+
+struct ProfScope {   // records a start/stop event pair around a launch when profiling is on
+    kss_ctx* c; int k; kss_ctx::EvPair ep; bool on;
+    ProfScope(kss_ctx* c_, int k_) : c(c_), k(k_), on(c_->prof) {
+        if (!on) return;
+        if (hipEventCreate(&ep.a) != hipSuccess || hipEventCreate(&ep.b) != hipSuccess) { on = false; return; }
+        hipEventRecord(ep.a, c->stream);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        hipEventRecord(ep.b, c->stream);
+        c->ev[k].push_back(ep);
+    }
+};
+
+static void prof_collect(kss_ctx* c) {
+    for (int k = 0; k < KSS_K_COUNT; ++k) {
+        for (auto& ep : c->ev[k]) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) { c->prof_ms[k] += ms; c->prof_n[k] += 1; }
+            hipEventDestroy(ep.a);
+            hipEventDestroy(ep.b);
+        }
+        c->ev[k].clear();
+    }
+}
+
+extern "C" {
+
+int kss_version(void) { return KSS_VERSION; }
+
+const char* kss_status_string(int s) {
+    switch (s) {
+        case KSS_OK: return "ok";
+        case KSS_ERR_ARG: return "invalid argument";
+        case KSS_ERR_HIP: return "HIP runtime error";
+        case KSS_ERR_NOMEM: return "out of memory";
+        case KSS_ERR_NODEVICE: return "no usable GPU device";
+        case KSS_ERR_CAPACITY: return "output buffer too small";
+        case KSS_ERR_RCCL: return "RCCL error";
+        default: return "unknown status";
+    }
+}
+
+const char* kss_last_error(const kss_ctx* ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+static int ctx_create_common(int device_id, void* stream, bool borrow, kss_ctx** out) {
+    if (!out) return KSS_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return KSS_ERR_NODEVICE;
+    if (device_id < 0 || device_id >= n) return KSS_ERR_ARG;
+    if (hipSetDevice(device_id) != hipSuccess) return KSS_ERR_NODEVICE;
+    kss_ctx* c = new (std::nothrow) kss_ctx();
+    if (!c) return KSS_ERR_NOMEM;
+    c->device = device_id;
+    if (borrow) {
+        c->stream = (hipStream_t)stream;
+        c->own_stream = false;
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return KSS_ERR_HIP; }
+        c->own_stream = true;
+    }
+    *out = c;
+    return KSS_OK;
+}
+
+int kss_ctx_create(int device_id, kss_ctx** out) { return ctx_create_common(device_id, nullptr, false, out); }
+int kss_ctx_create_on_stream(int device_id, void* hip_stream, kss_ctx** out) {
+    return ctx_create_common(device_id, hip_stream, true, out);
+}
+
+int kss_ctx_destroy(kss_ctx* c) {
+    if (!c) return KSS_ERR_ARG;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    DevBuf* bufs[] = {&c->tgt4, &c->src0, &c->cur[0], &c->cur[1], &c->keys, &c->partials, &c->sums, &c->nn_work,
+                      &c->red_work, &c->pair_red, &c->state, &c->cs, &c->scratch_a, &c->scratch_b, &c->scratch_c,
+                      &c->stage_src, &c->stage_tgt, &c->stage_idx, &c->stage_d2, &c->stage_out};
+    for (DevBuf* b : bufs)
+        if (b->p) hipFree(b->p);
+    if (c->h_sums) hipHostFree(c->h_sums);
+    if (c->h_state) hipHostFree(c->h_state);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+    return KSS_OK;
+}
+
+int kss_ctx_synchronize(kss_ctx* c) {
+    if (!c) return KSS_ERR_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KSS_OK;
+}
+
+void* kss_ctx_stream(kss_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int kss_profile_enable(kss_ctx* c, int on) {
+    if (!c) return KSS_ERR_ARG;
+    c->prof = on != 0;
+    return KSS_OK;
+}
+int kss_profile_reset(kss_ctx* c) {
+    if (!c) return KSS_ERR_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    for (int k = 0; k < KSS_K_COUNT; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
+    return KSS_OK;
+}
+int kss_profile_get(kss_ctx* c, int k, double* total_ms, int64_t* launches) {
+    if (!c || k < 0 || k >= KSS_K_COUNT) return KSS_ERR_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    if (total_ms) *total_ms = c->prof_ms[k];
+    if (launches) *launches = c->prof_n[k];
+    return KSS_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// ICP plan: how pairs, source blocks and target splits map onto workgroups
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct PairGeom {
+    int64_t ns, nt;
+    int32_t src_base;      // first source in the float4 source arrays
+    int32_t tgt_base;      // first (padded) target in tgt4
+    int32_t tgt_pad;       // padded target count = n_split * chunk
+    int32_t n_split, chunk;
+    int32_t key_base;
+    int32_t n_src_blocks;
+};
+
+struct IcpPlan {
+    int npairs = 0, S = 4;
+    std::vector<PairGeom> g;
+    std::vector<NNWork> nn;
+    std::vector<RedWork> red;
+    std::vector<PairRed> pred;
+    int64_t total_src = 0, total_tgt_pad = 0, total_keys = 0;
+    bool shared_target = false;
+};
+
+int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npairs, bool shared_target,
+               int S_req, int split_req, IcpPlan& pl) {
+    pl.npairs = npairs;
+    pl.shared_target = shared_target;
+    int64_t tot = 0;
+    for (int p = 0; p < npairs; ++p) {
+        if (ns[p] <= 0 || nt[p] <= 0) return set_err(c, KSS_ERR_ARG, "empty cloud in ICP pair");
+        tot += ns[p];
+    }
+    int S = S_req;
+    if (S != 1 && S != 2 && S != 4 && S != 8) S = tot >= 32768 ? 4 : (tot >= 8192 ? 2 : 1);
+    pl.S = S;
+    const int per_block = NN_THREADS * S;
+    int64_t src_blocks_total = 0;
+    for (int p = 0; p < npairs; ++p) src_blocks_total += (ns[p] + per_block - 1) / per_block;
+    // enough workgroups to keep 256 CUs x 8 resident workgroups busy with >= 2 rounds
+    int64_t want_split = 1;
+    if (src_blocks_total < 2048) want_split = (4096 + src_blocks_total - 1) / src_blocks_total;
+    if (split_req > 0) want_split = split_req;
+
+    pl.g.resize(npairs);
+    int64_t sb = 0, tb = 0, kb = 0;
+    for (int p = 0; p < npairs; ++p) {
+        PairGeom& g = pl.g[p];
+        g.ns = ns[p]; g.nt = nt[p];
+        const int64_t tiles = (nt[p] + NN_TILE - 1) / NN_TILE;
+        int64_t split = std::min<int64_t>(want_split, std::max<int64_t>(1, tiles / 2));
+        int64_t chunk_tiles = (tiles + split - 1) / split;
+        split = (tiles + chunk_tiles - 1) / chunk_tiles;
+        g.n_split = (int32_t)split;
+        g.chunk = (int32_t)(chunk_tiles * NN_TILE);
+        g.tgt_pad = g.n_split * g.chunk;
+        g.src_base = (int32_t)sb;
+        g.key_base = (int32_t)kb;
+        g.n_src_blocks = (int32_t)((ns[p] + per_block - 1) / per_block);
+        if (shared_target && p > 0) {
+            g.tgt_base = pl.g[0].tgt_base;
+        } else {
+            g.tgt_base = (int32_t)tb;
+            tb += g.tgt_pad;
+        }
+        sb += ns[p];
+        kb += (int64_t)g.n_split * ns[p];
+        if (sb > 0x7fff0000ll || tb > 0x7fff0000ll || kb > 0x7fff0000ll)
+            return set_err(c, KSS_ERR_ARG, "problem too large for 32-bit indexing");
+    }
+    pl.total_src = sb; pl.total_tgt_pad = tb; pl.total_keys = kb;
+
+    pl.nn.clear(); pl.red.clear(); pl.pred.resize(npairs);
+    int32_t prow = 0;
+    for (int p = 0; p < npairs; ++p) {
+        const PairGeom& g = pl.g[p];
+        for (int b = 0; b < g.n_src_blocks; ++b)
+            for (int s = 0; s < g.n_split; ++s) {
+                NNWork w;
+                w.pair = p;
+                w.src_begin = g.src_base + b * per_block;
+                w.src_count = (int32_t)std::min<int64_t>(per_block, g.ns - (int64_t)b * per_block);
+                w.tgt_begin = g.tgt_base + s * g.chunk;
+                w.tgt_count = g.chunk;
+                w.tgt_pair_base = g.tgt_base;
+                w.key_begin = g.key_base + (int32_t)((int64_t)s * g.ns) + b * per_block;
+                w.write_src = s == 0;
+                pl.nn.push_back(w);
+            }
+        pl.pred[p].first = prow;
+        const int nrb = (int)((g.ns + 255) / 256);
+        for (int b = 0; b < nrb; ++b) {
+            RedWork r;
+            r.pair = p;
+            r.src_begin = g.src_base + b * 256;
+            r.src_count = (int32_t)std::min<int64_t>(256, g.ns - (int64_t)b * 256);
+            r.key_begin = g.key_base + b * 256;
+            r.key_stride = (int32_t)g.ns;
+            r.n_split = g.n_split;
+            r.tgt_pair_base = g.tgt_base;
+            r.partial_index = prow++;
+            pl.red.push_back(r);
+        }
+        pl.pred[p].count = nrb;
+    }
+    return KSS_OK;
+}
+
+// Upload plan tables and size the workspace.
+int stage_plan(kss_ctx* c, const IcpPlan& pl) {
+    KCHK(ensure(c, c->tgt4, (size_t)pl.total_tgt_pad * sizeof(float4)));
+    KCHK(ensure(c, c->src0, (size_t)pl.total_src * sizeof(float4)));
+    KCHK(ensure(c, c->cur[0], (size_t)pl.total_src * sizeof(float4)));
+    KCHK(ensure(c, c->cur[1], (size_t)pl.total_src * sizeof(float4)));
+    KCHK(ensure(c, c->keys, (size_t)pl.total_keys * sizeof(unsigned long long)));
+    KCHK(ensure(c, c->partials, pl.red.size() * NSUMS * sizeof(double)));
+    KCHK(ensure(c, c->sums, (size_t)pl.npairs * NSUMS * sizeof(double)));
+    KCHK(ensure(c, c->nn_work, pl.nn.size() * sizeof(NNWork)));
+    KCHK(ensure(c, c->red_work, pl.red.size() * sizeof(RedWork)));
+    KCHK(ensure(c, c->pair_red, pl.pred.size() * sizeof(PairRed)));
+    KCHK(ensure(c, c->state, (size_t)pl.npairs * sizeof(PairState)));
+    KCHK(ensure_pinned(c, c->h_sums, c->h_sums_cap, (size_t)pl.npairs * NSUMS * sizeof(double)));
+    KCHK(ensure_pinned(c, c->h_state, c->h_state_cap, (size_t)pl.npairs * sizeof(PairState)));
+    HIPCHK(c, hipMemcpyAsync(c->nn_work.p, pl.nn.data(), pl.nn.size() * sizeof(NNWork), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->red_work.p, pl.red.data(), pl.red.size() * sizeof(RedWork), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->pair_red.p, pl.pred.data(), pl.pred.size() * sizeof(PairRed), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // the std::vector sources may die after return
+    return KSS_OK;
+}
+
+// Pack the clouds of every pair into the float4 workspace (targets sentinel padded).
+// dtype: KSS_F32 / KSS_F64 packed triples on the DEVICE; src_off/tgt_off in points.
+int pack_clouds(kss_ctx* c, const IcpPlan& pl, const void* d_src, const int64_t* src_off, const void* d_tgt,
+                const int64_t* tgt_off, int dtype) {
+    const size_t esz = dtype == KSS_F64 ? sizeof(double) : sizeof(float);
+    // sources are contiguous in both layouts
+    {
+        const char* base = (const char*)d_src + (size_t)src_off[0] * 3 * esz;
+        if (dtype == KSS_F64) launch_pack_f64_to_f4(c->stream, (const double*)base, pl.total_src, (float4*)c->src0.p, pl.total_src, false);
+        else launch_pack_f3_to_f4(c->stream, (const float*)base, pl.total_src, (float4*)c->src0.p, pl.total_src, false);
+    }
+    const int ntp = pl.shared_target ? 1 : pl.npairs;
+    for (int p = 0; p < ntp; ++p) {
+        const PairGeom& g = pl.g[p];
+        const char* base = (const char*)d_tgt + (size_t)tgt_off[p] * 3 * esz;
+        float4* out = (float4*)c->tgt4.p + g.tgt_base;
+        if (dtype == KSS_F64) launch_pack_f64_to_f4(c->stream, (const double*)base, g.nt, out, g.tgt_pad, true);
+        else launch_pack_f3_to_f4(c->stream, (const float*)base, g.nt, out, g.tgt_pad, true);
+    }
+    HIPCHK(c, hipGetLastError());
+    return KSS_OK;
+}
+
+// One NN sweep + correspondence reduce over every active pair.  h_sums receives npairs*NSUMS.
+int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, float4* d_out, double max_d2,
+            int32_t* d_idx_out, float* d_d2_out) {
+    PairState* hs = (PairState*)c->h_state;
+    HIPCHK(c, hipMemcpyAsync(c->state.p, hs, (size_t)pl.npairs * sizeof(PairState), hipMemcpyHostToDevice, c->stream));
+    {
+        ProfScope ps(c, KSS_K_NN_SWEEP);
+        launch_nn_sweep(c->stream, pl.S, fma, (const NNWork*)c->nn_work.p, (int)pl.nn.size(), (const PairState*)c->state.p,
+                        d_in, d_out, (const float4*)c->tgt4.p, (unsigned long long*)c->keys.p);
+    }
+    {
+        ProfScope ps(c, KSS_K_CORR_REDUCE);
+        launch_corr_reduce(c->stream, (const RedWork*)c->red_work.p, (int)pl.red.size(), (const PairState*)c->state.p,
+                           d_out, (const float4*)c->tgt4.p, (const unsigned long long*)c->keys.p, max_d2,
+                           (double*)c->partials.p, d_idx_out, d_d2_out);
+        launch_finalize_sums(c->stream, (const PairRed*)c->pair_red.p, pl.npairs, (const double*)c->partials.p, (double*)c->sums.p);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_sums, c->sums.p, (size_t)pl.npairs * NSUMS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KSS_OK;
+}
+
+void set_state(PairState& s, const float T[16], int active, int apply) {
+    for (int k = 0; k < 12; ++k) s.m[k] = T[k];
+    s.active = active; s.apply = apply; s.pad[0] = s.pad[1] = 0;
+}
+
+// The ICP loop over a packed workspace (src0/tgt4 already filled).
+int icp_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P, kss_icp_result* results) {
+    const int np = pl.npairs;
+    std::vector<Convergence> conv(np);
+    std::vector<float> fin((size_t)np * 16), Tk((size_t)np * 16);
+    std::vector<int> iters(np, 0), active(np, 1), converged(np, 0), state(np, 0);
+    std::vector<double> last_mse(np, 0.0);
+    PairState* hs = (PairState*)c->h_state;
+    float I[16];
+    mat4_identity(I);
+    for (int p = 0; p < np; ++p) {
+        Convergence& cv = conv[p];
+        cv.max_iterations = P.max_iterations;
+        cv.rotation_threshold = 1.0 - P.transformation_epsilon;
+        cv.translation_threshold = P.transformation_epsilon;
+        cv.mse_rel = P.euclidean_fitness_epsilon;
+        cv.mse_abs = P.abs_mse_epsilon;
+        cv.fixed_iterations = P.fixed_iterations != 0;
+        mat4_identity(&fin[(size_t)p * 16]);
+        set_state(hs[p], I, 1, 0);
+    }
+    const double max_d2 = P.max_corr_dist * P.max_corr_dist;
+    const double* hsum = (const double*)c->h_sums;
+    if (P.trace_n) *P.trace_n = 0;
+    int n_active = P.max_iterations > 0 ? np : 0;
+    if (P.max_iterations <= 0)
+        for (int p = 0; p < np; ++p) { active[p] = 0; }
+    int it = 0;
+    while (n_active > 0) {
+        const float4* d_in = it == 0 ? (const float4*)c->src0.p : (const float4*)c->cur[(it - 1) & 1].p;
+        float4* d_out = (float4*)c->cur[it & 1].p;
+        KCHK(nn_pass(c, pl, P.nn_fma != 0, d_in, d_out, max_d2, nullptr, nullptr));
+        for (int p = 0; p < np; ++p) {
+            if (!active[p]) continue;
+            const double* s = hsum + (size_t)p * NSUMS;
+            if ((int)s[0] < P.min_correspondences) {   // PCL: "Not enough correspondences found"
+                state[p] = KSS_STATE_NO_CORRESPONDENCES; converged[p] = 0; active[p] = 0; --n_active;
+                set_state(hs[p], I, 0, 0);
+                continue;
+            }
+            float* tk = &Tk[(size_t)p * 16];
+            rigid_from_sums(s, tk);
+            mat4_mul(tk, &fin[(size_t)p * 16], &fin[(size_t)p * 16]);   // final = transformation_ * final
+            ++iters[p];
+            const double mse = s[16] / s[0];
+            last_mse[p] = mse;
+            if (p == 0 && P.trace_n && *P.trace_n < P.trace_cap) {
+                if (P.trace_sums) std::memcpy(P.trace_sums + (size_t)(*P.trace_n) * NSUMS, s, NSUMS * sizeof(double));
+                if (P.trace_Tk) std::memcpy(P.trace_Tk + (size_t)(*P.trace_n) * 16, tk, 16 * sizeof(float));
+                ++*P.trace_n;
+            }
+            const bool done = conv[p].has_converged(iters[p], tk, mse);
+            state[p] = conv[p].state;
+            if (done) {
+                converged[p] = 1; active[p] = 0; --n_active;
+                set_state(hs[p], tk, 0, 1);
+            } else {
+                set_state(hs[p], tk, 1, 1);   // next sweep applies T_k on load (transformCloud)
+            }
+        }
+        ++it;
+    }
+    for (int p = 0; p < np; ++p) {
+        kss_icp_result& r = results[p];
+        std::memcpy(r.T, &fin[(size_t)p * 16], 16 * sizeof(float));
+        r.iterations = iters[p]; r.converged = converged[p]; r.state = state[p];
+        r.last_mse = last_mse[p]; r.fitness = 0.0; r.pair_id = p;
+    }
+    if (P.compute_fitness) {
+        // getFitnessScore(): NN of final * ORIGINAL input, mean d2 over all source points
+        for (int p = 0; p < np; ++p) set_state(hs[p], &fin[(size_t)p * 16], 1, 1);
+        KCHK(nn_pass(c, pl, P.nn_fma != 0, (const float4*)c->src0.p, (float4*)c->cur[0].p, max_d2, nullptr, nullptr));
+        for (int p = 0; p < np; ++p) results[p].fitness = hsum[(size_t)p * NSUMS + 17] / (double)pl.g[p].ns;
+    }
+    return KSS_OK;
+}
+
+int icp_run_dev(kss_ctx* c, const void* d_src, const int64_t* src_off, const void* d_tgt, const int64_t* tgt_off,
+                int npairs, bool shared_target, int dtype, const kss_icp_params* p, kss_icp_result* results) {
+    if (!c || !d_src || !d_tgt || !src_off || !tgt_off || !p || !results || npairs <= 0) return set_err(c, KSS_ERR_ARG, "icp: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<int64_t> ns(npairs), nt(npairs);
+    for (int i = 0; i < npairs; ++i) {
+        ns[i] = src_off[i + 1] - src_off[i];
+        nt[i] = shared_target ? tgt_off[1] - tgt_off[0] : tgt_off[i + 1] - tgt_off[i];
+    }
+    IcpPlan pl;
+    KCHK(build_plan(c, ns.data(), nt.data(), npairs, shared_target, p->nn_sources_per_thread, p->nn_target_splits, pl));
+    KCHK(stage_plan(c, pl));
+    KCHK(pack_clouds(c, pl, d_src, src_off, d_tgt, tgt_off, dtype));
+    return icp_loop(c, pl, *p, results);
+}
+
+// host -> device staging of a packed cloud
+int upload(kss_ctx* c, DevBuf& b, const void* h, size_t bytes) {
+    KCHK(ensure(c, b, bytes));
+    HIPCHK(c, hipMemcpyAsync(b.p, h, bytes, hipMemcpyHostToDevice, c->stream));
+    return KSS_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C-ABI: compute entry points
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int kss_icp_default_params(kss_icp_params* p) {
+    if (!p) return KSS_ERR_ARG;
+    std::memset(p, 0, sizeof *p);
+    p->max_iterations = 1000;             // Main_KSS_ICP.cpp:81
+    p->max_corr_dist = 1.0;               // KSS_ICP.hpp:156
+    p->transformation_epsilon = 1e-10;    // :157
+    p->euclidean_fitness_epsilon = 0.001; // :158
+    p->abs_mse_epsilon = 1e-12;
+    p->min_correspondences = 3;
+    p->compute_fitness = 1;
+    return KSS_OK;
+}
+
+int kss_icp_dev(kss_ctx* c, const float* d_src, int64_t ns, const float* d_tgt, int64_t nt,
+                const kss_icp_params* p, kss_icp_result* res) {
+    if (!c) return KSS_ERR_ARG;
+    if (ns <= 0 || nt <= 0) return set_err(c, KSS_ERR_ARG, "icp: empty cloud");
+    const int64_t so[2] = {0, ns}, to[2] = {0, nt};
+    return icp_run_dev(c, d_src, so, d_tgt, to, 1, false, KSS_F32, p, res);
+}
+
+int kss_icp(kss_ctx* c, const float* src, int64_t ns, const float* tgt, int64_t nt,
+            const kss_icp_params* p, kss_icp_result* res) {
+    if (!c || !src || !tgt) return set_err(c, KSS_ERR_ARG, "icp: null cloud");
+    if (ns <= 0 || nt <= 0) return set_err(c, KSS_ERR_ARG, "icp: empty cloud");
+    HIPCHK(c, hipSetDevice(c->device));
+    KCHK(upload(c, c->stage_src, src, (size_t)ns * 3 * sizeof(float)));
+    KCHK(upload(c, c->stage_tgt, tgt, (size_t)nt * 3 * sizeof(float)));
+    return kss_icp_dev(c, (const float*)c->stage_src.p, ns, (const float*)c->stage_tgt.p, nt, p, res);
+}
+
+int kss_icp_batch_dev(kss_ctx* c, const float* d_src_all, const int64_t* src_off, const float* d_tgt_all,
+                      const int64_t* tgt_off, int npairs, const kss_icp_params* p, kss_icp_result* results) {
+    if (!c) return KSS_ERR_ARG;
+    return icp_run_dev(c, d_src_all, src_off, d_tgt_all, tgt_off, npairs, false, KSS_F32, p, results);
+}
+
+int kss_icp_batch(kss_ctx* c, const float* src_all, const int64_t* src_off, const float* tgt_all,
+                  const int64_t* tgt_off, int npairs, const kss_icp_params* p, kss_icp_result* results) {
+    if (!c || !src_all || !tgt_all || !src_off || !tgt_off || npairs <= 0) return set_err(c, KSS_ERR_ARG, "icp_batch: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t s0 = src_off[0], s1 = src_off[npairs], t0 = tgt_off[0], t1 = tgt_off[npairs];
+    if (s1 <= s0 || t1 <= t0) return set_err(c, KSS_ERR_ARG, "icp_batch: empty batch");
+    KCHK(upload(c, c->stage_src, src_all + 3 * s0, (size_t)(s1 - s0) * 3 * sizeof(float)));
+    KCHK(upload(c, c->stage_tgt, tgt_all + 3 * t0, (size_t)(t1 - t0) * 3 * sizeof(float)));
+    std::vector<int64_t> so(npairs + 1), to(npairs + 1);
+    for (int i = 0; i <= npairs; ++i) { so[i] = src_off[i] - s0; to[i] = tgt_off[i] - t0; }
+    return icp_run_dev(c, c->stage_src.p, so.data(), c->stage_tgt.p, to.data(), npairs, false, KSS_F32, p, results);
+}
+
+// ---- NN -----------------------------------------------------------------------------------------
+static int nn_generic_dev(kss_ctx* c, const void* d_src, int64_t ns, const void* d_tgt, int64_t nt, int dtype,
+                          int32_t* d_idx, float* d_d2, double sums_out[NSUMS]) {
+    if (!c || !d_src || !d_tgt) return set_err(c, KSS_ERR_ARG, "nn: null cloud");
+    if (ns <= 0 || nt <= 0) return set_err(c, KSS_ERR_ARG, "nn: empty cloud");
+    HIPCHK(c, hipSetDevice(c->device));
+    IcpPlan pl;
+    KCHK(build_plan(c, &ns, &nt, 1, false, 0, 0, pl));
+    KCHK(stage_plan(c, pl));
+    const int64_t so[2] = {0, ns}, to[2] = {0, nt};
+    KCHK(pack_clouds(c, pl, d_src, so, d_tgt, to, dtype));
+    float I[16];
+    mat4_identity(I);
+    set_state(((PairState*)c->h_state)[0], I, 1, 0);
+    KCHK(nn_pass(c, pl, false, (const float4*)c->src0.p, (float4*)c->cur[0].p, 1e300, d_idx, d_d2));
+    if (sums_out) std::memcpy(sums_out, c->h_sums, NSUMS * sizeof(double));
+    return KSS_OK;
+}
+
+int kss_nn_dev(kss_ctx* c, const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int32_t* d_idx, float* d_d2) {
+    return nn_generic_dev(c, d_src, ns, d_tgt, nt, KSS_F32, d_idx, d_d2, nullptr);
+}
+
+int kss_nn(kss_ctx* c, const float* src, int64_t ns, const float* tgt, int64_t nt, int32_t* idx, float* d2) {
+    if (!c || !src || !tgt) return set_err(c, KSS_ERR_ARG, "nn: null cloud");
+    if (ns <= 0 || nt <= 0) return set_err(c, KSS_ERR_ARG, "nn: empty cloud");
+    HIPCHK(c, hipSetDevice(c->device));
+    KCHK(upload(c, c->stage_src, src, (size_t)ns * 3 * sizeof(float)));
+    KCHK(upload(c, c->stage_tgt, tgt, (size_t)nt * 3 * sizeof(float)));
+    KCHK(ensure(c, c->stage_idx, (size_t)ns * sizeof(int32_t)));
+    KCHK(ensure(c, c->stage_d2, (size_t)ns * sizeof(float)));
+    KCHK(kss_nn_dev(c, (const float*)c->stage_src.p, ns, (const float*)c->stage_tgt.p, nt, (int32_t*)c->stage_idx.p, (float*)c->stage_d2.p));
+    if (idx) HIPCHK(c, hipMemcpyAsync(idx, c->stage_idx.p, (size_t)ns * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (d2) HIPCHK(c, hipMemcpyAsync(d2, c->stage_d2.p, (size_t)ns * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KSS_OK;
+}
+
+// ---- covariance sums -----------------------------------------------------------------------------
+int kss_cov_dev(kss_ctx* c, const float* d_src, const float* d_tgt, const int32_t* d_idx, int64_t n, int64_t nt,
+                double max_d2, double sums[KSS_NSUMS]) {
+    if (!c || !d_src || !d_tgt || !d_idx || !sums) return set_err(c, KSS_ERR_ARG, "cov: null argument");
+    if (n <= 0 || nt <= 0) return set_err(c, KSS_ERR_ARG, "cov: empty input");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int nb = preshape_blocks(n);
+    KCHK(ensure(c, c->partials, (size_t)nb * NSUMS * sizeof(double)));
+    KCHK(ensure(c, c->sums, NSUMS * sizeof(double)));
+    KCHK(ensure_pinned(c, c->h_sums, c->h_sums_cap, NSUMS * sizeof(double)));
+    {
+        ProfScope ps(c, KSS_K_CORR_REDUCE);
+        launch_corr_reduce_idx(c->stream, d_src, d_tgt, d_idx, n, max_d2, (double*)c->partials.p, nb);
+        launch_sum_columns(c->stream, (const double*)c->partials.p, nb, NSUMS, (double*)c->sums.p);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_sums, c->sums.p, NSUMS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(sums, c->h_sums, NSUMS * sizeof(double));
+    return KSS_OK;
+}
+
+int kss_cov(kss_ctx* c, const float* src, const float* tgt, const int32_t* idx, int64_t n, int64_t nt, double max_d2,
+            double sums[KSS_NSUMS]) {
+    if (!c || !src || !tgt || !idx || !sums) return set_err(c, KSS_ERR_ARG, "cov: null argument");
+    if (n <= 0 || nt <= 0) return set_err(c, KSS_ERR_ARG, "cov: empty input");
+    for (int64_t i = 0; i < n; ++i)
+        if (idx[i] < 0 || idx[i] >= nt) return set_err(c, KSS_ERR_ARG, "cov: index out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    KCHK(upload(c, c->stage_src, src, (size_t)n * 3 * sizeof(float)));
+    KCHK(upload(c, c->stage_tgt, tgt, (size_t)nt * 3 * sizeof(float)));
+    KCHK(upload(c, c->stage_idx, idx, (size_t)n * sizeof(int32_t)));
+    return kss_cov_dev(c, (const float*)c->stage_src.p, (const float*)c->stage_tgt.p, (const int32_t*)c->stage_idx.p, n, nt, max_d2, sums);
+}
+
+int kss_rigid_from_sums(const double sums[KSS_NSUMS], float T[16]) {
+    if (!sums || !T) return KSS_ERR_ARG;
+    if (!(sums[0] >= 1.0)) return KSS_ERR_ARG;
+    rigid_from_sums(sums, T);
+    return KSS_OK;
+}
+
+// ---- pre-shape ------------------------------------------------------------------------------------
+int kss_preshape_stats_dev(kss_ctx* c, const void* d_xyz, int dtype, int64_t n, double centroid[3], double* mean_radius) {
+    if (!c || !d_xyz || !centroid || !mean_radius) return set_err(c, KSS_ERR_ARG, "preshape: null argument");
+    if (n <= 0) return set_err(c, KSS_ERR_ARG, "preshape: empty cloud");
+    if (dtype != KSS_F32 && dtype != KSS_F64) return set_err(c, KSS_ERR_ARG, "preshape: bad dtype");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int nb = preshape_blocks(n);
+    KCHK(ensure(c, c->partials, (size_t)nb * 4 * sizeof(double)));
+    KCHK(ensure(c, c->sums, 8 * sizeof(double)));
+    KCHK(ensure_pinned(c, c->h_sums, c->h_sums_cap, 8 * sizeof(double)));
+    double* d_cent = (double*)c->sums.p;   // [0..2] centroid, [4] radius sum
+    {
+        ProfScope ps(c, KSS_K_PRESHAPE);
+        launch_preshape_sum(c->stream, d_xyz, dtype, n, (double*)c->partials.p, nb);
+        launch_preshape_centroid(c->stream, (const double*)c->partials.p, nb, n, d_cent);
+        launch_preshape_radius(c->stream, d_xyz, dtype, n, d_cent, (double*)c->partials.p, nb);
+        launch_sum_columns(c->stream, (const double*)c->partials.p, nb, 1, d_cent + 4);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_sums, d_cent, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const double* h = (const double*)c->h_sums;
+    centroid[0] = h[0]; centroid[1] = h[1]; centroid[2] = h[2];
+    *mean_radius = h[4] / (double)n;
+    return KSS_OK;
+}
+
+int kss_preshape_stats(kss_ctx* c, const void* xyz, int dtype, int64_t n, double centroid[3], double* mean_radius) {
+    if (!c || !xyz) return set_err(c, KSS_ERR_ARG, "preshape: null argument");
+    if (n <= 0) return set_err(c, KSS_ERR_ARG, "preshape: empty cloud");
+    if (dtype != KSS_F32 && dtype != KSS_F64) return set_err(c, KSS_ERR_ARG, "preshape: bad dtype");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t esz = dtype == KSS_F64 ? 8 : 4;
+    KCHK(upload(c, c->stage_src, xyz, (size_t)n * 3 * esz));
+    return kss_preshape_stats_dev(c, c->stage_src.p, dtype, n, centroid, mean_radius);
+}
+
+// ---- pose / transform application -------------------------------------------------------------------
+int kss_pose_apply_dev(kss_ctx* c, const double* d_in, int64_t n, const kss_pose* pose, double* d_out) {
+    if (!c || !d_in || !d_out || !pose) return set_err(c, KSS_ERR_ARG, "pose_apply: null argument");
+    if (n < 0) return set_err(c, KSS_ERR_ARG, "pose_apply: negative size");
+    if (n == 0) return KSS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    // cos/sin evaluated on the host so that they are the caller's libm values (reference: cos(angle) per point)
+    const double cs[6] = {std::cos(pose->angle[0]), std::sin(pose->angle[0]), std::cos(pose->angle[1]),
+                          std::sin(pose->angle[1]), std::cos(pose->angle[2]), std::sin(pose->angle[2])};
+    {
+        ProfScope ps(c, KSS_K_POSE_APPLY);
+        launch_pose_apply(c->stream, d_in, n, *pose, cs, d_out);
+    }
+    HIPCHK(c, hipGetLastError());
+    return KSS_OK;
+}
+
+int kss_pose_apply(kss_ctx* c, const double* in, int64_t n, const kss_pose* pose, double* out) {
+    if (!c || !in || !out || !pose) return set_err(c, KSS_ERR_ARG, "pose_apply: null argument");
+    if (n < 0) return set_err(c, KSS_ERR_ARG, "pose_apply: negative size");
+    if (n == 0) return KSS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    KCHK(upload(c, c->stage_src, in, (size_t)n * 3 * sizeof(double)));
+    KCHK(ensure(c, c->stage_out, (size_t)n * 3 * sizeof(double)));
+    KCHK(kss_pose_apply_dev(c, (const double*)c->stage_src.p, n, pose, (double*)c->stage_out.p));
+    HIPCHK(c, hipMemcpyAsync(out, c->stage_out.p, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KSS_OK;
+}
+
+int kss_transform_apply_dev(kss_ctx* c, const float T[16], const double* d_in, int64_t n, double* d_out) {
+    if (!c || !T || !d_in || !d_out) return set_err(c, KSS_ERR_ARG, "transform_apply: null argument");
+    if (n < 0) return set_err(c, KSS_ERR_ARG, "transform_apply: negative size");
+    if (n == 0) return KSS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    {
+        ProfScope ps(c, KSS_K_POSE_APPLY);
+        launch_transform_apply_f64(c->stream, T, d_in, n, d_out);
+    }
+    HIPCHK(c, hipGetLastError());
+    return KSS_OK;
+}
+
+int kss_transform_apply(kss_ctx* c, const float T[16], const double* in, int64_t n, double* out) {
+    if (!c || !T || !in || !out) return set_err(c, KSS_ERR_ARG, "transform_apply: null argument");
+    if (n < 0) return set_err(c, KSS_ERR_ARG, "transform_apply: negative size");
+    if (n == 0) return KSS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    KCHK(upload(c, c->stage_src, in, (size_t)n * 3 * sizeof(double)));
+    KCHK(ensure(c, c->stage_out, (size_t)n * 3 * sizeof(double)));
+    KCHK(kss_transform_apply_dev(c, T, (const double*)c->stage_src.p, n, (double*)c->stage_out.p));
+    HIPCHK(c, hipMemcpyAsync(out, c->stage_out.p, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KSS_OK;
+}
+
+// ---- rotation search --------------------------------------------------------------------------------
+int kss_grid_angles(double step, double* angles, int capacity) {
+    if (!angles || capacity <= 0 || !(step > 0)) return KSS_ERR_ARG;
+    const int g = grid_angles(step, angles, capacity);
+    return g < 0 ? KSS_ERR_CAPACITY : g;
+}
+
+int kss_rotation_candidates(const double* err, int g, double step, double best_angle[3], double* angle_list,
+                            int list_capacity, int* n_list) {
+    if (!err || g <= 0 || !best_angle || !n_list || !(step > 0)) return KSS_ERR_ARG;
+    std::vector<double> ang(g);
+    if (grid_angles(step, ang.data(), g) != g) return KSS_ERR_ARG;
+    // global arg-min, strict '<' against errorT = 9999 in i, j, k loop order (:239, :258-265)
+    double errorT = 9999;
+    double bi = 0, bj = 0, bk = 0;
+    for (int i = 0; i < g; ++i)
+        for (int j = 0; j < g; ++j)
+            for (int k = 0; k < g; ++k) {
+                const double e = err[((int64_t)i * g + j) * g + k];
+                if (e < errorT) { errorT = e; bi = ang[i]; bj = ang[j]; bk = ang[k]; }
+            }
+    best_angle[0] = bi; best_angle[1] = bj; best_angle[2] = bk;
+    int nl = 0;
+    for (int i = 0; i < g; ++i)
+        for (int j = 0; j < g; ++j)
+            for (int k = 0; k < g; ++k)
+                if (is_local_min(err, g, i, j, k, 2)) {
+                    if (angle_list) {
+                        if (nl >= list_capacity) return KSS_ERR_CAPACITY;
+                        angle_list[3 * nl + 0] = (double)i * 6.3 / step;   // :282-284
+                        angle_list[3 * nl + 1] = (double)j * 6.3 / step;
+                        angle_list[3 * nl + 2] = (double)k * 6.3 / step;
+                    }
+                    ++nl;
+                }
+    *n_list = nl;
+    return KSS_OK;
+}
+
+int kss_rotation_search_dev(kss_ctx* c, const double* d_src, int64_t ns, const double* d_tgt, int64_t nt, double step,
+                            double* err, int64_t err_capacity, int* g_out) {
+    if (!c || !d_src || !d_tgt || !err || !g_out) return set_err(c, KSS_ERR_ARG, "rotation_search: null argument");
+    if (ns <= 0 || nt <= 0 || !(step > 0)) return set_err(c, KSS_ERR_ARG, "rotation_search: empty cloud or bad step");
+    if (ns > 0x7fff0000ll || nt > 0x7fff0000ll) return set_err(c, KSS_ERR_ARG, "rotation_search: cloud too large");
+    HIPCHK(c, hipSetDevice(c->device));
+    double ang[64];
+    const int g = grid_angles(step, ang, 40);
+    if (g <= 0) return set_err(c, KSS_ERR_ARG, "rotation_search: grid larger than 40 per axis");
+    const int64_t ncand = (int64_t)g * g * g;
+    if (err_capacity < ncand) return set_err(c, KSS_ERR_CAPACITY, "rotation_search: err buffer too small");
+    std::vector<double> cs(2 * g);
+    for (int a = 0; a < g; ++a) { cs[2 * a] = std::cos(ang[a]); cs[2 * a + 1] = std::sin(ang[a]); }
+    const int64_t nt_pad = (nt + NN_TILE - 1) / NN_TILE * NN_TILE;
+    const int nsb = (int)((ns + 255) / 256);
+    KCHK(ensure(c, c->tgt4, (size_t)nt_pad * sizeof(float4)));
+    KCHK(ensure(c, c->cs, cs.size() * sizeof(double)));
+    KCHK(ensure(c, c->partials, (size_t)ncand * nsb * sizeof(double)));
+    KCHK(ensure(c, c->scratch_c, (size_t)ncand * sizeof(double)));
+    HIPCHK(c, hipMemcpyAsync(c->cs.p, cs.data(), cs.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    launch_pack_f64_to_f4(c->stream, d_tgt, nt, (float4*)c->tgt4.p, nt_pad, true);   // :232-234 narrowing to PointXYZ
+    {
+        ProfScope ps(c, KSS_K_ROT_SEARCH);
+        launch_rot_search(c->stream, d_src, ns, (const float4*)c->tgt4.p, nt_pad, (const double*)c->cs.p, g,
+                          (double*)c->partials.p, nsb);
+        launch_row_sums(c->stream, (const double*)c->partials.p, (int)ncand, nsb, 1.0, (double*)c->scratch_c.p);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(err, c->scratch_c.p, (size_t)ncand * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int64_t i = 0; i < ncand; ++i) err[i] = err[i] / (double)ns;   // :448 distanceSum / size
+    *g_out = g;
+    return KSS_OK;
+}
+
+int kss_rotation_search(kss_ctx* c, const double* src, int64_t ns, const double* tgt, int64_t nt, double step,
+                        double* err, int64_t err_capacity, int* g_out) {
+    if (!c || !src || !tgt) return set_err(c, KSS_ERR_ARG, "rotation_search: null argument");
+    if (ns <= 0 || nt <= 0) return set_err(c, KSS_ERR_ARG, "rotation_search: empty cloud");
+    HIPCHK(c, hipSetDevice(c->device));
+    KCHK(upload(c, c->scratch_a, src, (size_t)ns * 3 * sizeof(double)));
+    KCHK(upload(c, c->scratch_b, tgt, (size_t)nt * 3 * sizeof(double)));
+    return kss_rotation_search_dev(c, (const double*)c->scratch_a.p, ns, (const double*)c->scratch_b.p, nt, step, err, err_capacity, g_out);
+}
+
+// ---- PCR_QM -------------------------------------------------------------------------------------------
+int kss_pcr_qm(kss_ctx* c, const double* aligned, int64_t na, const double* tmpl, int64_t nt, double out[3]) {
+    if (!c || !aligned || !tmpl || !out) return set_err(c, KSS_ERR_ARG, "pcr_qm: null argument");
+    if (na <= 0 || nt <= 0) return set_err(c, KSS_ERR_ARG, "pcr_qm: empty cloud");
+    HIPCHK(c, hipSetDevice(c->device));
+    KCHK(upload(c, c->scratch_a, aligned, (size_t)na * 3 * sizeof(double)));
+    KCHK(upload(c, c->scratch_b, tmpl, (size_t)nt * 3 * sizeof(double)));
+    double sums[NSUMS];
+    KCHK(nn_generic_dev(c, c->scratch_a.p, na, c->scratch_b.p, nt, KSS_F64, nullptr, nullptr, sums));
+    const double mse = sums[17] / (double)na;      // registrationMeasure.hpp:85
+    out[0] = mse;
+    out[1] = std::sqrt(mse);                        // :87
+    out[2] = sums[18] / (double)na;                 // :86
+    return KSS_OK;
+}
+
+// ---- KSSICP_Registration on down-sampled clouds ----------------------------------------------------------
+int kss_register(kss_ctx* c, const double* src_sub, int64_t nss, const double* tgt_sub, int64_t nts,
+                 const double* src_full, int64_t nsf, double accurate, int iter, double* point_align,
+                 kss_register_result* res) {
+    if (!c || !src_sub || !tgt_sub || !res) return set_err(c, KSS_ERR_ARG, "register: null argument");
+    if (nss <= 0 || nts <= 0 || nsf < 0 || (nsf > 0 && !src_full)) return set_err(c, KSS_ERR_ARG, "register: bad sizes");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::memset(res, 0, sizeof *res);
+    // resident copies of S', T' (f64)
+    DevBuf dS, dT, dP, dAll;
+    auto cleanup = [&]() { if (dS.p) hipFree(dS.p); if (dT.p) hipFree(dT.p); if (dP.p) hipFree(dP.p); if (dAll.p) hipFree(dAll.p); };
+#define RCHK(expr) do { int rc_ = (expr); if (rc_ != KSS_OK) { cleanup(); return rc_; } } while (0)
+    RCHK(upload(c, dS, src_sub, (size_t)nss * 3 * sizeof(double)));
+    RCHK(upload(c, dT, tgt_sub, (size_t)nts * 3 * sizeof(double)));
+    RCHK(ensure(c, dP, (size_t)nss * 3 * sizeof(double)));
+    // (a2) pre-shape
+    double cS[3], cT[3], rS, rT;
+    RCHK(kss_preshape_stats_dev(c, dS.p, KSS_F64, nss, cS, &rS));
+    RCHK(kss_preshape_stats_dev(c, dT.p, KSS_F64, nts, cT, &rT));
+    kss_pose pose;
+    for (int k = 0; k < 3; ++k) { pose.shift[k] = cT[k] - cS[k]; pose.center[k] = cT[k]; pose.angle[k] = 0.0; }
+    pose.scale = rT / rS;
+    res->scale = pose.scale;
+    RCHK(kss_pose_apply_dev(c, (const double*)dS.p, nss, &pose, (double*)dP.p));   // S' (angle 0 -> exact identity rotation)
+    // (a4) rotation search
+    std::vector<double> err(40 * 40 * 40);
+    int g = 0;
+    RCHK(kss_rotation_search_dev(c, (const double*)dP.p, nss, (const double*)dT.p, nts, accurate, err.data(), (int64_t)err.size(), &g));
+    res->grid = g;
+    std::vector<double> alist((size_t)3 * g * g * g);
+    double best[3];
+    int nl = 0;
+    RCHK(kss_rotation_candidates(err.data(), g, accurate, best, alist.data(), g * g * g, &nl));
+    res->n_angle_list = nl;
+
+    kss_icp_params ip;
+    kss_icp_default_params(&ip);
+    ip.max_iterations = iter;
+    const int64_t to[2] = {0, nts};
+    // (a14) judge: ICP from the best grid pose (KSS_ICP.hpp:92-93)
+    for (int k = 0; k < 3; ++k) pose.angle[k] = best[k];
+    RCHK(kss_pose_apply_dev(c, (const double*)dS.p, nss, &pose, (double*)dP.p));
+    kss_icp_result r0;
+    {
+        const int64_t so[2] = {0, nss};
+        RCHK(icp_run_dev(c, dP.p, so, dT.p, to, 1, false, KSS_F64, &ip, &r0));
+    }
+    res->E_d_init = r0.fitness;
+    double chosen[3] = {best[0], best[1], best[2]};
+    kss_icp_result rfinal = r0;
+    bool have_final = true;   // the judge ICP *is* the final ICP when the threshold branch is not taken
+    if (res->E_d_init > 0.0005 && nl > 0) {   // :99
+        // (a14) all candidate ICPs as ONE batch sharing the target (:102-118)
+        RCHK(ensure(c, dAll, (size_t)nl * nss * 3 * sizeof(double)));
+        std::vector<int64_t> so(nl + 1);
+        for (int i = 0; i < nl; ++i) {
+            so[i] = (int64_t)i * nss;
+            for (int k = 0; k < 3; ++k) pose.angle[k] = alist[3 * i + k];
+            RCHK(kss_pose_apply_dev(c, (const double*)dS.p, nss, &pose, (double*)dAll.p + (size_t)i * nss * 3));
+        }
+        so[nl] = (int64_t)nl * nss;
+        std::vector<kss_icp_result> rr(nl);
+        RCHK(icp_run_dev(c, dAll.p, so.data(), dT.p, to, nl, true, KSS_F64, &ip, rr.data()));
+        double Q = 9999; int angleIndex = 0;
+        for (int i = 0; i < nl; ++i) {
+            const double ri = rr[i].fitness;
+            if (ri < Q && ri >= 0) { Q = ri; angleIndex = i; }   // :113-116
+        }
+        res->used_angle_list = 1; res->angle_index = angleIndex;
+        for (int k = 0; k < 3; ++k) chosen[k] = alist[3 * angleIndex + k];
+        rfinal = rr[angleIndex];   // identical inputs => identical to re-running :130
+    } else if (res->E_d_init > 0.0005) {
+        res->used_angle_list = 1;  // empty angle list: the reference would index out of range; keep the best grid pose
+    }
+    (void)have_final;
+    for (int k = 0; k < 3; ++k) res->angle[k] = chosen[k];
+    res->final_fitness = rfinal.fitness;
+    res->icp_iterations = rfinal.iterations;
+    res->icp_converged = rfinal.converged;
+    std::memcpy(res->T_icp, rfinal.T, sizeof rfinal.T);
+    // composite similarity: R = R_icp R0, t = R (c_T - s c_S) + t_icp
+    double R0[9];
+    euler_matrix(chosen, R0);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            res->R[3 * i + j] = (double)rfinal.T[4 * i] * R0[j] + (double)rfinal.T[4 * i + 1] * R0[3 + j] + (double)rfinal.T[4 * i + 2] * R0[6 + j];
+    double v[3];
+    for (int k = 0; k < 3; ++k) v[k] = cT[k] - pose.scale * cS[k];
+    for (int i = 0; i < 3; ++i)
+        res->t[i] = res->R[3 * i] * v[0] + res->R[3 * i + 1] * v[1] + res->R[3 * i + 2] * v[2] + (double)rfinal.T[4 * i + 3];
+    // (a13) pointAlign = M * Rotation_Angle(pointSource) (:120/:124, :224-230)
+    if (point_align && nsf > 0) {
+        DevBuf dF, dG;
+        int rc = upload(c, dF, src_full, (size_t)nsf * 3 * sizeof(double));
+        if (rc == KSS_OK) rc = ensure(c, dG, (size_t)nsf * 3 * sizeof(double));
+        for (int k = 0; k < 3; ++k) pose.angle[k] = chosen[k];
+        if (rc == KSS_OK) rc = kss_pose_apply_dev(c, (const double*)dF.p, nsf, &pose, (double*)dG.p);
+        if (rc == KSS_OK) rc = kss_transform_apply_dev(c, rfinal.T, (const double*)dG.p, nsf, (double*)dF.p);
+        if (rc == KSS_OK && hipMemcpyAsync(point_align, dF.p, (size_t)nsf * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = KSS_ERR_HIP;
+        if (rc == KSS_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = KSS_ERR_HIP;
+        if (dF.p) hipFree(dF.p);
+        if (dG.p) hipFree(dG.p);
+        if (rc != KSS_OK) { cleanup(); return rc; }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    cleanup();
+#undef RCHK
+    return KSS_OK;
+}
+
+// ---- RCCL gather of result records ------------------------------------------------------------------------
+// ncclAllGather is resolved at run time from librccl.so so that libkssicp.so has no link-time RCCL
+// dependency (single-GPU users never load it).
+int kss_gather_results(kss_ctx* c, void* rccl_comm, int world_size, const kss_icp_result* local, int n_local,
+                       kss_icp_result* all) {
+    if (!c || !rccl_comm || !local || !all || n_local <= 0 || world_size <= 0) return set_err(c, KSS_ERR_ARG, "gather: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+    static allgather_fn fn = nullptr;
+    if (!fn) {
+        void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return set_err(c, KSS_ERR_RCCL, "cannot dlopen librccl.so");
+        fn = (allgather_fn)dlsym(h, "ncclAllGather");
+        if (!fn) return set_err(c, KSS_ERR_RCCL, "ncclAllGather not found in librccl.so");
+    }
+    const size_t bytes = (size_t)n_local * sizeof(kss_icp_result);
+    KCHK(ensure(c, c->scratch_a, bytes));
+    KCHK(ensure(c, c->scratch_b, bytes * (size_t)world_size));
+    HIPCHK(c, hipMemcpyAsync(c->scratch_a.p, local, bytes, hipMemcpyHostToDevice, c->stream));
+    const int rc = fn(c->scratch_a.p, c->scratch_b.p, bytes, /*ncclInt8*/ 0, rccl_comm, c->stream);
+    if (rc != 0) return set_err(c, KSS_ERR_RCCL, "ncclAllGather failed");
+    HIPCHK(c, hipMemcpyAsync(all, c->scratch_b.p, bytes * (size_t)world_size, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KSS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+// kss_internal.hpp -- shared declarations between the HIP kernels (kss_kernels.hip) and the
+// C-ABI / host drivers (kss_api.hip).  Product code; gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/kssicp.h"
+#include "kss_host_math.hpp"
+
+namespace kss {
+
+// ---- device-visible descriptors ---------------------------------------------------------------
+// Per-pair state re-uploaded every ICP iteration (64 B): rows 0..2 of the Matrix4f to apply to
+// the source on load, and whether the pair still iterates.
+struct alignas(16) PairState {
+    float m[12];
+    int32_t active;
+    int32_t apply;   // 0: copy source unchanged (identity guess, PCL copies the cloud)
+    int32_t pad[2];
+};
+
+// One NN-sweep workgroup = (block of sources of one pair) x (one target split).
+struct alignas(16) NNWork {
+    int32_t pair;
+    int32_t src_begin;   // first source point (global index into the float4 source arrays)
+    int32_t src_count;   // <= 256 * S
+    int32_t tgt_begin;   // first target point of this split (global index into tgt4), multiple of TILE from pair base
+    int32_t tgt_count;   // targets in this split, multiple of TILE (sentinel padded)
+    int32_t tgt_pair_base;  // first target of the pair (idx written relative to it)
+    int32_t key_begin;   // where this block's keys start: keys[key_begin + local_source]
+    int32_t write_src;   // split 0 writes the transformed sources
+};
+
+// One correspondence-reduce workgroup = 256 consecutive sources of one pair.
+struct alignas(16) RedWork {
+    int32_t pair;
+    int32_t src_begin;
+    int32_t src_count;      // <= 256
+    int32_t key_begin;      // keys[key_begin + s * key_stride + t]
+    int32_t key_stride;     // distance between splits (= padded source count of the pair)
+    int32_t n_split;
+    int32_t tgt_pair_base;
+    int32_t partial_index;  // row in the partial-sums array
+};
+
+struct PairRed {            // final reduce: rows [first, first+count) of partials -> sums[pair]
+    int32_t first;
+    int32_t count;
+};
+
+constexpr int NN_TILE = 256;      // targets staged per LDS tile (one float4 per thread)
+constexpr int NN_SUB = 32;        // targets per sub-tile (arg-min bookkeeping granularity)
+constexpr int NN_THREADS = 256;
+
+// ---- kernel launchers (kss_kernels.hip) ---------------------------------------------------------
+void launch_pack_f3_to_f4(hipStream_t st, const float* d_in, int64_t n, float4* d_out, int64_t n_pad, bool sentinel);
+void launch_pack_f64_to_f4(hipStream_t st, const double* d_in, int64_t n, float4* d_out, int64_t n_pad, bool sentinel);
+
+void launch_nn_sweep(hipStream_t st, int S, bool fma, const NNWork* d_work, int n_work,
+                     const PairState* d_state, const float4* d_src_in, float4* d_src_out,
+                     const float4* d_tgt4, unsigned long long* d_keys);
+
+void launch_corr_reduce(hipStream_t st, const RedWork* d_work, int n_work, const PairState* d_state,
+                        const float4* d_src, const float4* d_tgt4, const unsigned long long* d_keys,
+                        double max_d2, double* d_partials, int32_t* d_idx_out, float* d_d2_out);
+// idx-driven variant for kss_cov: d2 recomputed with the reference arithmetic
+void launch_corr_reduce_idx(hipStream_t st, const float* d_src3, const float* d_tgt3, const int32_t* d_idx,
+                            int64_t n, double max_d2, double* d_partials, int n_blocks);
+void launch_finalize_sums(hipStream_t st, const PairRed* d_pairs, int n_pairs, const double* d_partials,
+                          double* d_out /* n_pairs * NSUMS, device or host-mapped */);
+
+void launch_preshape_sum(hipStream_t st, const void* d_xyz, int dtype, int64_t n, double* d_partials, int n_blocks);
+void launch_preshape_centroid(hipStream_t st, const double* d_partials, int n_blocks, int64_t n, double* d_centroid);
+void launch_preshape_radius(hipStream_t st, const void* d_xyz, int dtype, int64_t n, const double* d_centroid,
+                            double* d_partials, int n_blocks);
+void launch_sum_columns(hipStream_t st, const double* d_partials, int n_rows, int n_cols, double* d_out);
+void launch_row_sums(hipStream_t st, const double* d_partials, int n_rows, int n_cols, double scale, double* d_out);
+
+void launch_pose_apply(hipStream_t st, const double* d_in, int64_t n, const kss_pose& pose,
+                       const double cs[6], double* d_out);
+void launch_transform_apply_f64(hipStream_t st, const float T[16], const double* d_in, int64_t n, double* d_out);
+
+void launch_rot_search(hipStream_t st, const double* d_src, int64_t ns, const float4* d_tgt4, int64_t nt_pad,
+                       const double* d_cs /* g*2: cos,sin */, int g, double* d_partials, int n_src_blocks);
+
+int preshape_blocks(int64_t n);
+
+}  // namespace kss

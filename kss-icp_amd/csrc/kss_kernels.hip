@@ -1,0 +1,526 @@
+// kss_kernels.hip -- hand-written HIP kernels of the KSS-ICP registration core for gfx950 (CDNA4).
+//
+// Kernels (DESIGN.md has the roofline of each):
+//   nn_sweep_kernel      (b) brute-force exact 1-NN: LDS-tiled source x target sweep, FP32 VALU bound
+//   corr_reduce_kernel   (c) correspondence sums (3x3 cross-covariance etc.), f64, wave + LDS reduce
+//   preshape_*           (a) KSS pre-shape centroid / mean radius, f64 block reduce, HBM streaming
+//   rot_search_kernel        all g^3 Euler candidates x n(S') NN in one launch
+//   pose_apply / transform_apply   streaming similarity / Matrix4f application in f64
+//
+// Arithmetic contract: everything that feeds a parity-checked result is evaluated WITHOUT fused
+// multiply-add, in the reference's operation order (FLANN L2_Simple<float>, Eigen Matrix4f * vec4,
+// initRegistration_Transfer in double).  The file is compiled with -ffp-contract=off and the pragma
+// below; the optional FMA distance form uses __builtin_fmaf explicitly.
+#pragma clang fp contract(off)
+
+#include <hip/hip_runtime.h>
+
+#include "kss_internal.hpp"
+
+namespace kss {
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+template <bool FMA>
+__device__ __forceinline__ float dist2(float sx, float sy, float sz, float tx, float ty, float tz) {
+    const float dx = sx - tx, dy = sy - ty, dz = sz - tz;
+    if constexpr (FMA) {
+        return __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+    } else {
+        return (dx * dx + dy * dy) + dz * dz;   // FLANN L2_Simple: result += diff*diff in x,y,z order
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Block-wide sum of NV doubles per thread (256 threads = 4 waves). Result valid in thread c < NV.
+template <int NV>
+__device__ __forceinline__ double block_sum(const double (&v)[NV], double (*sh)[NV]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const double r = wave_sum(v[c]);
+        if (lane == 0) sh[wave][c] = r;
+    }
+    __syncthreads();
+    double out = 0.0;
+    if (threadIdx.x < NV) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int w = 0; w < nw; ++w) out += sh[w][threadIdx.x];   // fixed order: reproducible
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// packing: xyz triples -> float4 (x, y, z, 0), tail filled with +inf sentinels so that padded
+// targets can never win the arg-min.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pack_to_f4_kernel(const T* __restrict__ in, int64_t n,
+                                                         float4* __restrict__ out, int64_t n_pad, int sentinel) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    float4 v;
+    if (i < n) {
+        v = make_float4((float)in[3 * i], (float)in[3 * i + 1], (float)in[3 * i + 2], 0.f);
+    } else {
+        const float f = sentinel ? __builtin_inff() : 0.f;
+        v = make_float4(f, f, f, 0.f);
+    }
+    out[i] = v;
+}
+
+void launch_pack_f3_to_f4(hipStream_t st, const float* d_in, int64_t n, float4* d_out, int64_t n_pad, bool sentinel) {
+    if (n_pad <= 0) return;
+    const int blocks = (int)((n_pad + 255) / 256);
+    hipLaunchKernelGGL(pack_to_f4_kernel<float>, dim3(blocks), dim3(256), 0, st, d_in, n, d_out, n_pad, sentinel ? 1 : 0);
+}
+void launch_pack_f64_to_f4(hipStream_t st, const double* d_in, int64_t n, float4* d_out, int64_t n_pad, bool sentinel) {
+    if (n_pad <= 0) return;
+    const int blocks = (int)((n_pad + 255) / 256);
+    hipLaunchKernelGGL(pack_to_f4_kernel<double>, dim3(blocks), dim3(256), 0, st, d_in, n, d_out, n_pad, sentinel ? 1 : 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// (b) NN sweep.  One workgroup = 256*S sources of one pair x one split of that pair's targets.
+//   - sources live in registers (S per lane), optionally transformed on load by the previous
+//     iteration's Matrix4f (PCL transformCloud: ((m0*x + m1*y) + m2*z) + m3, float, no fma);
+//   - targets stream through a double-buffered 256-point LDS tile (one float4 per thread, one
+//     barrier per tile); every lane reads the same LDS address (broadcast, conflict free);
+//   - the inner loop keeps only a running MIN per 32-target sub-tile (v_min3), and remembers the
+//     first sub-tile that achieved the best value; the winning sub-tile is re-scanned once at the
+//     end to recover the exact lowest index.  ~8.6 VALU ops per (source, target) pair;
+//   - result key = (bits(d2) << 32) | idx: unsigned-min over splits == (min d2, lowest idx).
+// ---------------------------------------------------------------------------------------------
+template <int S, bool FMA>
+__global__ __launch_bounds__(NN_THREADS) void nn_sweep_kernel(const NNWork* __restrict__ work,
+                                                              const PairState* __restrict__ state,
+                                                              const float4* __restrict__ src_in,
+                                                              float4* __restrict__ src_out,
+                                                              const float4* __restrict__ tgt,
+                                                              unsigned long long* __restrict__ keys) {
+    __shared__ float4 tile[2][NN_TILE];
+    const NNWork w = work[blockIdx.x];
+    const PairState ps = state[w.pair];
+    if (!ps.active) return;   // uniform: whole workgroup leaves
+    const int tid = threadIdx.x;
+
+    float sx[S], sy[S], sz[S], best[S];
+    int bsub[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        const int l = tid + j * NN_THREADS;
+        const bool valid = l < w.src_count;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) p = src_in[w.src_begin + l];
+        if (ps.apply) {
+            const float x = p.x, y = p.y, z = p.z;
+            p.x = ((ps.m[0] * x + ps.m[1] * y) + ps.m[2] * z) + ps.m[3];
+            p.y = ((ps.m[4] * x + ps.m[5] * y) + ps.m[6] * z) + ps.m[7];
+            p.z = ((ps.m[8] * x + ps.m[9] * y) + ps.m[10] * z) + ps.m[11];
+        }
+        if (valid && w.write_src) src_out[w.src_begin + l] = p;
+        sx[j] = p.x; sy[j] = p.y; sz[j] = p.z;
+        best[j] = __builtin_inff();
+        bsub[j] = 0;
+    }
+
+    const float4* __restrict__ tp = tgt + w.tgt_begin;
+    const int ntiles = w.tgt_count / NN_TILE;
+    float4 pre = tp[tid];
+    int buf = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        tile[buf][tid] = pre;
+        __syncthreads();
+        if (t + 1 < ntiles) pre = tp[(t + 1) * NN_TILE + tid];
+        const float4* __restrict__ tl = tile[buf];
+#pragma unroll 1
+        for (int sub = 0; sub < NN_TILE / NN_SUB; ++sub) {
+            float m[S];
+#pragma unroll
+            for (int j = 0; j < S; ++j) m[j] = __builtin_inff();
+#pragma unroll
+            for (int u = 0; u < NN_SUB; ++u) {
+                const float4 q = tl[sub * NN_SUB + u];
+#pragma unroll
+                for (int j = 0; j < S; ++j) m[j] = fminf(m[j], dist2<FMA>(sx[j], sy[j], sz[j], q.x, q.y, q.z));
+            }
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                if (m[j] < best[j]) {   // strict: the FIRST sub-tile holding the minimum wins
+                    best[j] = m[j];
+                    bsub[j] = t * (NN_TILE / NN_SUB) + sub;
+                }
+            }
+        }
+        buf ^= 1;
+    }
+
+    // exact arg-min inside the winning sub-tile (same arithmetic => same bits as `best`)
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        const float4* __restrict__ rp = tp + bsub[j] * NN_SUB;
+        float bd = __builtin_inff();
+        int bi = 0;
+#pragma unroll 8
+        for (int u = 0; u < NN_SUB; ++u) {
+            const float4 q = rp[u];
+            const float d = dist2<FMA>(sx[j], sy[j], sz[j], q.x, q.y, q.z);
+            if (d < bd) { bd = d; bi = u; }
+        }
+        const int l = tid + j * NN_THREADS;
+        if (l < w.src_count) {
+            const unsigned idx = (unsigned)(w.tgt_begin - w.tgt_pair_base + bsub[j] * NN_SUB + bi);
+            keys[w.key_begin + l] = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned long long)idx;
+        }
+    }
+}
+
+void launch_nn_sweep(hipStream_t st, int S, bool fma, const NNWork* d_work, int n_work,
+                     const PairState* d_state, const float4* d_src_in, float4* d_src_out,
+                     const float4* d_tgt4, unsigned long long* d_keys) {
+    if (n_work <= 0) return;
+    const dim3 grid(n_work), block(NN_THREADS);
+#define KSS_NN_LAUNCH(SV, FV)                                                                               \
+    hipLaunchKernelGGL((nn_sweep_kernel<SV, FV>), grid, block, 0, st, d_work, d_state, d_src_in, d_src_out, \
+                       d_tgt4, d_keys)
+    if (!fma) {
+        switch (S) {
+            case 1: KSS_NN_LAUNCH(1, false); break;
+            case 2: KSS_NN_LAUNCH(2, false); break;
+            case 8: KSS_NN_LAUNCH(8, false); break;
+            default: KSS_NN_LAUNCH(4, false); break;
+        }
+    } else {
+        switch (S) {
+            case 1: KSS_NN_LAUNCH(1, true); break;
+            case 2: KSS_NN_LAUNCH(2, true); break;
+            case 8: KSS_NN_LAUNCH(8, true); break;
+            default: KSS_NN_LAUNCH(4, true); break;
+        }
+    }
+#undef KSS_NN_LAUNCH
+}
+
+// ---------------------------------------------------------------------------------------------
+// (c) correspondence reduce: merge the per-split keys, gather the matched target, accumulate the
+// 20 sums in f64 (wave shuffle reduce -> LDS -> one partial row per workgroup).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void accumulate_corr(double (&acc)[NSUMS], float px, float py, float pz,
+                                                float qx, float qy, float qz, float d2f, double max_d2) {
+    const double d2 = (double)d2f;
+    acc[17] += d2;
+    acc[18] += sqrt(d2);
+    if (!(d2 > max_d2)) {   // PCL: `if (distance[0] > max_dist_sqr) continue;`
+        const double p[3] = {(double)px, (double)py, (double)pz};
+        const double q[3] = {(double)qx, (double)qy, (double)qz};
+        acc[0] += 1.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { acc[1 + k] += p[k]; acc[4 + k] += q[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) acc[7 + 3 * k + l] += p[k] * q[l];
+        acc[16] += d2;
+    }
+}
+
+__global__ __launch_bounds__(256) void corr_reduce_kernel(const RedWork* __restrict__ work,
+                                                          const PairState* __restrict__ state,
+                                                          const float4* __restrict__ src,
+                                                          const float4* __restrict__ tgt,
+                                                          const unsigned long long* __restrict__ keys,
+                                                          double max_d2, double* __restrict__ partials,
+                                                          int32_t* __restrict__ idx_out,
+                                                          float* __restrict__ d2_out) {
+    __shared__ double sh[4][NSUMS];
+    const RedWork w = work[blockIdx.x];
+    double acc[NSUMS];
+#pragma unroll
+    for (int c = 0; c < NSUMS; ++c) acc[c] = 0.0;
+    const bool active = state[w.pair].active != 0;
+    const int t = threadIdx.x;
+    if (active && t < w.src_count) {
+        unsigned long long key = ~0ull;
+        for (int s = 0; s < w.n_split; ++s) {
+            const unsigned long long k = keys[w.key_begin + (int64_t)s * w.key_stride + t];
+            key = k < key ? k : key;
+        }
+        const float d2 = __uint_as_float((unsigned)(key >> 32));
+        const int idx = (int)(unsigned)(key & 0xffffffffull);
+        const float4 p = src[w.src_begin + t];
+        const float4 q = tgt[w.tgt_pair_base + idx];
+        accumulate_corr(acc, p.x, p.y, p.z, q.x, q.y, q.z, d2, max_d2);
+        if (idx_out) idx_out[w.src_begin + t] = idx;
+        if (d2_out) d2_out[w.src_begin + t] = d2;
+    }
+    const double r = block_sum<NSUMS>(acc, sh);
+    if (t < NSUMS) partials[(int64_t)w.partial_index * NSUMS + t] = r;
+}
+
+void launch_corr_reduce(hipStream_t st, const RedWork* d_work, int n_work, const PairState* d_state,
+                        const float4* d_src, const float4* d_tgt4, const unsigned long long* d_keys,
+                        double max_d2, double* d_partials, int32_t* d_idx_out, float* d_d2_out) {
+    if (n_work <= 0) return;
+    hipLaunchKernelGGL(corr_reduce_kernel, dim3(n_work), dim3(256), 0, st, d_work, d_state, d_src, d_tgt4,
+                       d_keys, max_d2, d_partials, d_idx_out, d_d2_out);
+}
+
+// idx-driven variant behind kss_cov(): packed float3 clouds + an index array
+__global__ __launch_bounds__(256) void corr_reduce_idx_kernel(const float* __restrict__ src,
+                                                              const float* __restrict__ tgt,
+                                                              const int32_t* __restrict__ idx, int64_t n,
+                                                              double max_d2, double* __restrict__ partials) {
+    __shared__ double sh[4][NSUMS];
+    double acc[NSUMS];
+#pragma unroll
+    for (int c = 0; c < NSUMS; ++c) acc[c] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = idx[i];
+        const float px = src[3 * i], py = src[3 * i + 1], pz = src[3 * i + 2];
+        const float qx = tgt[3 * j], qy = tgt[3 * j + 1], qz = tgt[3 * j + 2];
+        const float d2 = dist2<false>(px, py, pz, qx, qy, qz);
+        accumulate_corr(acc, px, py, pz, qx, qy, qz, d2, max_d2);
+    }
+    const double r = block_sum<NSUMS>(acc, sh);
+    if (threadIdx.x < NSUMS) partials[(int64_t)blockIdx.x * NSUMS + threadIdx.x] = r;
+}
+
+void launch_corr_reduce_idx(hipStream_t st, const float* d_src3, const float* d_tgt3, const int32_t* d_idx,
+                            int64_t n, double max_d2, double* d_partials, int n_blocks) {
+    hipLaunchKernelGGL(corr_reduce_idx_kernel, dim3(n_blocks), dim3(256), 0, st, d_src3, d_tgt3, d_idx, n,
+                       max_d2, d_partials);
+}
+
+// final stage: sums[pair][c] = sum over that pair's partial rows, in row order (deterministic)
+__global__ __launch_bounds__(64) void finalize_sums_kernel(const PairRed* __restrict__ pairs,
+                                                           const double* __restrict__ partials,
+                                                           double* __restrict__ out) {
+    const PairRed pr = pairs[blockIdx.x];
+    const int c = threadIdx.x;
+    if (c >= NSUMS) return;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int r = 0;
+    const double* base = partials + (int64_t)pr.first * NSUMS + c;
+    for (; r + 4 <= pr.count; r += 4) {
+        a0 += base[(int64_t)(r + 0) * NSUMS];
+        a1 += base[(int64_t)(r + 1) * NSUMS];
+        a2 += base[(int64_t)(r + 2) * NSUMS];
+        a3 += base[(int64_t)(r + 3) * NSUMS];
+    }
+    for (; r < pr.count; ++r) a0 += base[(int64_t)r * NSUMS];
+    out[(int64_t)blockIdx.x * NSUMS + c] = (a0 + a1) + (a2 + a3);
+}
+
+void launch_finalize_sums(hipStream_t st, const PairRed* d_pairs, int n_pairs, const double* d_partials, double* d_out) {
+    if (n_pairs <= 0) return;
+    hipLaunchKernelGGL(finalize_sums_kernel, dim3(n_pairs), dim3(64), 0, st, d_pairs, d_partials, d_out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// (a) KSS pre-shape statistics (initRegistration_MiddleAlign): two streaming passes, f64.
+// ---------------------------------------------------------------------------------------------
+int preshape_blocks(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    if (b > 2048) b = 2048;   // 256 CUs x 8 workgroups, grid-stride beyond
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void preshape_sum_kernel(const T* __restrict__ xyz, int64_t n,
+                                                           double* __restrict__ partials) {
+    __shared__ double sh[4][3];
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        acc[0] += (double)xyz[3 * i];
+        acc[1] += (double)xyz[3 * i + 1];
+        acc[2] += (double)xyz[3 * i + 2];
+    }
+    const double r = block_sum<3>(acc, sh);
+    if (threadIdx.x < 3) partials[(int64_t)blockIdx.x * 3 + threadIdx.x] = r;
+}
+
+// centroid = (sum over partial rows) / n   (single wave)
+__global__ __launch_bounds__(64) void preshape_centroid_kernel(const double* __restrict__ partials, int n_blocks,
+                                                               int64_t n, double* __restrict__ centroid) {
+    const int c = threadIdx.x;
+    if (c >= 3) return;
+    double a = 0.0;
+    for (int r = 0; r < n_blocks; ++r) a += partials[(int64_t)r * 3 + c];
+    centroid[c] = a / (double)n;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void preshape_radius_kernel(const T* __restrict__ xyz, int64_t n,
+                                                              const double* __restrict__ centroid,
+                                                              double* __restrict__ partials) {
+    __shared__ double sh[4][1];
+    const double cx = centroid[0], cy = centroid[1], cz = centroid[2];
+    double acc[1] = {0.0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double xl = (double)xyz[3 * i] - cx, yl = (double)xyz[3 * i + 1] - cy, zl = (double)xyz[3 * i + 2] - cz;
+        acc[0] += sqrt((xl * xl + yl * yl) + zl * zl);
+    }
+    const double r = block_sum<1>(acc, sh);
+    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
+__global__ __launch_bounds__(64) void sum_columns_kernel(const double* __restrict__ partials, int n_rows, int n_cols,
+                                                         double* __restrict__ out) {
+    const int c = threadIdx.x;
+    if (c >= n_cols) return;
+    double a = 0.0;
+    for (int r = 0; r < n_rows; ++r) a += partials[(int64_t)r * n_cols + c];
+    out[c] = a;
+}
+
+void launch_preshape_sum(hipStream_t st, const void* d_xyz, int dtype, int64_t n, double* d_partials, int n_blocks) {
+    if (dtype == KSS_F64)
+        hipLaunchKernelGGL(preshape_sum_kernel<double>, dim3(n_blocks), dim3(256), 0, st, (const double*)d_xyz, n, d_partials);
+    else
+        hipLaunchKernelGGL(preshape_sum_kernel<float>, dim3(n_blocks), dim3(256), 0, st, (const float*)d_xyz, n, d_partials);
+}
+void launch_preshape_centroid(hipStream_t st, const double* d_partials, int n_blocks, int64_t n, double* d_centroid) {
+    hipLaunchKernelGGL(preshape_centroid_kernel, dim3(1), dim3(64), 0, st, d_partials, n_blocks, n, d_centroid);
+}
+void launch_preshape_radius(hipStream_t st, const void* d_xyz, int dtype, int64_t n, const double* d_centroid,
+                            double* d_partials, int n_blocks) {
+    if (dtype == KSS_F64)
+        hipLaunchKernelGGL(preshape_radius_kernel<double>, dim3(n_blocks), dim3(256), 0, st, (const double*)d_xyz, n, d_centroid, d_partials);
+    else
+        hipLaunchKernelGGL(preshape_radius_kernel<float>, dim3(n_blocks), dim3(256), 0, st, (const float*)d_xyz, n, d_centroid, d_partials);
+}
+void launch_sum_columns(hipStream_t st, const double* d_partials, int n_rows, int n_cols, double* d_out) {
+    hipLaunchKernelGGL(sum_columns_kernel, dim3(1), dim3(64), 0, st, d_partials, n_rows, n_cols, d_out);
+}
+
+// out[r] = (sum_c partials[r][c]) * scale, one thread per row, columns added in order
+__global__ __launch_bounds__(256) void row_sums_kernel(const double* __restrict__ partials, int n_rows, int n_cols,
+                                                       double scale, double* __restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    double a = 0.0;
+    for (int c = 0; c < n_cols; ++c) a += partials[(int64_t)r * n_cols + c];
+    out[r] = a * scale;
+}
+void launch_row_sums(hipStream_t st, const double* d_partials, int n_rows, int n_cols, double scale, double* d_out) {
+    hipLaunchKernelGGL(row_sums_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, st, d_partials, n_rows, n_cols, scale, d_out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// pose application (initRegistration_Rotation[_Angle]) and Matrix4f application, f64 streaming
+// ---------------------------------------------------------------------------------------------
+struct PoseArgs {
+    double shift[3], center[3], scale;
+    double cs[6];   // cos/sin of the x, y, z angles, evaluated on the host (same libm as the caller)
+};
+
+__device__ __forceinline__ void euler_rotate(double& x, double& y, double& z, double cx, double sx, double cy,
+                                             double sy, double cz, double sz) {
+    // initRegistration_Transfer cord 1, 2, 3 in sequence (initRegistrationKSS.hpp:365-404)
+    const double y1 = y * cx - z * sx;
+    const double z1 = y * sx + z * cx;
+    const double x2 = z1 * sy + x * cy;
+    const double z2 = z1 * cy - x * sy;
+    const double x3 = x2 * cz - y1 * sz;
+    const double y3 = x2 * sz + y1 * cz;
+    x = x3; y = y3; z = z2;
+}
+
+__global__ __launch_bounds__(256) void pose_apply_kernel(const double* __restrict__ in, int64_t n, PoseArgs a,
+                                                         double* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double v[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double s = in[3 * i + k] + a.shift[k];            // :78-80
+            v[k] = a.center[k] + (s - a.center[k]) * a.scale;       // :81-83
+        }
+        euler_rotate(v[0], v[1], v[2], a.cs[0], a.cs[1], a.cs[2], a.cs[3], a.cs[4], a.cs[5]);
+        out[3 * i] = v[0]; out[3 * i + 1] = v[1]; out[3 * i + 2] = v[2];
+    }
+}
+
+void launch_pose_apply(hipStream_t st, const double* d_in, int64_t n, const kss_pose& pose, const double cs[6], double* d_out) {
+    if (n <= 0) return;
+    PoseArgs a;
+    for (int k = 0; k < 3; ++k) { a.shift[k] = pose.shift[k]; a.center[k] = pose.center[k]; }
+    a.scale = pose.scale;
+    for (int k = 0; k < 6; ++k) a.cs[k] = cs[k];
+    hipLaunchKernelGGL(pose_apply_kernel, dim3(preshape_blocks(n)), dim3(256), 0, st, d_in, n, a, d_out);
+}
+
+struct M34 { float m[12]; };
+
+__global__ __launch_bounds__(256) void transform_apply_f64_kernel(const double* __restrict__ in, int64_t n, M34 T,
+                                                                  double* __restrict__ out) {
+    // KSS_ICP.hpp:224-230: float coefficient x double coordinate, evaluated left to right in double
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            out[3 * i + r] = (((double)T.m[4 * r] * x + (double)T.m[4 * r + 1] * y) + (double)T.m[4 * r + 2] * z) + (double)T.m[4 * r + 3];
+    }
+}
+
+void launch_transform_apply_f64(hipStream_t st, const float T[16], const double* d_in, int64_t n, double* d_out) {
+    if (n <= 0) return;
+    M34 m;
+    for (int k = 0; k < 12; ++k) m.m[k] = T[k];
+    hipLaunchKernelGGL(transform_apply_f64_kernel, dim3(preshape_blocks(n)), dim3(256), 0, st, d_in, n, m, d_out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// rotation search: grid = (source blocks, g^3 candidates).  Each lane rotates its pre-shaped
+// source point in f64 by the candidate's Euler angles, narrows to f32 (:440-442), sweeps the
+// whole target through LDS keeping only the minimum d2, and contributes sqrt((double)d2) (:444).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rot_search_kernel(const double* __restrict__ src, int ns,
+                                                         const float4* __restrict__ tgt, int nt_pad,
+                                                         const double* __restrict__ cs, int g,
+                                                         double* __restrict__ partials) {
+    __shared__ float4 tile[2][NN_TILE];
+    __shared__ double sh[4][1];
+    const int cand = blockIdx.y;
+    const int ia = cand / (g * g), ib = (cand / g) % g, ic = cand % g;
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * 256 + tid;
+    const bool valid = i < ns;
+    double x = 0.0, y = 0.0, z = 0.0;
+    if (valid) { x = src[3 * (int64_t)i]; y = src[3 * (int64_t)i + 1]; z = src[3 * (int64_t)i + 2]; }
+    euler_rotate(x, y, z, cs[2 * ia], cs[2 * ia + 1], cs[2 * ib], cs[2 * ib + 1], cs[2 * ic], cs[2 * ic + 1]);
+    const float sx = (float)x, sy = (float)y, sz = (float)z;
+    float best = __builtin_inff();
+    const int ntiles = nt_pad / NN_TILE;
+    float4 pre = tgt[tid];
+    int buf = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        tile[buf][tid] = pre;
+        __syncthreads();
+        if (t + 1 < ntiles) pre = tgt[(t + 1) * NN_TILE + tid];
+        const float4* __restrict__ tl = tile[buf];
+#pragma unroll 16
+        for (int u = 0; u < NN_TILE; ++u) {
+            const float4 q = tl[u];
+            best = fminf(best, dist2<false>(sx, sy, sz, q.x, q.y, q.z));
+        }
+        buf ^= 1;
+    }
+    double acc[1] = {valid ? sqrt((double)best) : 0.0};
+    const double r = block_sum<1>(acc, sh);
+    if (tid == 0) partials[(int64_t)cand * gridDim.x + blockIdx.x] = r;
+}
+
+void launch_rot_search(hipStream_t st, const double* d_src, int64_t ns, const float4* d_tgt4, int64_t nt_pad,
+                       const double* d_cs, int g, double* d_partials, int n_src_blocks) {
+    const dim3 grid(n_src_blocks, g * g * g);
+    hipLaunchKernelGGL(rot_search_kernel, grid, dim3(256), 0, st, d_src, (int)ns, d_tgt4, (int)nt_pad, d_cs, g, d_partials);
+}
+
+}  // namespace kss

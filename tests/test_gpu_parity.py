@@ -1,0 +1,265 @@
+"""GPU parity tests (-m gpu): every call goes through the C-ABI of libkssicp.so and is compared with
+the CPU oracle on the same seeded inputs, with the committed golden vectors, and -- at full benchmark
+sizes -- through size-independent properties.
+
+Bars: bit-exact for indices and f32 squared distances (same no-fma arithmetic); f64 reductions within
+1e-12 relative (summation order differs: tree vs serial); ICP transform within BASELINE.json's north-star
+tolerance (1e-4 rotation, 1e-3 translation) -- in practice ~1e-6."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-12
+
+
+def _close(a, b, rel=REL):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.all(np.abs(a - b) <= rel * np.maximum(1.0, np.maximum(np.abs(a), np.abs(b))))
+
+
+# ---- (a8) NN --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ns,nt", [(1, 1), (1, 300), (257, 1), (1000, 1000), (2000, 2048), (5000, 777), (10000, 10000)])
+def test_nn_bit_exact(ctx, O, ns, nt):
+    rng = np.random.default_rng(ns * 7 + nt)
+    s = rng.normal(size=(ns, 3)).astype(np.float32)
+    t = rng.normal(size=(nt, 3)).astype(np.float32)
+    idx, d2 = ctx.nn(s, t)
+    oi, od = O.nn_brute(s, t)
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(d2.view(np.uint32), od.view(np.uint32))
+
+
+def test_nn_ties_take_lowest_index(ctx, O):
+    rng = np.random.default_rng(9)
+    t = rng.normal(size=(3000, 3)).astype(np.float32)
+    t[1500] = t[10]; t[2999] = t[10]; t[700] = t[699]      # duplicates across sub-tiles, tiles and splits
+    s = np.concatenate([t[[10, 699, 2999]], rng.normal(size=(500, 3)).astype(np.float32)])
+    idx, d2 = ctx.nn(s, t)
+    assert idx[0] == 10 and idx[1] == 699 and idx[2] == 10 and d2[0] == 0
+    oi, od = O.nn_brute(s, t)
+    assert np.array_equal(idx, oi) and np.array_equal(d2, od)
+    # a lattice has massive exact ties
+    g = np.stack(np.meshgrid(*[np.arange(12, dtype=np.float32)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    q = g[::3] + np.float32(0.5)
+    idx, d2 = ctx.nn(q, g)
+    oi, od = O.nn_brute(q, g)
+    assert np.array_equal(idx, oi) and np.array_equal(d2, od)
+
+
+def test_nn_golden_vector(ctx):
+    g = np.load(os.path.join(GOLDEN, "oracle_vectors.npz"))
+    idx, d2 = ctx.nn(g["g4_src"], g["g4_tgt"])
+    assert np.array_equal(idx, g["g4_nn_idx"]) and np.array_equal(d2, g["g4_nn_d2"])
+
+
+def test_nn_full_size_properties(ctx, pkg, O):
+    """100k x 100k (config C2 size): self-query is the identity with zero distance; a shuffled +
+    jittered copy maps back to the permutation; the kd-tree oracle agrees bit for bit."""
+    src, tgt = pkg.synth.config_c2(100000)
+    idx, d2 = ctx.nn(tgt, tgt)
+    assert np.array_equal(idx, np.arange(len(tgt), dtype=np.int32)) and not d2.any()
+    idx, d2 = ctx.nn(src, tgt)
+    oi, od = O.KdTree(tgt).nn(src, nthreads=8)
+    assert np.array_equal(idx, oi) and np.array_equal(d2, od)
+
+
+def test_nn_rejects_bad_arguments(ctx, pkg):
+    with pytest.raises(pkg.KssError) as e:
+        ctx.nn(np.zeros((0, 3), np.float32), np.zeros((5, 3), np.float32))
+    assert e.value.status == -1
+    with pytest.raises(pkg.KssError):
+        ctx.nn(np.zeros((5, 3), np.float32), np.zeros((0, 3), np.float32))
+
+
+# ---- (a10) covariance sums ----------------------------------------------------------------------------------
+def test_cov_matches_oracle_sums(ctx, O):
+    g = np.load(os.path.join(GOLDEN, "oracle_vectors.npz"))
+    s, t = g["g4_src"], g["g4_tgt"]
+    sums = ctx.cov(s, t, g["g4_nn_idx"], 1.0)
+    assert _close(sums, g["g4_trace_sums"][0])          # first ICP iteration of the golden trace
+    assert sums[0] == g["g4_trace_sums"][0][0]
+    # max distance gate: only correspondences with d2 <= max_d2 are kept, [17],[18] always sum all
+    thr = float(np.median(g["g4_nn_d2"]))
+    sums2 = ctx.cov(s, t, g["g4_nn_idx"], thr)
+    assert sums2[0] == np.sum(g["g4_nn_d2"].astype(np.float64) <= thr)
+    assert _close(sums2[17], sums[17]) and _close(sums2[18], sums[18])
+    # linearity: sums of a concatenation = sum of sums
+    a = ctx.cov(s[:700], t, g["g4_nn_idx"][:700], 1.0)
+    b = ctx.cov(s[700:], t, g["g4_nn_idx"][700:], 1.0)
+    assert _close(a + b, sums, 1e-11)
+
+
+# ---- (a2) pre-shape --------------------------------------------------------------------------------------------
+def test_preshape_matches_oracle(ctx, O):
+    g = np.load(os.path.join(GOLDEN, "oracle_vectors.npz"))
+    src64, tgt64 = g["g1_src"].astype(np.float64), g["g1_tgt"].astype(np.float64)
+    cS, rS = ctx.preshape_stats(src64)
+    cT, rT = ctx.preshape_stats(tgt64)
+    st = g["g1_stats"]
+    assert _close(cS, st[0:3]) and _close(cT, st[3:6]) and _close(rS, st[9]) and _close(rT, st[10])
+    assert _close(rT / rS, st[11])
+    cS32, rS32 = ctx.preshape_stats(g["g1_src"])         # f32 input widened on load
+    assert _close(cS32, st[0:3]) and _close(rS32, st[9])
+
+
+def test_preshape_large_and_ragged(ctx, O, pkg):
+    for n in (1, 255, 257, 100003):
+        p = (pkg.synth.bumpy(n, n) * 3.0 + np.array([5.0, -2.0, 0.5]))
+        c, r = ctx.preshape_stats(p)
+        ps = O.preshape_stats(p, p)
+        assert _close(c, ps.c_src, 1e-11) and _close(r, ps.r_src, 1e-11)
+
+
+# ---- (a3,a7) pose application ----------------------------------------------------------------------------------------
+def test_pose_apply_bit_exact(ctx, O):
+    g = np.load(os.path.join(GOLDEN, "oracle_vectors.npz"))
+    src64 = g["g1_src"].astype(np.float64)
+    st = g["g1_stats"]
+    pose = ctx.make_pose(st[6:9], st[3:6], st[11], [0.7875, 5.5125, 3.15])
+    out = ctx.pose_apply(src64, pose)
+    assert np.array_equal(out, g["g3_pose"])            # same f64 operations, same order, no fma
+    pose0 = ctx.make_pose(st[6:9], st[3:6], st[11], [0, 0, 0])
+    assert np.array_equal(ctx.pose_apply(src64, pose0), g["g1_preshaped"])
+
+
+def test_transform_apply_matches_reference_expression(ctx):
+    rng = np.random.default_rng(1)
+    P = rng.normal(size=(1000, 3))
+    T = np.eye(4, dtype=np.float32); T[:3, :3] = rng.normal(size=(3, 3)).astype(np.float32); T[:3, 3] = [0.1, 0.2, 0.3]
+    out = ctx.transform_apply(T, P)
+    Td = T.astype(np.float64)
+    exp = np.stack([((Td[r, 0] * P[:, 0] + Td[r, 1] * P[:, 1]) + Td[r, 2] * P[:, 2]) + Td[r, 3] for r in range(3)], 1)
+    assert np.array_equal(out, exp)                      # KSS_ICP.hpp:224-230 evaluated left to right
+
+
+# ---- (a4) rotation search ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("step", [6, 8])
+def test_rotation_search_matches_oracle(ctx, pkg, step):
+    g = np.load(os.path.join(GOLDEN, "oracle_vectors.npz"))
+    err = ctx.rotation_search(g["g1_preshaped"], g["g1_tgt"].astype(np.float64), step)
+    ref = g["g2_value_%d" % step]
+    assert err.shape == ref.shape
+    assert _close(err, ref, 1e-12)
+    best, alist = pkg.rotation_candidates(err, step)
+    assert np.array_equal(best, g["g2_angle_%d" % step])
+    assert np.array_equal(alist, g["g2_list_%d" % step])
+
+
+# ---- (a9) ICP ---------------------------------------------------------------------------------------------------------
+def test_icp_trace_matches_oracle(ctx, O):
+    g = np.load(os.path.join(GOLDEN, "oracle_vectors.npz"))
+    r = ctx.icp(g["g4_src"], g["g4_tgt"], trace_cap=64)
+    assert r["iterations"] == int(g["g4_iters"][0]) and int(r["converged"]) == int(g["g4_iters"][1])
+    assert r["state"] == int(g["g4_iters"][2])
+    n = len(g["g4_trace_sums"])
+    assert len(r["trace_sums"]) == n
+    assert np.array_equal(r["trace_sums"][:, 0], g["g4_trace_sums"][:, 0])      # correspondence counts
+    assert _close(r["trace_sums"], g["g4_trace_sums"], 1e-9)
+    assert np.abs(r["trace_Tk"] - g["g4_trace_Tk"]).max() < 1e-6
+    assert np.abs(r["T"][:3, :3] - g["g4_T"][:3, :3]).max() < 1e-4              # north-star tolerance
+    assert np.abs(r["T"][:3, 3] - g["g4_T"][:3, 3]).max() < 1e-3
+    assert np.abs(r["T"] - g["g4_T"]).max() < 5e-6                              # what we actually reach
+    assert abs(r["fitness"] - g["g4_fitness"][0]) < 1e-9
+
+
+@pytest.mark.parametrize("ns,nt", [(3, 50), (900, 1300), (4000, 2500)])
+def test_icp_matches_oracle_ragged(ctx, O, pkg, ns, nt):
+    S = pkg.synth
+    src, tgt = S.make_pair(ns + nt, nt, R=S.rot_axis_angle([0.1, 0.9, 0.2], np.deg2rad(9.0)), t=(0.01, 0.02, -0.01),
+                           shape="bumpy", n_src=ns)
+    got = ctx.icp(src, tgt)
+    ref = O.icp(src, tgt)
+    assert got["iterations"] == ref["iterations"] and got["converged"] == ref["converged"] and got["state"] == ref["state"]
+    assert np.abs(got["T"] - ref["T"]).max() < 1e-5
+    assert abs(got["fitness"] - ref["fitness"]) < 1e-9
+
+
+def test_icp_fixed_iterations_and_fma_mode(ctx, O, pkg):
+    S = pkg.synth
+    src, tgt = S.make_pair(21, 3000, R=S.rot_axis_angle([0, 0, 1], np.deg2rad(10.0)))
+    p = ctx.icp_params(max_iterations=7, fixed_iterations=1)
+    got = ctx.icp(src, tgt, p)
+    ref = O.icp(src, tgt, O.icp_params(max_iterations=7, fixed_iterations=1))
+    assert got["iterations"] == 7 and ref["iterations"] == 7 and got["state"] == 1
+    assert np.abs(got["T"] - ref["T"]).max() < 1e-5
+    p = ctx.icp_params(max_iterations=7, fixed_iterations=1, nn_fma=1)
+    got = ctx.icp(src, tgt, p)
+    ref = O.icp(src, tgt, O.icp_params(max_iterations=7, fixed_iterations=1, fma=1))
+    assert np.abs(got["T"] - ref["T"]).max() < 1e-5
+
+
+def test_icp_not_enough_correspondences(ctx, O):
+    src = np.array([[10, 0, 0], [0, 10, 0], [0, 0, 10], [10, 10, 10]], np.float32)      # all farther than 1.0
+    tgt = np.zeros((8, 3), np.float32) + np.arange(8, dtype=np.float32)[:, None] * 0.01
+    got = ctx.icp(src, tgt)
+    ref = O.icp(src, tgt)
+    assert not got["converged"] and got["state"] == 5 and got["iterations"] == 0
+    assert ref["state"] == 5 and not ref["converged"]
+    assert np.array_equal(got["T"], np.eye(4, dtype=np.float32))
+    assert abs(got["fitness"] - ref["fitness"]) < 1e-9 * ref["fitness"]
+
+
+def test_icp_tuning_knobs_do_not_change_results(ctx, pkg):
+    S = pkg.synth
+    src, tgt = S.make_pair(5, 6000, R=S.rot_axis_angle([0, 1, 1], np.deg2rad(7.0)), shape="bumpy")
+    base = ctx.icp(src, tgt, ctx.icp_params(max_iterations=5, fixed_iterations=1), trace_cap=8)
+    for spt, split in [(1, 1), (2, 3), (4, 7), (8, 2)]:
+        r = ctx.icp(src, tgt, ctx.icp_params(max_iterations=5, fixed_iterations=1, nn_sources_per_thread=spt,
+                                             nn_target_splits=split), trace_cap=8)
+        assert np.array_equal(r["trace_sums"], base["trace_sums"])      # bitwise: exact NN + fixed-order sums
+        assert np.array_equal(r["T"], base["T"])
+
+
+def test_icp_batch_equals_singles(ctx, pkg):
+    S = pkg.synth
+    pairs = [S.config_c3_pair(i, n) for i, n in enumerate([1500, 800, 2300, 1, 1024])]
+    pairs[3] = (pairs[0][0][:1], pairs[3][1])         # a 1-point source: < 3 correspondences
+    src_all = np.concatenate([p[0] for p in pairs]); tgt_all = np.concatenate([p[1] for p in pairs])
+    so = np.cumsum([0] + [len(p[0]) for p in pairs]); to = np.cumsum([0] + [len(p[1]) for p in pairs])
+    res = ctx.icp_batch(src_all, so, tgt_all, to)
+    for i, (s, t) in enumerate(pairs):
+        one = ctx.icp(s, t)
+        assert res[i].pair_id == i
+        assert res[i].iterations == one["iterations"] and bool(res[i].converged) == one["converged"]
+        assert np.array_equal(res[i].matrix(), one["T"])
+        assert res[i].fitness == one["fitness"]
+    assert res[3].state == 5
+
+
+def test_icp_config_c2_shape(ctx, O, pkg):
+    """Config C2 inputs (100k x 100k sphere, R_z(10 deg)), a few fixed iterations, vs the kd-tree oracle."""
+    src, tgt = pkg.synth.config_c2(100000)
+    got = ctx.icp(src, tgt, ctx.icp_params(max_iterations=3, fixed_iterations=1), trace_cap=4)
+    ref = O.icp(src, tgt, O.icp_params(max_iterations=3, fixed_iterations=1, nthreads=8), trace_cap=4)
+    assert np.array_equal(got["trace_sums"][:, 0], ref["trace_sums"][:, 0])
+    assert _close(got["trace_sums"], ref["trace_sums"], 1e-9)
+    assert np.abs(got["T"] - ref["T"]).max() < 1e-5
+    assert abs(got["fitness"] - ref["fitness"]) < 1e-10
+
+
+# ---- PCR_QM and the orchestrated registration ------------------------------------------------------------------------------
+def test_pcr_qm_matches_oracle(ctx, O, ref_pairs):
+    S, T = ref_pairs[("registration", "Horse")]
+    got = ctx.pcr_qm(S, T)
+    ref = O.pcr_qm(S, T)
+    assert _close(got, ref, 1e-12)
+
+
+@pytest.mark.parametrize("key", [("registration", "Bunny"), ("registration", "Horse"), ("registration_scale", "Bunny")])
+def test_register_matches_oracle_on_reference_pairs(ctx, O, ref_pairs, key):
+    S, T = ref_pairs[key]
+    got = ctx.register(S, T, S, 8.0, 1000)
+    ref = O.kssicp_register(S, T, S, 8.0, 1000)
+    assert got["grid"] == 9 and got["n_angle_list"] == ref["n_angle_list"]
+    assert got["used_angle_list"] == ref["used_angle_list"] and got["angle_index"] == ref["angle_index"]
+    assert np.array_equal(got["angle"], ref["angle"])
+    assert _close(got["scale"], ref["scale"])
+    assert np.abs(got["R"] - ref["R"]).max() < 1e-4 and np.abs(got["t"] - ref["t"]).max() < 1e-3    # north star
+    assert np.abs(got["R"] - ref["R"]).max() < 1e-5
+    assert abs(got["E_d_init"] - ref["E_d_init"]) < 1e-8 and abs(got["final_fitness"] - ref["final_fitness"]) < 1e-8
+    assert np.abs(got["pointAlign"] - ref["pointAlign"]).max() < 1e-4

@@ -1,0 +1,89 @@
+// tools/valu_bench.hip -- FP32 VALU issue-rate microbenchmark for gfx950 (sizes the NN-sweep roofline).
+// Measures lane-ops/s for scalar vs packed f32 VALU instructions with every CU busy.
+// build: hipcc --offload-arch=gfx950 -O3 tools/valu_bench.hip -o tools/valu_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define REP 64
+template <int MODE>
+__global__ __launch_bounds__(256) void k(float* out, int iters) {
+    float a0 = threadIdx.x * 1e-3f, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    float b = 1.0000001f, c = 1e-9f;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, pb = {b, b}, pc = {c, c};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int r = 0; r < REP / 8; ++r) {
+            if (MODE == 0) {  // v_fma_f32
+                asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                             "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            } else if (MODE == 1) {  // v_mul_f32
+                asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
+                             "v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+            } else if (MODE == 2) {  // v_pk_mul_f32 (2 lanes-values per instr)
+                asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4\n"
+                             "v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4\n"
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb));
+            } else if (MODE == 3) {  // v_pk_fma_f32
+                asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n"
+                             "v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n"
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb), "v"(pc));
+            } else if (MODE == 4) {  // v_pk_add_f32
+                asm volatile("v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4\n"
+                             "v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4\n"
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pc));
+            } else if (MODE == 5) {  // v_min3_f32
+                asm volatile("v_min3_f32 %0, %0, %8, %9\n v_min3_f32 %1, %1, %8, %9\n v_min3_f32 %2, %2, %8, %9\n v_min3_f32 %3, %3, %8, %9\n"
+                             "v_min3_f32 %4, %4, %8, %9\n v_min3_f32 %5, %5, %8, %9\n v_min3_f32 %6, %6, %8, %9\n v_min3_f32 %7, %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            } else if (MODE == 6) {  // v_sub_f32 with an SGPR-free VGPR pair (same as add)
+                asm volatile("v_sub_f32 %0, %0, %8\n v_sub_f32 %1, %1, %8\n v_sub_f32 %2, %2, %8\n v_sub_f32 %3, %3, %8\n"
+                             "v_sub_f32 %4, %4, %8\n v_sub_f32 %5, %5, %8\n v_sub_f32 %6, %6, %8\n v_sub_f32 %7, %7, %8\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
+            } else if (MODE == 7) {  // v_min_f32
+                asm volatile("v_min_f32 %0, %0, %8\n v_min_f32 %1, %1, %8\n v_min_f32 %2, %2, %8\n v_min_f32 %3, %3, %8\n"
+                             "v_min_f32 %4, %4, %8\n v_min_f32 %5, %5, %8\n v_min_f32 %6, %6, %8\n v_min_f32 %7, %7, %8\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+            }
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
+}
+
+template <int MODE>
+double run(const char* name, int lanes_per_instr, int blocks, float* d_out) {
+    const int iters = 4096;
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d_out, 64);
+    hipDeviceSynchronize();
+    hipEventRecord(a);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d_out, iters);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    const double instr = (double)blocks * 256 * (double)iters * REP;   // lane-instructions
+    const double tl = instr / (ms * 1e-3) / 1e12;
+    printf("%-14s blocks=%5d  %8.3f ms  %7.2f T lane-instr/s  %7.2f T elem-ops/s\n", name, blocks, ms, tl, tl * lanes_per_instr);
+    return tl;
+}
+
+int main() {
+    float* d_out;
+    hipMalloc(&d_out, sizeof(float) * 256 * 8192);
+    for (int blocks : {256 * 2, 256 * 4, 256 * 8}) {
+        run<0>("v_fma_f32", 1, blocks, d_out);
+        run<1>("v_mul_f32", 1, blocks, d_out);
+        run<6>("v_sub_f32", 1, blocks, d_out);
+        run<7>("v_min_f32", 1, blocks, d_out);
+        run<5>("v_min3_f32", 1, blocks, d_out);
+        run<2>("v_pk_mul_f32", 2, blocks, d_out);
+        run<4>("v_pk_add_f32", 2, blocks, d_out);
+        run<3>("v_pk_fma_f32", 2, blocks, d_out);
+    }
+    return 0;
+}
