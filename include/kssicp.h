@@ -174,6 +174,16 @@ int kss_icp_batch_dev(kss_ctx *ctx, const float *d_src_all, const int64_t *src_o
 int kss_transform_apply(kss_ctx *ctx, const float T[16], const double *in, int64_t n, double *out);
 int kss_transform_apply_dev(kss_ctx *ctx, const float T[16], const double *d_in, int64_t n, double *d_out);
 
+/* pcl transformCloud / the PCL `output` cloud of align(): Matrix4f x float point, float result
+ * (KSS_ICP.hpp:162,170-180 read it back as pointAlign in the full-resolution overload) */
+int kss_transform_apply_f32(kss_ctx *ctx, const float T[16], const float *in, int64_t n, float *out);
+
+/* ---- down-sampling stand-in for AIVS (Method_AIVS_SimPro.hpp, KSS_ICP.hpp:71-81) ----
+ * Exact farthest-point sampling in f64 starting from point 0 (ties -> lowest index); returns the m
+ * selected points in selection order.  NOT AIVS parity: AIVS is the reference's own racy voxel-FPS
+ *  and is the next component to build; this keeps KSSICP_Registration drop-in. */
+int kss_downsample_fps(kss_ctx *ctx, const double *xyz, int64_t n, int64_t m, double *out, int32_t *out_idx);
+
 /* ---- PCR_QM: registrationMeasure.hpp:47-98 -> out = {MSE, RMSE, MAE} ---- */
 int kss_pcr_qm(kss_ctx *ctx, const double *aligned, int64_t na, const double *tmpl, int64_t nt,
                double out[3]);
@@ -183,6 +193,7 @@ typedef struct {
     double  scale;
     double  angle[3];         /* chosen Euler angles */
     double  R[9], t[3];       /* composite similarity p' = scale*R*p + t */
+    double  c_src[3], c_tgt[3]; /* pre-shape centroids of S', T' (x_middle_S.. = c_tgt, x_middle.. = c_tgt - c_src) */
     float   T_icp[16];
     double  E_d_init;         /* :93 */
     double  final_fitness;    /* :130 */

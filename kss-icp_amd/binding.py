@@ -23,7 +23,7 @@ SYMBOLS = [
     "kss_nn", "kss_nn_dev", "kss_cov", "kss_cov_dev", "kss_rigid_from_sums", "kss_rotation_search",
     "kss_rotation_search_dev", "kss_grid_angles", "kss_rotation_candidates", "kss_icp_default_params", "kss_icp",
     "kss_icp_dev", "kss_icp_batch", "kss_icp_batch_dev", "kss_transform_apply", "kss_transform_apply_dev",
-    "kss_pcr_qm", "kss_register", "kss_gather_results",
+    "kss_pcr_qm", "kss_register", "kss_gather_results", "kss_transform_apply_f32", "kss_downsample_fps",
 ]
 
 
@@ -60,7 +60,7 @@ class Pose(C.Structure):
 
 class RegisterResult(C.Structure):
     _fields_ = [("scale", C.c_double), ("angle", C.c_double * 3), ("R", C.c_double * 9), ("t", C.c_double * 3),
-                ("T_icp", C.c_float * 16), ("E_d_init", C.c_double), ("final_fitness", C.c_double),
+                ("c_src", C.c_double * 3), ("c_tgt", C.c_double * 3), ("T_icp", C.c_float * 16), ("E_d_init", C.c_double), ("final_fitness", C.c_double),
                 ("used_angle_list", C.c_int32), ("angle_index", C.c_int32), ("n_angle_list", C.c_int32),
                 ("icp_iterations", C.c_int32), ("icp_converged", C.c_int32), ("grid", C.c_int32)]
 
@@ -124,6 +124,8 @@ def load_library():
     for n in ("kss_transform_apply", "kss_transform_apply_dev"):
         getattr(L, n).argtypes = [vp, vp, vp, i64, vp]
     L.kss_pcr_qm.argtypes = [vp, vp, i64, vp, i64, vp]
+    L.kss_transform_apply_f32.argtypes = [vp, vp, vp, i64, vp]
+    L.kss_downsample_fps.argtypes = [vp, vp, i64, i64, vp, vp]
     L.kss_register.argtypes = [vp, vp, i64, vp, i64, vp, i64, dbl, C.c_int, vp, C.POINTER(RegisterResult)]
     L.kss_gather_results.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
     _LIB = L
@@ -351,6 +353,20 @@ class Context:
         self._chk(self.L.kss_icp_batch_dev(self.h, C.c_void_p(int(d_src_all)), _p(so), C.c_void_p(int(d_tgt_all)), _p(to),
                                            npairs, C.byref(params), C.cast(res, C.c_void_p)), "kss_icp_batch_dev")
         return res
+
+    def transform_apply_f32(self, T, pts):
+        a = _f32(pts)
+        Tm = np.ascontiguousarray(T, dtype=np.float32).reshape(16)
+        out = np.empty_like(a)
+        self._chk(self.L.kss_transform_apply_f32(self.h, _p(Tm), _p(a), len(a), _p(out)), "kss_transform_apply_f32")
+        return out
+
+    def downsample_fps(self, pts, m):
+        a = _f64(pts)
+        out = np.empty((int(m), 3), np.float64)
+        idx = np.empty(int(m), np.int32)
+        self._chk(self.L.kss_downsample_fps(self.h, _p(a), len(a), int(m), _p(out), _p(idx)), "kss_downsample_fps")
+        return out, idx
 
     # ---- PCR_QM
     def pcr_qm(self, aligned, tmpl):

@@ -1,0 +1,57 @@
+// mirror_check.cpp -- exercises the C++ mirror classes (include/*.hpp) end to end on the GPU and prints
+// machine-readable lines that tests/test_gpu_cli.py compares with the oracle.
+// usage: mirror_check src.xyzn tgt.xyzn   (files: first line N, then N lines "x y z")
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <vector>
+
+#include "KSS_ICP.hpp"
+#include "initRegistrationKSS.hpp"
+#include "registrationMeasure.hpp"
+
+static std::vector<std::vector<double>> load(const char* path) {
+    std::ifstream fin(path);
+    std::vector<std::vector<double>> out;
+    size_t n = 0;
+    fin >> n;
+    for (size_t i = 0; i < n; ++i) {
+        double x, y, z;
+        fin >> x >> y >> z;
+        out.push_back({x, y, z});
+    }
+    return out;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 3) return 2;
+    auto S = load(argv[1]), T = load(argv[2]);
+    std::printf("LOADED %zu %zu\n", S.size(), T.size());
+    try {
+        initRegistration_KSS ir;
+        ir.initRegistration_init(S, T, 6);
+        std::printf("PRESHAPE %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", ir.x_middle_S, ir.y_middle_S, ir.z_middle_S, ir.x_middle,
+                    ir.y_middle, ir.z_middle, ir.scale);
+        std::printf("ANGLE %.17g %.17g %.17g NLIST %zu GRID %d\n", ir.angle[0], ir.angle[1], ir.angle[2], ir.angleList.size(), ir.gridSize());
+        auto P = ir.initRegistration_Rotation(S);
+        std::printf("POSE0 %.17g %.17g %.17g\n", P[0][0], P[0][1], P[0][2]);
+        KSSICP ki;
+        ki.KSSICP_init(S, T, 6);
+        const double f = ki.shapeRegistration_ICP_Judge(1000, P, T);
+        std::printf("JUDGE %.17g\n", f);
+        const double f2 = ki.shapeRegistration_ICP(1000, P, T);
+        std::printf("ICP2 %.17g ALIGN0 %.17g %.17g %.17g\n", f2, ki.pointAlign[0][0], ki.pointAlign[0][1], ki.pointAlign[0][2]);
+        PCR_QM pq;
+        pq.PCR_QM_init(P, T);
+        auto m = pq.PCR_QM_ReturnResult();
+        std::printf("QM %.17g %.17g %.17g\n", m[0], m[1], m[2]);
+        KSSICP k2;
+        k2.KSSICP_init(S, T, 6);
+        k2.KSSICP_Registration(1000);
+        std::printf("REG scale %.17g fitness %.17g n %zu\n", k2.lastRegistration.scale, k2.lastRegistration.final_fitness, k2.pointAlign.size());
+    } catch (const std::exception& e) {
+        std::printf("FAILED %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

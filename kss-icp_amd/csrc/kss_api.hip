@@ -724,6 +724,39 @@ int kss_transform_apply(kss_ctx* c, const float T[16], const double* in, int64_t
     return KSS_OK;
 }
 
+int kss_transform_apply_f32(kss_ctx* c, const float T[16], const float* in, int64_t n, float* out) {
+    if (!c || !T || !in || !out) return set_err(c, KSS_ERR_ARG, "transform_apply_f32: null argument");
+    if (n < 0) return set_err(c, KSS_ERR_ARG, "transform_apply_f32: negative size");
+    if (n == 0) return KSS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    KCHK(upload(c, c->stage_src, in, (size_t)n * 3 * sizeof(float)));
+    KCHK(ensure(c, c->stage_out, (size_t)n * 3 * sizeof(float)));
+    {
+        ProfScope ps(c, KSS_K_POSE_APPLY);
+        launch_transform_apply_f32(c->stream, T, (const float*)c->stage_src.p, n, (float*)c->stage_out.p);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->stage_out.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KSS_OK;
+}
+
+int kss_downsample_fps(kss_ctx* c, const double* xyz, int64_t n, int64_t m, double* out, int32_t* out_idx) {
+    if (!c || !xyz || !out) return set_err(c, KSS_ERR_ARG, "downsample_fps: null argument");
+    if (n <= 0 || m <= 0 || m > n || n > 0x7fff0000ll) return set_err(c, KSS_ERR_ARG, "downsample_fps: need 0 < m <= n");
+    HIPCHK(c, hipSetDevice(c->device));
+    KCHK(upload(c, c->scratch_a, xyz, (size_t)n * 3 * sizeof(double)));
+    KCHK(ensure(c, c->scratch_b, (size_t)n * sizeof(double)));
+    KCHK(ensure(c, c->stage_idx, (size_t)m * sizeof(int32_t)));
+    KCHK(ensure(c, c->stage_out, (size_t)m * 3 * sizeof(double)));
+    launch_fps(c->stream, (const double*)c->scratch_a.p, (int)n, (int)m, (double*)c->scratch_b.p, (int32_t*)c->stage_idx.p, (double*)c->stage_out.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->stage_out.p, (size_t)m * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (out_idx) HIPCHK(c, hipMemcpyAsync(out_idx, c->stage_idx.p, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KSS_OK;
+}
+
 // ---- rotation search --------------------------------------------------------------------------------
 int kss_grid_angles(double step, double* angles, int capacity) {
     if (!angles || capacity <= 0 || !(step > 0)) return KSS_ERR_ARG;
@@ -847,6 +880,7 @@ int kss_register(kss_ctx* c, const double* src_sub, int64_t nss, const double* t
     for (int k = 0; k < 3; ++k) { pose.shift[k] = cT[k] - cS[k]; pose.center[k] = cT[k]; pose.angle[k] = 0.0; }
     pose.scale = rT / rS;
     res->scale = pose.scale;
+    for (int k = 0; k < 3; ++k) { res->c_src[k] = cS[k]; res->c_tgt[k] = cT[k]; }
     RCHK(kss_pose_apply_dev(c, (const double*)dS.p, nss, &pose, (double*)dP.p));   // S' (angle 0 -> exact identity rotation)
     // (a4) rotation search
     std::vector<double> err(40 * 40 * 40);

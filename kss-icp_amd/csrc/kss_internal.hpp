@@ -83,6 +83,9 @@ void launch_pose_apply(hipStream_t st, const double* d_in, int64_t n, const kss_
                        const double cs[6], double* d_out);
 void launch_transform_apply_f64(hipStream_t st, const float T[16], const double* d_in, int64_t n, double* d_out);
 
+void launch_transform_apply_f32(hipStream_t st, const float T[16], const float* d_in, int64_t n, float* d_out);
+void launch_fps(hipStream_t st, const double* d_xyz, int n, int m, double* d_mind, int32_t* d_idx, double* d_out);
+
 void launch_rot_search(hipStream_t st, const double* d_src, int64_t ns, const float4* d_tgt4, int64_t nt_pad,
                        const double* d_cs /* g*2: cos,sin */, int g, double* d_partials, int n_src_blocks);
 

@@ -476,6 +476,78 @@ void launch_transform_apply_f64(hipStream_t st, const float T[16], const double*
     hipLaunchKernelGGL(transform_apply_f64_kernel, dim3(preshape_blocks(n)), dim3(256), 0, st, d_in, n, m, d_out);
 }
 
+__global__ __launch_bounds__(256) void transform_apply_f32_kernel(const float* __restrict__ in, int64_t n, M34 T,
+                                                                  float* __restrict__ out) {
+    // pcl transformCloud: pt_t = tr * (x, y, z, 1), Eigen order, float, no fma
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) out[3 * i + r] = ((T.m[4 * r] * x + T.m[4 * r + 1] * y) + T.m[4 * r + 2] * z) + T.m[4 * r + 3];
+    }
+}
+
+void launch_transform_apply_f32(hipStream_t st, const float T[16], const float* d_in, int64_t n, float* d_out) {
+    if (n <= 0) return;
+    M34 m;
+    for (int k = 0; k < 12; ++k) m.m[k] = T[k];
+    hipLaunchKernelGGL(transform_apply_f32_kernel, dim3(preshape_blocks(n)), dim3(256), 0, st, d_in, n, m, d_out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// farthest-point sampling (AIVS stand-in): ONE workgroup of 1024 lanes iterates m-1 times over the
+// cloud, keeping min-distance-to-selected per point in global memory and an arg-max per iteration
+// (wave shuffle -> LDS).  Ties -> lowest index, so the result is deterministic.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void fps_kernel(const double* __restrict__ xyz, int n, int m,
+                                                   double* __restrict__ mind, int32_t* __restrict__ out_idx,
+                                                   double* __restrict__ out_xyz) {
+    __shared__ double s_val[16];
+    __shared__ int s_idx[16];
+    __shared__ int s_cur;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < n; i += 1024) mind[i] = __builtin_inf();
+    int cur = 0;
+    for (int k = 0; k < m; ++k) {
+        if (tid == 0) {
+            out_idx[k] = cur;
+            out_xyz[3 * k] = xyz[3 * (int64_t)cur]; out_xyz[3 * k + 1] = xyz[3 * (int64_t)cur + 1]; out_xyz[3 * k + 2] = xyz[3 * (int64_t)cur + 2];
+        }
+        if (k + 1 == m) break;
+        const double cx = xyz[3 * (int64_t)cur], cy = xyz[3 * (int64_t)cur + 1], cz = xyz[3 * (int64_t)cur + 2];
+        double bv = -1.0;
+        int bi = 0x7fffffff;
+        for (int i = tid; i < n; i += 1024) {
+            const double dx = xyz[3 * (int64_t)i] - cx, dy = xyz[3 * (int64_t)i + 1] - cy, dz = xyz[3 * (int64_t)i + 2] - cz;
+            const double d = (dx * dx + dy * dy) + dz * dz;
+            const double mnew = fmin(mind[i], d);
+            mind[i] = mnew;
+            if (mnew > bv) { bv = mnew; bi = i; }   // ascending i per lane: first maximum kept
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_down(bv, off, 64);
+            const int oi = __shfl_down(bi, off, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { s_val[wave] = bv; s_idx[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            double v = s_val[0];
+            int ix = s_idx[0];
+            for (int w = 1; w < 16; ++w)
+                if (s_val[w] > v || (s_val[w] == v && s_idx[w] < ix)) { v = s_val[w]; ix = s_idx[w]; }
+            s_cur = ix;
+        }
+        __syncthreads();
+        cur = s_cur;
+        __syncthreads();
+    }
+}
+
+void launch_fps(hipStream_t st, const double* d_xyz, int n, int m, double* d_mind, int32_t* d_idx, double* d_out) {
+    hipLaunchKernelGGL(fps_kernel, dim3(1), dim3(1024), 0, st, d_xyz, n, m, d_mind, d_idx, d_out);
+}
+
 // ---------------------------------------------------------------------------------------------
 // rotation search: grid = (source blocks, g^3 candidates).  Each lane rotates its pre-shaped
 // source point in f64 by the candidate's Euler angles, narrows to f32 (:440-442), sweeps the

@@ -752,6 +752,26 @@ int64_t ko_ply_load(const char *path, double **pts) {
 }
 
 /* ------------------------------------------------------------------------------------ */
+void ko_fps(const double *xyz, int64_t n, int64_t m, int32_t *idx) {
+    double *mind = (double *)malloc(sizeof(double) * (size_t)n);
+    for (int64_t i = 0; i < n; i++) mind[i] = INFINITY;
+    int64_t cur = 0;
+    for (int64_t k = 0; k < m; k++) {
+        idx[k] = (int32_t)cur;
+        if (k + 1 == m) break;
+        double bv = -1.0; int64_t bi = 0;
+        for (int64_t i = 0; i < n; i++) {
+            double dx = xyz[3 * i] - xyz[3 * cur], dy = xyz[3 * i + 1] - xyz[3 * cur + 1], dz = xyz[3 * i + 2] - xyz[3 * cur + 2];
+            double d = (dx * dx + dy * dy) + dz * dz;
+            if (d < mind[i]) mind[i] = d;
+            if (mind[i] > bv) { bv = mind[i]; bi = i; }
+        }
+        cur = bi;
+    }
+    free(mind);
+}
+
+/* ------------------------------------------------------------------------------------ */
 uint64_t ko_splitmix64(uint64_t seed, uint64_t counter) {
     uint64_t z = seed + (counter + 1) * 0x9E3779B97F4A7C15ULL;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;

@@ -158,6 +158,12 @@ int ko_kssicp_register(const double *Ssub, int64_t nss, const double *Tsub, int6
 int64_t ko_ply_load(const char *path, double **pts);
 void ko_free(void *p);
 
+/* ---- farthest-point sampling: the checker of the product's AIVS stand-in (kss_downsample_fps).
+ * NOT a restatement of the reference (AIVS, Method_AIVS_SimPro.hpp, is not built: SURVEY 8f #1):
+ * start at point 0, repeatedly take the point farthest (f64 squared distance, ties -> lowest index)
+ * from the selected set. */
+void ko_fps(const double *xyz, int64_t n, int64_t m, int32_t *idx);
+
 /* ---- synthetic clouds (portable counter-based RNG) ---- */
 uint64_t ko_splitmix64(uint64_t seed, uint64_t counter);
 

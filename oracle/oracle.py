@@ -86,6 +86,7 @@ def lib():
         L.ko_ply_load.restype = C.c_int64
         L.ko_ply_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_double))]
         L.ko_free.argtypes = [C.c_void_p]
+        L.ko_fps.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.ko_splitmix64.restype = C.c_uint64
         L.ko_splitmix64.argtypes = [C.c_uint64, C.c_uint64]
     return _LIB
@@ -283,6 +284,13 @@ def ply_load(path):
     arr = np.ctypeslib.as_array(pp, shape=(n * 3,)).reshape(n, 3).copy() if n > 0 else np.zeros((0, 3))
     lib().ko_free(pp)
     return int(n), arr
+
+
+def fps(xyz, m):
+    a = _f64(xyz)
+    idx = np.empty(int(m), np.int32)
+    lib().ko_fps(_p(a), len(a), int(m), _p(idx))
+    return idx
 
 
 def splitmix64(seed, counter):

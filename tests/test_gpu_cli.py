@@ -1,0 +1,87 @@
+"""GPU tests of the C++ host mirror (include/*.hpp) and the CLI: the reference's class surface driven the
+way Main_KSS_ICP.cpp drives it, compared with the oracle."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(ROOT, "kss-icp_amd", "cli")
+
+
+def _build():
+    subprocess.check_call(["make", "-C", CLI, "-s"])
+
+
+def _vals(out, tag):
+    line = [l for l in out.splitlines() if l.startswith(tag + " ")][0]
+    return [float(x) for x in re.findall(r"[-+]?\d+\.?\d*(?:[eE][-+]?\d+)?", line[len(tag):])]
+
+
+def test_downsample_and_transform_f32(ctx, O, pkg):
+    P = pkg.synth.bumpy(3, 5000) * 0.7 + np.array([0.3, -0.1, 0.2])
+    out, idx = ctx.downsample_fps(P, 300)
+    ref = O.fps(P, 300)
+    assert np.array_equal(idx, ref) and np.array_equal(out, P[ref])
+    assert len(set(idx.tolist())) == 300 and idx[0] == 0
+    out1, idx1 = ctx.downsample_fps(P, 1)
+    assert idx1[0] == 0
+    outn, idxn = ctx.downsample_fps(P[:50], 50)
+    assert sorted(idxn.tolist()) == list(range(50))
+    with pytest.raises(pkg.KssError):
+        ctx.downsample_fps(P[:10], 11)
+    T = np.eye(4, dtype=np.float32); T[:3, :3] = pkg.synth.rot_axis_angle([1, 2, 3], 0.4).astype(np.float32); T[:3, 3] = [0.5, 0.25, -1]
+    p32 = P.astype(np.float32)
+    assert np.array_equal(ctx.transform_apply_f32(T, p32), O.transform_points_f32(T, p32))
+
+
+def test_mirror_classes_against_oracle(O, ref_pairs):
+    _build()
+    d = os.path.join(GOLDEN, "ref_data", "registration")
+    r = subprocess.run([os.path.join(CLI, "mirror_check"), os.path.join(d, "Horse.gird"), os.path.join(d, "Horse.wlop")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout
+    S, T = ref_pairs[("registration", "Horse")]
+    ps = O.preshape_stats(S, T)
+    pre = _vals(out, "PRESHAPE")
+    assert np.allclose(pre[0:3], ps.c_tgt, rtol=1e-12, atol=1e-13) and np.allclose(pre[3:6], ps.shift, rtol=1e-12, atol=1e-13)
+    assert abs(pre[6] - ps.scale) < 1e-12
+    rs = O.rotation_search(O.similarity_apply(S, ps), T, 6)
+    ang = _vals(out, "ANGLE")
+    assert ang[0:3] == list(rs["angle"]) and int(ang[3]) == len(rs["angle_list"]) and int(ang[4]) == 6
+    P = O.pose_apply(S, ps, rs["angle"])
+    assert np.allclose(_vals(out, "POSE0"), P[0], rtol=0, atol=1e-14)
+    ri = O.icp(P.astype(np.float32), T.astype(np.float32))
+    assert abs(_vals(out, "JUDGE")[0] - ri["fitness"]) < 1e-8
+    icp2 = _vals(out, "ICP2")
+    assert abs(icp2[0] - ri["fitness"]) < 1e-8
+    Td = ri["T"].astype(np.float64)
+    exp0 = Td[:3, :3] @ S[0] + Td[:3, 3]        # member pointSource is the ORIGINAL source here (:224)
+    assert np.allclose(icp2[1:4], exp0, atol=1e-4)
+    assert np.allclose(_vals(out, "QM"), O.pcr_qm(P, T), rtol=1e-10)
+    reg = _vals(out, "REG")
+    assert abs(reg[0] - 1.0) < 5e-2 and reg[1] < 1e-3 and int(reg[2]) == len(S)
+
+
+def test_cli_config_c1(pkg, tmp_path):
+    """Config C1: two 2k-point uniform-sphere PLYs, 30 degree rotation, through the CLI front-end."""
+    _build()
+    S = pkg.synth
+    src, tgt = S.make_pair(0, 2000, R=S.rot_axis_angle([0, 0, 1], np.deg2rad(30.0)))
+    ps, pt, po = str(tmp_path / "s.ply"), str(tmp_path / "t.ply"), str(tmp_path / "o.xyz")
+    S.write_ply(ps, src); S.write_ply(pt, tgt)
+    r = subprocess.run([os.path.join(CLI, "kss_icp"), ps, pt, po], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "registration finished." in r.stdout and "Registration Measure:MSE:" in r.stdout
+    mse = float(re.search(r"Registration Measure:MSE: (\S+)", r.stdout).group(1))
+    assert mse < 1e-3          # a sphere is rotation-degenerate: only the fit quality is meaningful
+    lines = open(po).read().split("\n")
+    assert int(lines[0]) == 2000 and len(lines[1].split()) == 3
+    # missing file: reference-style diagnostics, non-zero exit
+    r = subprocess.run([os.path.join(CLI, "kss_icp"), str(tmp_path / "nope.ply"), pt], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "failed" in r.stdout
