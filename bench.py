@@ -105,14 +105,13 @@ def main():
     ctx = pkg.Context(local_rank)       # raises without libkssicp.so / GPU
     params = ctx.icp_params(max_iterations=a.iters, fixed_iterations=1, compute_fitness=1, nn_fma=a.fma,
                             nn_sources_per_thread=a.spt, nn_target_splits=a.splits)
-    rec = torch.zeros(96, dtype=torch.uint8, device=dev)
-    allrec = torch.zeros(96 * world, dtype=torch.uint8, device=dev)
+    RecArr = pkg.IcpResult * 1
 
     def step():
         res = ctx.icp_dev(d_src.data_ptr(), a.n, d_tgt.data_ptr(), a.n, params)
-        if world > 1:       # final gather of the (R,t) records over RCCL/xGMI
-            rec.copy_(torch.frombuffer(bytearray(bytes(res)), dtype=torch.uint8))
-            dist.all_gather_into_tensor(allrec, rec)
+        if world > 1:       # final gather of the (R,t) records over RCCL/xGMI: one 96-B record per pair
+            local = pkg.shard.records_to_array(RecArr(res), rank)
+            pkg.shard.gather_records(local, world, world, rank, device=dev)
         return res
 
     for _ in range(a.warmup):

@@ -12,6 +12,7 @@ from .binding import (KssError, Context, IcpParams, IcpResult, RegisterResult, P
                       exported_symbols, NSUMS, K_NN_SWEEP, K_CORR_REDUCE, K_PRESHAPE, K_ROT_SEARCH, K_POSE_APPLY,
                       grid_angles, rotation_candidates, rigid_from_sums, build_library)
 from . import synth
+from . import shard
 
 __all__ = ["KssError", "Context", "IcpParams", "IcpResult", "RegisterResult", "Pose", "lib_path", "load_library",
            "exported_symbols", "NSUMS", "grid_angles", "rotation_candidates", "rigid_from_sums", "build_library", "synth"]

@@ -62,13 +62,16 @@ def test_mirror_classes_against_oracle(O, ref_pairs):
     assert abs(icp2[0] - ri["fitness"]) < 1e-8
     Td = ri["T"].astype(np.float64)
     exp0 = Td[:3, :3] @ S[0] + Td[:3, 3]        # member pointSource is the ORIGINAL source here (:224)
-    assert np.allclose(icp2[1:4], exp0, atol=1e-4)
+    assert np.allclose(icp2[2:5], exp0, atol=1e-4)     # icp2[1] is the "0" of the ALIGN0 tag
     assert np.allclose(_vals(out, "QM"), O.pcr_qm(P, T), rtol=1e-10)
     reg = _vals(out, "REG")
-    assert abs(reg[0] - 1.0) < 5e-2 and reg[1] < 1e-3 and int(reg[2]) == len(S)
+    # KSSICP_Registration = FPS down-sample (pNumber = min(n)/2, KSS_ICP.hpp:57-66) + kss_register: same pipeline on the oracle
+    m = min(len(S), len(T)) // 2
+    ko = O.kssicp_register(S[O.fps(S, m)], T[O.fps(T, m)], S, 6.0, 1000)
+    assert abs(reg[0] - ko["scale"]) < 1e-12 and abs(reg[1] - ko["final_fitness"]) < 1e-8 and int(reg[2]) == len(S)
 
 
-def test_cli_config_c1(pkg, tmp_path):
+def test_cli_config_c1(pkg, O, tmp_path):
     """Config C1: two 2k-point uniform-sphere PLYs, 30 degree rotation, through the CLI front-end."""
     _build()
     S = pkg.synth
@@ -79,7 +82,10 @@ def test_cli_config_c1(pkg, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "registration finished." in r.stdout and "Registration Measure:MSE:" in r.stdout
     mse = float(re.search(r"Registration Measure:MSE: (\S+)", r.stdout).group(1))
-    assert mse < 1e-3          # a sphere is rotation-degenerate: only the fit quality is meaningful
+    # a sphere is rotation-degenerate: compare the fit quality with the same pipeline on the oracle
+    s64, t64 = src.astype(np.float64), tgt.astype(np.float64)
+    ko = O.kssicp_register(s64[O.fps(s64, 1000)], t64[O.fps(t64, 1000)], s64, 8.0, 1000)
+    assert abs(mse - O.pcr_qm(ko["pointAlign"], t64)[0]) < 1e-6 * mse + 1e-9
     lines = open(po).read().split("\n")
     assert int(lines[0]) == 2000 and len(lines[1].split()) == 3
     # missing file: reference-style diagnostics, non-zero exit
