@@ -39,6 +39,7 @@ def parse_args():
     ap.add_argument("--fma", type=int, default=0, help="1: fused distance form (not bit-parity)")
     ap.add_argument("--spt", type=int, default=0, help="NN sources per thread (0 = auto)")
     ap.add_argument("--splits", type=int, default=0, help="NN target splits (0 = auto)")
+    ap.add_argument("--mode", default="auto", choices=["auto", "brute", "grid"], help="NN search structure (same results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -104,7 +105,8 @@ def main():
 
     ctx = pkg.Context(local_rank)       # raises without libkssicp.so / GPU
     params = ctx.icp_params(max_iterations=a.iters, fixed_iterations=1, compute_fitness=1, nn_fma=a.fma,
-                            nn_sources_per_thread=a.spt, nn_target_splits=a.splits)
+                            nn_sources_per_thread=a.spt, nn_target_splits=a.splits,
+                            nn_mode={"auto": pkg.NN_AUTO, "brute": pkg.NN_BRUTE, "grid": pkg.NN_GRID}[a.mode])
     RecArr = pkg.IcpResult * 1
 
     def step():
@@ -131,6 +133,8 @@ def main():
     dt = time.perf_counter() - t0
     nn_ms, nn_launches = ctx.profile_get(pkg.K_NN_SWEEP)
     red_ms, red_launches = ctx.profile_get(pkg.K_CORR_REDUCE)
+    grid_ms, grid_launches = ctx.profile_get(pkg.K_GRID_NN)
+    build_ms, build_launches = ctx.profile_get(pkg.K_GRID_BUILD)
     ctx.profile_enable(False)
 
     if world > 1:
@@ -169,6 +173,9 @@ def main():
                                  "achieved": alg_bytes / nn_avg_s / 1e9 if nn_avg_s > 0 else 0.0, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": (alg_bytes / nn_avg_s / 1e9 / HBM_PEAK_GBS) if nn_avg_s > 0 else 0.0}},
             "corr_reduce": {"avg_launch_ms": red_ms / max(1, red_launches), "launches": red_launches},
+            "grid_nn": {"avg_launch_ms": grid_ms / max(1, grid_launches), "launches": grid_launches,
+                        "build_avg_ms": build_ms / max(1, build_launches), "builds": build_launches},
+            "nn_mode": a.mode,
             "result": {"iterations": int(last.iterations), "fitness": float(last.fitness)},
         }
         if world == 1 and not a.no_cpu_baseline:

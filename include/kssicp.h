@@ -57,10 +57,14 @@ int   kss_ctx_destroy(kss_ctx *ctx);
 int   kss_ctx_synchronize(kss_ctx *ctx);
 void *kss_ctx_stream(kss_ctx *ctx);
 
+/* default NN search structure of this context (KSS_NN_AUTO / _BRUTE / _GRID, see below); used whenever an
+ * entry point has no nn_mode of its own or it is KSS_NN_AUTO.  Results never depend on it. */
+int   kss_ctx_set_nn_mode(kss_ctx *ctx, int nn_mode);
+
 /* per-kernel timing with HIP events recorded on the context's stream around every launch of
  * the named kernel class (used by bench.py for the roofline object). */
 enum { KSS_K_NN_SWEEP = 0, KSS_K_CORR_REDUCE = 1, KSS_K_PRESHAPE = 2, KSS_K_ROT_SEARCH = 3,
-       KSS_K_POSE_APPLY = 4, KSS_K_COUNT = 5 };
+       KSS_K_POSE_APPLY = 4, KSS_K_GRID_NN = 5, KSS_K_GRID_BUILD = 6, KSS_K_COUNT = 7 };
 int kss_profile_enable(kss_ctx *ctx, int on);
 int kss_profile_reset(kss_ctx *ctx);
 /* synchronises the stream; total_ms = sum of event-timed durations, launches = count */
@@ -136,12 +140,18 @@ typedef struct {
     int    compute_fitness;            /* getFitnessScore() after align (:164) */
     int    nn_sources_per_thread;      /* tuning, 0 = auto */
     int    nn_target_splits;           /* tuning, 0 = auto */
+    int    nn_mode;                    /* KSS_NN_AUTO / KSS_NN_BRUTE / KSS_NN_GRID: same results bit for bit */
     /* optional per-iteration trace for parity tests (host pointers, may be NULL) */
     double *trace_sums;                /* trace_cap * KSS_NSUMS */
     float  *trace_Tk;                  /* trace_cap * 16 */
     int     trace_cap;
     int    *trace_n;
 } kss_icp_params;
+
+/* NN search structure.  BRUTE: the LDS-tiled source x target sweep (north star).  GRID: exact search
+ * through a uniform cell list built once per target, queries unresolved within a few cell shells fall
+ * back to the brute-force sweep.  AUTO picks GRID for one large pair, BRUTE otherwise. */
+enum { KSS_NN_AUTO = 0, KSS_NN_BRUTE = 1, KSS_NN_GRID = 2 };
 
 enum { KSS_STATE_NOT_CONVERGED = 0, KSS_STATE_ITERATIONS = 1, KSS_STATE_TRANSFORM = 2,
        KSS_STATE_ABS_MSE = 3, KSS_STATE_REL_MSE = 4, KSS_STATE_NO_CORRESPONDENCES = 5 };

@@ -12,13 +12,14 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 NSUMS = 20
-K_NN_SWEEP, K_CORR_REDUCE, K_PRESHAPE, K_ROT_SEARCH, K_POSE_APPLY = 0, 1, 2, 3, 4
+K_NN_SWEEP, K_CORR_REDUCE, K_PRESHAPE, K_ROT_SEARCH, K_POSE_APPLY, K_GRID_NN, K_GRID_BUILD = 0, 1, 2, 3, 4, 5, 6
+NN_AUTO, NN_BRUTE, NN_GRID = 0, 1, 2
 F32, F64 = 0, 1
 
 # every symbol include/kssicp.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = [
     "kss_version", "kss_status_string", "kss_last_error", "kss_ctx_create", "kss_ctx_create_on_stream",
-    "kss_ctx_destroy", "kss_ctx_synchronize", "kss_ctx_stream", "kss_profile_enable", "kss_profile_reset",
+    "kss_ctx_destroy", "kss_ctx_synchronize", "kss_ctx_stream", "kss_ctx_set_nn_mode", "kss_profile_enable", "kss_profile_reset",
     "kss_profile_get", "kss_preshape_stats", "kss_preshape_stats_dev", "kss_pose_apply", "kss_pose_apply_dev",
     "kss_nn", "kss_nn_dev", "kss_cov", "kss_cov_dev", "kss_rigid_from_sums", "kss_rotation_search",
     "kss_rotation_search_dev", "kss_grid_angles", "kss_rotation_candidates", "kss_icp_default_params", "kss_icp",
@@ -41,7 +42,7 @@ class IcpParams(C.Structure):
                 ("transformation_epsilon", C.c_double), ("euclidean_fitness_epsilon", C.c_double),
                 ("abs_mse_epsilon", C.c_double), ("min_correspondences", C.c_int),
                 ("fixed_iterations", C.c_int), ("nn_fma", C.c_int), ("compute_fitness", C.c_int),
-                ("nn_sources_per_thread", C.c_int), ("nn_target_splits", C.c_int),
+                ("nn_sources_per_thread", C.c_int), ("nn_target_splits", C.c_int), ("nn_mode", C.c_int),
                 ("trace_sums", C.POINTER(C.c_double)), ("trace_Tk", C.POINTER(C.c_float)),
                 ("trace_cap", C.c_int), ("trace_n", C.POINTER(C.c_int))]
 
@@ -100,6 +101,7 @@ def load_library():
     L.kss_ctx_synchronize.argtypes = [vp]
     L.kss_ctx_stream.restype = vp
     L.kss_ctx_stream.argtypes = [vp]
+    L.kss_ctx_set_nn_mode.argtypes = [vp, C.c_int]
     L.kss_profile_enable.argtypes = [vp, C.c_int]
     L.kss_profile_reset.argtypes = [vp]
     L.kss_profile_get.argtypes = [vp, C.c_int, C.POINTER(dbl), C.POINTER(i64)]
@@ -211,6 +213,9 @@ class Context:
     def _chk(self, rc, where):
         if rc != 0:
             raise KssError(rc, where, self.L.kss_last_error(self.h).decode() or self.L.kss_status_string(rc).decode())
+
+    def set_nn_mode(self, mode):
+        self._chk(self.L.kss_ctx_set_nn_mode(self.h, int(mode)), "kss_ctx_set_nn_mode")
 
     def synchronize(self):
         self._chk(self.L.kss_ctx_synchronize(self.h), "kss_ctx_synchronize")

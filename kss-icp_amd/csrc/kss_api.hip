@@ -33,10 +33,12 @@ struct kss_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
+    int nn_mode = KSS_NN_AUTO;
 
     // grow-only device workspace
     DevBuf tgt4, src0, cur[2], keys, partials, sums, nn_work, red_work, pair_red, state, cs, scratch_a,
-        scratch_b, scratch_c, stage_src, stage_tgt, stage_idx, stage_d2, stage_out;
+        scratch_b, scratch_c, stage_src, stage_tgt, stage_idx, stage_d2, stage_out, g_counts, g_start, g_cursor,
+        g_bsums, g_sorted, g_list, g_count, g_bbox;
     // pinned host staging
     void* h_sums = nullptr;  size_t h_sums_cap = 0;
     void* h_state = nullptr; size_t h_state_cap = 0;
@@ -171,7 +173,8 @@ int kss_ctx_destroy(kss_ctx* c) {
     prof_collect(c);
     DevBuf* bufs[] = {&c->tgt4, &c->src0, &c->cur[0], &c->cur[1], &c->keys, &c->partials, &c->sums, &c->nn_work,
                       &c->red_work, &c->pair_red, &c->state, &c->cs, &c->scratch_a, &c->scratch_b, &c->scratch_c,
-                      &c->stage_src, &c->stage_tgt, &c->stage_idx, &c->stage_d2, &c->stage_out};
+                      &c->stage_src, &c->stage_tgt, &c->stage_idx, &c->stage_d2, &c->stage_out, &c->g_counts, &c->g_start,
+                      &c->g_cursor, &c->g_bsums, &c->g_sorted, &c->g_list, &c->g_count, &c->g_bbox};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (c->h_sums) hipHostFree(c->h_sums);
@@ -188,6 +191,12 @@ int kss_ctx_synchronize(kss_ctx* c) {
 }
 
 void* kss_ctx_stream(kss_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int kss_ctx_set_nn_mode(kss_ctx* c, int nn_mode) {
+    if (!c || nn_mode < KSS_NN_AUTO || nn_mode > KSS_NN_GRID) return KSS_ERR_ARG;
+    c->nn_mode = nn_mode;
+    return KSS_OK;
+}
 
 int kss_profile_enable(kss_ctx* c, int on) {
     if (!c) return KSS_ERR_ARG;
@@ -235,12 +244,17 @@ struct IcpPlan {
     std::vector<PairRed> pred;
     int64_t total_src = 0, total_tgt_pad = 0, total_keys = 0;
     bool shared_target = false;
+    bool grid = false;      // exact cell-list search (single pair) with brute-force list fallback
+    GridParams gp;
 };
 
 int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npairs, bool shared_target,
-               int S_req, int split_req, IcpPlan& pl) {
+               int S_req, int split_req, int nn_mode, IcpPlan& pl) {
     pl.npairs = npairs;
     pl.shared_target = shared_target;
+    if (nn_mode == KSS_NN_AUTO) nn_mode = c->nn_mode;
+    pl.grid = nn_mode == KSS_NN_GRID || (nn_mode == KSS_NN_AUTO && npairs == 1 && nt[0] >= 4096 && ns[0] >= 1024);
+    if (npairs != 1) pl.grid = false;   // the cell list is built per target; batches use the brute-force sweep
     int64_t tot = 0;
     for (int p = 0; p < npairs; ++p) {
         if (ns[p] <= 0 || nt[p] <= 0) return set_err(c, KSS_ERR_ARG, "empty cloud in ICP pair");
@@ -279,7 +293,7 @@ int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npairs, boo
             tb += g.tgt_pad;
         }
         sb += ns[p];
-        kb += (int64_t)g.n_split * ns[p];
+        kb += pl.grid ? ns[p] : (int64_t)g.n_split * ns[p];
         if (sb > 0x7fff0000ll || tb > 0x7fff0000ll || kb > 0x7fff0000ll)
             return set_err(c, KSS_ERR_ARG, "problem too large for 32-bit indexing");
     }
@@ -300,18 +314,27 @@ int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npairs, boo
                 w.tgt_pair_base = g.tgt_base;
                 w.key_begin = g.key_base + (int32_t)((int64_t)s * g.ns) + b * per_block;
                 w.write_src = s == 0;
+                if (pl.grid) {   // LIST semantics (kss_kernels.hip): offsets into the unresolved list, key row 0
+                    w.src_begin = b * per_block;
+                    w.key_begin = g.key_base;
+                    w.write_src = g.src_base;
+                }
                 pl.nn.push_back(w);
             }
         pl.pred[p].first = prow;
-        const int nrb = (int)((g.ns + 255) / 256);
+        // reduce workgroups own 256*R consecutive sources: ~100 partial rows per pair at most
+        int64_t R = (g.ns + 256 * 96 - 1) / (256 * 96);
+        R = std::max<int64_t>(1, std::min<int64_t>(R, 64));
+        const int64_t rchunk = 256 * R;
+        const int nrb = (int)((g.ns + rchunk - 1) / rchunk);
         for (int b = 0; b < nrb; ++b) {
             RedWork r;
             r.pair = p;
-            r.src_begin = g.src_base + b * 256;
-            r.src_count = (int32_t)std::min<int64_t>(256, g.ns - (int64_t)b * 256);
-            r.key_begin = g.key_base + b * 256;
+            r.src_begin = g.src_base + (int32_t)(b * rchunk);
+            r.src_count = (int32_t)std::min<int64_t>(rchunk, g.ns - (int64_t)b * rchunk);
+            r.key_begin = g.key_base + (int32_t)(b * rchunk);
             r.key_stride = (int32_t)g.ns;
-            r.n_split = g.n_split;
+            r.n_split = pl.grid ? 1 : g.n_split;
             r.tgt_pair_base = g.tgt_base;
             r.partial_index = prow++;
             pl.red.push_back(r);
@@ -366,12 +389,74 @@ int pack_clouds(kss_ctx* c, const IcpPlan& pl, const void* d_src, const int64_t*
     return KSS_OK;
 }
 
+// Build the uniform cell list over the (single) target: bbox -> cell size -> counting sort.
+int grid_setup(kss_ctx* c, IcpPlan& pl) {
+    if (!pl.grid) return KSS_OK;
+    const PairGeom& g = pl.g[0];
+    const int nt = (int)g.nt, ns = (int)g.ns;
+    const int nbb = 64;
+    KCHK(ensure(c, c->g_bbox, (size_t)nbb * 6 * sizeof(float)));
+    const float4* tgt = (const float4*)c->tgt4.p + g.tgt_base;
+    ProfScope ps(c, KSS_K_GRID_BUILD);
+    launch_grid_bbox(c->stream, tgt, nt, (float*)c->g_bbox.p, nbb);
+    std::vector<float> hb((size_t)nbb * 6);
+    HIPCHK(c, hipMemcpyAsync(hb.data(), c->g_bbox.p, hb.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int b = 0; b < nbb; ++b)
+        for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], hb[(size_t)b * 6 + k]); mx[k] = std::max(mx[k], hb[(size_t)b * 6 + 3 + k]); }
+    if (!(std::isfinite(mn[0]) && std::isfinite(mn[1]) && std::isfinite(mn[2]) && std::isfinite(mx[0]) && std::isfinite(mx[1]) && std::isfinite(mx[2])))
+        return set_err(c, KSS_ERR_ARG, "non-finite target coordinates");
+    const float ext[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+    const float emax = std::max(ext[0], std::max(ext[1], ext[2]));
+    GridParams gp;
+    // cell edge: ~3 points per occupied cell if the target is a surface (area ~ emax^2 * few)
+    float h = emax * 1.5f * std::sqrt(3.0f / (float)nt);
+    h = std::max(h, emax / 255.5f);
+    if (!(h > 0.f)) h = 1.f;   // all targets coincide
+    gp.ox = mn[0]; gp.oy = mn[1]; gp.oz = mn[2];
+    gp.h = h; gp.inv_h = 1.0f / h;
+    gp.gx = std::max(1, std::min(256, (int)std::floor(ext[0] / h) + 1));
+    gp.gy = std::max(1, std::min(256, (int)std::floor(ext[1] / h) + 1));
+    gp.gz = std::max(1, std::min(256, (int)std::floor(ext[2] / h) + 1));
+    const float mag = std::max(std::max(std::fabs(mn[0]), std::fabs(mx[0])), std::max(std::max(std::fabs(mn[1]), std::fabs(mx[1])), std::max(std::fabs(mn[2]), std::fabs(mx[2]))));
+    gp.eps = 2e-6f * (mag + emax) + 1e-30f;
+    gp.rcap = 12;
+    pl.gp = gp;
+    const size_t ncells = (size_t)gp.gx * gp.gy * gp.gz;
+    KCHK(ensure(c, c->g_counts, ncells * sizeof(int32_t)));
+    KCHK(ensure(c, c->g_start, (ncells + 1) * sizeof(int32_t)));
+    KCHK(ensure(c, c->g_cursor, ncells * sizeof(int32_t)));
+    KCHK(ensure(c, c->g_bsums, ((ncells + 4095) / 4096 + 1) * sizeof(int32_t)));
+    KCHK(ensure(c, c->g_sorted, (size_t)nt * sizeof(float4)));
+    KCHK(ensure(c, c->g_list, (size_t)ns * sizeof(int32_t)));
+    KCHK(ensure(c, c->g_count, 64));
+    launch_grid_build(c->stream, tgt, nt, gp, (int32_t*)c->g_counts.p, (int32_t*)c->g_start.p, (int32_t*)c->g_cursor.p,
+                      (int32_t*)c->g_bsums.p, (float4*)c->g_sorted.p);
+    HIPCHK(c, hipGetLastError());
+    return KSS_OK;
+}
+
 // One NN sweep + correspondence reduce over every active pair.  h_sums receives npairs*NSUMS.
 int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, float4* d_out, double max_d2,
             int32_t* d_idx_out, float* d_d2_out) {
     PairState* hs = (PairState*)c->h_state;
     HIPCHK(c, hipMemcpyAsync(c->state.p, hs, (size_t)pl.npairs * sizeof(PairState), hipMemcpyHostToDevice, c->stream));
-    {
+    if (pl.grid) {
+        HIPCHK(c, hipMemsetAsync(c->g_count.p, 0, sizeof(int32_t), c->stream));
+        {
+            ProfScope ps(c, KSS_K_GRID_NN);
+            launch_grid_nn(c->stream, fma, (const PairState*)c->state.p, d_in, d_out, (int)pl.g[0].ns, pl.gp,
+                           (const int32_t*)c->g_start.p, (const float4*)c->g_sorted.p, (unsigned long long*)c->keys.p,
+                           (int32_t*)c->g_list.p, (int32_t*)c->g_count.p);
+        }
+        {   // queries the cell search gave up on (far from the target): brute-force sweep over the list
+            ProfScope ps(c, KSS_K_NN_SWEEP);
+            launch_nn_sweep_list(c->stream, pl.S, fma, (const NNWork*)c->nn_work.p, (int)pl.nn.size(), (const PairState*)c->state.p,
+                                 d_out, (const float4*)c->tgt4.p, (unsigned long long*)c->keys.p, (const int32_t*)c->g_list.p,
+                                 (const int32_t*)c->g_count.p);
+        }
+    } else {
         ProfScope ps(c, KSS_K_NN_SWEEP);
         launch_nn_sweep(c->stream, pl.S, fma, (const NNWork*)c->nn_work.p, (int)pl.nn.size(), (const PairState*)c->state.p,
                         d_in, d_out, (const float4*)c->tgt4.p, (unsigned long long*)c->keys.p);
@@ -481,9 +566,10 @@ int icp_run_dev(kss_ctx* c, const void* d_src, const int64_t* src_off, const voi
         nt[i] = shared_target ? tgt_off[1] - tgt_off[0] : tgt_off[i + 1] - tgt_off[i];
     }
     IcpPlan pl;
-    KCHK(build_plan(c, ns.data(), nt.data(), npairs, shared_target, p->nn_sources_per_thread, p->nn_target_splits, pl));
+    KCHK(build_plan(c, ns.data(), nt.data(), npairs, shared_target, p->nn_sources_per_thread, p->nn_target_splits, p->nn_mode, pl));
     KCHK(stage_plan(c, pl));
     KCHK(pack_clouds(c, pl, d_src, src_off, d_tgt, tgt_off, dtype));
+    KCHK(grid_setup(c, pl));
     return icp_loop(c, pl, *p, results);
 }
 
@@ -558,10 +644,11 @@ static int nn_generic_dev(kss_ctx* c, const void* d_src, int64_t ns, const void*
     if (ns <= 0 || nt <= 0) return set_err(c, KSS_ERR_ARG, "nn: empty cloud");
     HIPCHK(c, hipSetDevice(c->device));
     IcpPlan pl;
-    KCHK(build_plan(c, &ns, &nt, 1, false, 0, 0, pl));
+    KCHK(build_plan(c, &ns, &nt, 1, false, 0, 0, KSS_NN_AUTO, pl));
     KCHK(stage_plan(c, pl));
     const int64_t so[2] = {0, ns}, to[2] = {0, nt};
     KCHK(pack_clouds(c, pl, d_src, so, d_tgt, to, dtype));
+    KCHK(grid_setup(c, pl));
     float I[16];
     mat4_identity(I);
     set_state(((PairState*)c->h_state)[0], I, 1, 0);

@@ -1,0 +1,263 @@
+// kss_grid.hip -- exact nearest neighbour through a uniform cell list (the HBM/L2-bound variant of (a8)).
+//
+// "a uniform-grid-binned NN (cell list in HBM) is the variant that becomes
+// genuinely HBM-bound; keep the brute-force kernel as the exact reference and measure both".
+// The result is BIT-IDENTICAL to nn_sweep_kernel (same f32 no-fma distance, ties -> lowest index):
+//   build   : bbox -> per-cell counts (atomics) -> exclusive scan -> scatter into cell order.  The order
+//             inside a cell is whatever the atomics give; the query's explicit (d2, idx) tie rule makes
+//             the answer independent of it.
+//   query   : one lane per source point.  Shells r = 0, 1, 2, ... of cells around the query's cell are
+//             visited row by row (cells adjacent in x are contiguous in the sorted array, so a row of
+//             2r+1 cells is ONE range).  After shell r every unvisited point is farther than the
+//             distance b(r) from the query to the faces of the visited block; the search stops when
+//             best_d2 < (b(r) - eps)^2 * (1 - 1e-6), a bound that is conservative w.r.t. the f32 rounding
+//             of both the cell assignment and the distance, so it can only search MORE than needed.
+//   fallback: a query not resolved within GRID_RCAP shells is appended to a list and resolved by the
+//             brute-force sweep (nn_sweep_kernel<LIST>) -- far-away clouds never degrade below it.
+#pragma clang fp contract(off)
+
+#include <hip/hip_runtime.h>
+
+#include "kss_internal.hpp"
+
+namespace kss {
+
+// ---- bbox of the real (non-sentinel) targets ---------------------------------------------------------
+__global__ __launch_bounds__(256) void grid_bbox_kernel(const float4* __restrict__ tgt, int n, float* __restrict__ partial) {
+    __shared__ float sh[4][6];
+    float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 p = tgt[i];
+        mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+        mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = fminf(mn[k], __shfl_down(mn[k], off, 64));
+            mx[k] = fmaxf(mx[k], __shfl_down(mx[k], off, 64));
+        }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+        for (int k = 0; k < 3; ++k) { sh[wave][k] = mn[k]; sh[wave][3 + k] = mx[k]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = sh[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fminf(v, sh[w][threadIdx.x]) : fmaxf(v, sh[w][threadIdx.x]);
+        partial[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+void launch_grid_bbox(hipStream_t st, const float4* d_tgt, int n, float* d_partial, int n_blocks) {
+    hipLaunchKernelGGL(grid_bbox_kernel, dim3(n_blocks), dim3(256), 0, st, d_tgt, n, d_partial);
+}
+
+__device__ __forceinline__ int cell_coord(float v, float o, float inv_h, int g) {
+    int c = (int)floorf((v - o) * inv_h);
+    c = c < 0 ? 0 : c;
+    return c >= g ? g - 1 : c;
+}
+
+// ---- counting sort into cell order ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grid_count_kernel(const float4* __restrict__ tgt, int n, GridParams gp,
+                                                         int32_t* __restrict__ counts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = tgt[i];
+    const int cx = cell_coord(p.x, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(p.y, gp.oy, gp.inv_h, gp.gy),
+              cz = cell_coord(p.z, gp.oz, gp.inv_h, gp.gz);
+    atomicAdd(&counts[(cz * gp.gy + cy) * gp.gx + cx], 1);
+}
+
+// exclusive scan, 3 phases; each workgroup owns SCAN_CHUNK consecutive elements
+constexpr int SCAN_CHUNK = 4096;   // 256 threads x 16
+
+__global__ __launch_bounds__(256) void scan_block_sums_kernel(const int32_t* __restrict__ in, int n, int32_t* __restrict__ block_sums) {
+    __shared__ int sh[4];
+    const int base = blockIdx.x * SCAN_CHUNK;
+    int s = 0;
+    for (int k = threadIdx.x; k < SCAN_CHUNK; k += 256) {
+        const int i = base + k;
+        if (i < n) s += in[i];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// single workgroup: exclusive scan of up to 1024*16 block sums, in place
+__global__ __launch_bounds__(1024) void scan_of_block_sums_kernel(int32_t* __restrict__ block_sums, int nb) {
+    __shared__ int sh[1024];
+    const int per = (nb + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(nb, lo + per);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += block_sums[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan over the 1024 partials
+        int v = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = threadIdx.x > 0 ? sh[threadIdx.x - 1] : 0;
+    for (int i = lo; i < hi; ++i) {
+        const int v = block_sums[i];
+        block_sums[i] = run;
+        run += v;
+    }
+}
+
+__global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restrict__ in, int n, const int32_t* __restrict__ block_sums,
+                                                         int32_t* __restrict__ out_start, int32_t* __restrict__ cursor) {
+    // each lane scans 16 consecutive elements, wave/LDS scan of the lane totals, plus the workgroup offset
+    __shared__ int sh[256];
+    const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * 16;
+    int v[16];
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int i = base + k;
+        v[k] = i < n ? in[i] : 0;
+        s += v[k];
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        int t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int run = block_sums[blockIdx.x] + (threadIdx.x > 0 ? sh[threadIdx.x - 1] : 0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int i = base + k;
+        if (i < n) { out_start[i] = run; cursor[i] = run; }
+        run += v[k];
+    }
+}
+
+__global__ void scan_tail_kernel(const int32_t* __restrict__ counts, int32_t* __restrict__ start, int n) {
+    // start[n] = total = start[n-1] + counts[n-1]
+    if (threadIdx.x == 0 && blockIdx.x == 0) start[n] = start[n - 1] + counts[n - 1];
+}
+
+__global__ __launch_bounds__(256) void grid_scatter_kernel(const float4* __restrict__ tgt, int n, GridParams gp,
+                                                           int32_t* __restrict__ cursor, float4* __restrict__ sorted) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 p = tgt[i];
+    const int cx = cell_coord(p.x, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(p.y, gp.oy, gp.inv_h, gp.gy),
+              cz = cell_coord(p.z, gp.oz, gp.inv_h, gp.gz);
+    const int pos = atomicAdd(&cursor[(cz * gp.gy + cy) * gp.gx + cx], 1);
+    p.w = __int_as_float(i);   // original index rides in .w
+    sorted[pos] = p;
+}
+
+void launch_grid_build(hipStream_t st, const float4* d_tgt, int n, const GridParams& gp, int32_t* d_counts,
+                       int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums, float4* d_sorted) {
+    const int ncells = gp.gx * gp.gy * gp.gz;
+    hipMemsetAsync(d_counts, 0, (size_t)ncells * sizeof(int32_t), st);
+    hipLaunchKernelGGL(grid_count_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_tgt, n, gp, d_counts);
+    const int nb = (ncells + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(256), 0, st, d_counts, ncells, d_block_sums);
+    hipLaunchKernelGGL(scan_of_block_sums_kernel, dim3(1), dim3(1024), 0, st, d_block_sums, nb);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, st, d_counts, ncells, d_block_sums, d_start, d_cursor);
+    hipLaunchKernelGGL(scan_tail_kernel, dim3(1), dim3(64), 0, st, d_counts, d_start, ncells);
+    hipLaunchKernelGGL(grid_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_tgt, n, gp, d_cursor, d_sorted);
+}
+
+// ---- query -----------------------------------------------------------------------------------------------
+template <bool FMA>
+__device__ __forceinline__ void scan_range(const float4* __restrict__ sorted, int lo, int hi, float qx, float qy, float qz,
+                                           float& best, int& bidx) {
+    for (int k = lo; k < hi; ++k) {
+        const float4 p = sorted[k];
+        const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+        float d;
+        if constexpr (FMA) d = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+        else d = (dx * dx + dy * dy) + dz * dz;
+        const int id = __float_as_int(p.w);
+        if (d < best || (d == best && id < bidx)) { best = d; bidx = id; }
+    }
+}
+
+template <bool FMA>
+__global__ __launch_bounds__(256) void grid_nn_kernel(const PairState* __restrict__ state, const float4* __restrict__ src_in,
+                                                      float4* __restrict__ src_out, int ns, GridParams gp,
+                                                      const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
+                                                      unsigned long long* __restrict__ keys, int32_t* __restrict__ list,
+                                                      int32_t* __restrict__ list_count) {
+    const PairState ps = state[0];
+    if (!ps.active) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    float4 p = src_in[i];
+    if (ps.apply) {   // pcl transformCloud with the previous iteration's Matrix4f, as nn_sweep_kernel does
+        const float x = p.x, y = p.y, z = p.z;
+        p.x = ((ps.m[0] * x + ps.m[1] * y) + ps.m[2] * z) + ps.m[3];
+        p.y = ((ps.m[4] * x + ps.m[5] * y) + ps.m[6] * z) + ps.m[7];
+        p.z = ((ps.m[8] * x + ps.m[9] * y) + ps.m[10] * z) + ps.m[11];
+    }
+    src_out[i] = p;
+    const float qx = p.x, qy = p.y, qz = p.z;
+    const int cx = cell_coord(qx, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(qy, gp.oy, gp.inv_h, gp.gy),
+              cz = cell_coord(qz, gp.oz, gp.inv_h, gp.gz);
+    float best = __builtin_inff();
+    int bidx = 0x7fffffff;
+    bool done = false;
+    for (int r = 0; r <= gp.rcap && !done; ++r) {
+        const int z0 = max(cz - r, 0), z1 = min(cz + r, gp.gz - 1);
+        const int y0 = max(cy - r, 0), y1 = min(cy + r, gp.gy - 1);
+        const int x0 = max(cx - r, 0), x1 = min(cx + r, gp.gx - 1);
+        for (int z = z0; z <= z1; ++z) {
+            const bool zface = (z == cz - r) || (z == cz + r);
+            for (int y = y0; y <= y1; ++y) {
+                const int row = (z * gp.gy + y) * gp.gx;
+                if (zface || y == cy - r || y == cy + r) {
+                    // a row on the shell's y/z faces: the whole x extent is new -> one contiguous range
+                    scan_range<FMA>(sorted, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, best, bidx);
+                } else {
+                    // interior row: only the two x end cells belong to shell r
+                    if (cx - r >= 0) scan_range<FMA>(sorted, cell_start[row + cx - r], cell_start[row + cx - r + 1], qx, qy, qz, best, bidx);
+                    if (cx + r < gp.gx) scan_range<FMA>(sorted, cell_start[row + cx + r], cell_start[row + cx + r + 1], qx, qy, qz, best, bidx);
+                }
+            }
+        }
+        // distance from the query to the faces of the visited block; faces on the grid border are open
+        float b = __builtin_inff();
+        if (cx - r > 0) b = fminf(b, qx - (gp.ox + (float)(cx - r) * gp.h));
+        if (cx + r < gp.gx - 1) b = fminf(b, (gp.ox + (float)(cx + r + 1) * gp.h) - qx);
+        if (cy - r > 0) b = fminf(b, qy - (gp.oy + (float)(cy - r) * gp.h));
+        if (cy + r < gp.gy - 1) b = fminf(b, (gp.oy + (float)(cy + r + 1) * gp.h) - qy);
+        if (cz - r > 0) b = fminf(b, qz - (gp.oz + (float)(cz - r) * gp.h));
+        if (cz + r < gp.gz - 1) b = fminf(b, (gp.oz + (float)(cz + r + 1) * gp.h) - qz);
+        const float bs = b - gp.eps;
+        if (b == __builtin_inff()) done = true;                       // the whole grid has been visited
+        else if (bs > 0.f && best < bs * bs * 0.999999f) done = true; // every unvisited point is strictly farther
+    }
+    if (done) {
+        keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(unsigned)bidx;
+    } else {
+        keys[i] = ~0ull;   // resolved by the brute-force list pass through atomicMin
+        const int slot = atomicAdd(list_count, 1);
+        list[slot] = i;
+    }
+}
+
+void launch_grid_nn(hipStream_t st, bool fma, const PairState* d_state, const float4* d_src_in, float4* d_src_out, int ns,
+                    const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted, unsigned long long* d_keys,
+                    int32_t* d_list, int32_t* d_list_count) {
+    const dim3 grid((ns + 255) / 256), block(256);
+    if (fma)
+        hipLaunchKernelGGL(grid_nn_kernel<true>, grid, block, 0, st, d_state, d_src_in, d_src_out, ns, gp, d_cell_start, d_sorted, d_keys, d_list, d_list_count);
+    else
+        hipLaunchKernelGGL(grid_nn_kernel<false>, grid, block, 0, st, d_state, d_src_in, d_src_out, ns, gp, d_cell_start, d_sorted, d_keys, d_list, d_list_count);
+}
+
+}  // namespace kss

@@ -51,6 +51,15 @@ struct PairRed {            // final reduce: rows [first, first+count) of partia
     int32_t count;
 };
 
+// Uniform cell list over the target's bounding box (kss_grid.hip)
+struct GridParams {
+    float ox, oy, oz;   // bbox minimum
+    float h, inv_h;     // cell edge
+    float eps;          // absolute slack covering f32 rounding of the cell assignment
+    int32_t gx, gy, gz; // cells per axis (x fastest in the linear cell index)
+    int32_t rcap;       // shells searched before a query falls back to the brute-force list pass
+};
+
 constexpr int NN_TILE = 256;      // targets staged per LDS tile (one float4 per thread)
 constexpr int NN_SUB = 32;        // targets per sub-tile (arg-min bookkeeping granularity)
 constexpr int NN_THREADS = 256;
@@ -62,6 +71,16 @@ void launch_pack_f64_to_f4(hipStream_t st, const double* d_in, int64_t n, float4
 void launch_nn_sweep(hipStream_t st, int S, bool fma, const NNWork* d_work, int n_work,
                      const PairState* d_state, const float4* d_src_in, float4* d_src_out,
                      const float4* d_tgt4, unsigned long long* d_keys);
+
+void launch_nn_sweep_list(hipStream_t st, int S, bool fma, const NNWork* d_work, int n_work,
+                          const PairState* d_state, float4* d_src_cur, const float4* d_tgt4,
+                          unsigned long long* d_keys, const int32_t* d_list, const int32_t* d_count);
+void launch_grid_bbox(hipStream_t st, const float4* d_tgt, int n, float* d_partial, int n_blocks);
+void launch_grid_build(hipStream_t st, const float4* d_tgt, int n, const GridParams& gp, int32_t* d_counts,
+                       int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums, float4* d_sorted);
+void launch_grid_nn(hipStream_t st, bool fma, const PairState* d_state, const float4* d_src_in, float4* d_src_out, int ns,
+                    const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted, unsigned long long* d_keys,
+                    int32_t* d_list, int32_t* d_list_count);
 
 void launch_corr_reduce(hipStream_t st, const RedWork* d_work, int n_work, const PairState* d_state,
                         const float4* d_src, const float4* d_tgt4, const unsigned long long* d_keys,

@@ -97,34 +97,53 @@ void launch_pack_f64_to_f4(hipStream_t st, const double* d_in, int64_t n, float4
 //     end to recover the exact lowest index.  ~8.6 VALU ops per (source, target) pair;
 //   - result key = (bits(d2) << 32) | idx: unsigned-min over splits == (min d2, lowest idx).
 // ---------------------------------------------------------------------------------------------
-template <int S, bool FMA>
+// LIST = true is the fallback pass of the grid search (kss_grid.hip): the sources are the entries of a
+// device-side list (count in device memory, so the host launches the worst-case grid and surplus
+// workgroups leave at once), they are already transformed, and results are merged into key row 0 with a
+// 64-bit atomic min.  In that mode NNWork.src_begin is the offset into the list, NNWork.key_begin the
+// pair's key base and NNWork.write_src the pair's first source index.
+template <int S, bool FMA, bool LIST>
 __global__ __launch_bounds__(NN_THREADS) void nn_sweep_kernel(const NNWork* __restrict__ work,
                                                               const PairState* __restrict__ state,
                                                               const float4* __restrict__ src_in,
                                                               float4* __restrict__ src_out,
                                                               const float4* __restrict__ tgt,
-                                                              unsigned long long* __restrict__ keys) {
+                                                              unsigned long long* __restrict__ keys,
+                                                              const int32_t* __restrict__ list,
+                                                              const int32_t* __restrict__ list_count) {
     __shared__ float4 tile[2][NN_TILE];
     const NNWork w = work[blockIdx.x];
     const PairState ps = state[w.pair];
     if (!ps.active) return;   // uniform: whole workgroup leaves
     const int tid = threadIdx.x;
+    int src_count = w.src_count;
+    if constexpr (LIST) {
+        src_count = *list_count - w.src_begin;
+        if (src_count > NN_THREADS * S) src_count = NN_THREADS * S;
+        if (src_count <= 0) return;   // uniform
+    }
 
     float sx[S], sy[S], sz[S], best[S];
-    int bsub[S];
+    int bsub[S], gidx[S];
 #pragma unroll
     for (int j = 0; j < S; ++j) {
         const int l = tid + j * NN_THREADS;
-        const bool valid = l < w.src_count;
+        const bool valid = l < src_count;
         float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid) p = src_in[w.src_begin + l];
-        if (ps.apply) {
-            const float x = p.x, y = p.y, z = p.z;
-            p.x = ((ps.m[0] * x + ps.m[1] * y) + ps.m[2] * z) + ps.m[3];
-            p.y = ((ps.m[4] * x + ps.m[5] * y) + ps.m[6] * z) + ps.m[7];
-            p.z = ((ps.m[8] * x + ps.m[9] * y) + ps.m[10] * z) + ps.m[11];
+        if constexpr (LIST) {
+            gidx[j] = valid ? list[w.src_begin + l] : 0;
+            if (valid) p = src_out[gidx[j]];
+        } else {
+            gidx[j] = w.src_begin + l;
+            if (valid) p = src_in[gidx[j]];
+            if (ps.apply) {
+                const float x = p.x, y = p.y, z = p.z;
+                p.x = ((ps.m[0] * x + ps.m[1] * y) + ps.m[2] * z) + ps.m[3];
+                p.y = ((ps.m[4] * x + ps.m[5] * y) + ps.m[6] * z) + ps.m[7];
+                p.z = ((ps.m[8] * x + ps.m[9] * y) + ps.m[10] * z) + ps.m[11];
+            }
+            if (valid && w.write_src) src_out[gidx[j]] = p;
         }
-        if (valid && w.write_src) src_out[w.src_begin + l] = p;
         sx[j] = p.x; sy[j] = p.y; sz[j] = p.z;
         best[j] = __builtin_inff();
         bsub[j] = 0;
@@ -174,21 +193,24 @@ __global__ __launch_bounds__(NN_THREADS) void nn_sweep_kernel(const NNWork* __re
             if (d < bd) { bd = d; bi = u; }
         }
         const int l = tid + j * NN_THREADS;
-        if (l < w.src_count) {
+        if (l < src_count) {
             const unsigned idx = (unsigned)(w.tgt_begin - w.tgt_pair_base + bsub[j] * NN_SUB + bi);
-            keys[w.key_begin + l] = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned long long)idx;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned long long)idx;
+            if constexpr (LIST) atomicMin(&keys[w.key_begin + (gidx[j] - w.write_src)], key);
+            else keys[w.key_begin + l] = key;
         }
     }
 }
 
-void launch_nn_sweep(hipStream_t st, int S, bool fma, const NNWork* d_work, int n_work,
-                     const PairState* d_state, const float4* d_src_in, float4* d_src_out,
-                     const float4* d_tgt4, unsigned long long* d_keys) {
+template <bool LIST>
+static void nn_sweep_dispatch(hipStream_t st, int S, bool fma, const NNWork* d_work, int n_work, const PairState* d_state,
+                              const float4* d_src_in, float4* d_src_out, const float4* d_tgt4, unsigned long long* d_keys,
+                              const int32_t* d_list, const int32_t* d_count) {
     if (n_work <= 0) return;
     const dim3 grid(n_work), block(NN_THREADS);
-#define KSS_NN_LAUNCH(SV, FV)                                                                               \
-    hipLaunchKernelGGL((nn_sweep_kernel<SV, FV>), grid, block, 0, st, d_work, d_state, d_src_in, d_src_out, \
-                       d_tgt4, d_keys)
+#define KSS_NN_LAUNCH(SV, FV)                                                                                        \
+    hipLaunchKernelGGL((nn_sweep_kernel<SV, FV, LIST>), grid, block, 0, st, d_work, d_state, d_src_in, d_src_out, \
+                       d_tgt4, d_keys, d_list, d_count)
     if (!fma) {
         switch (S) {
             case 1: KSS_NN_LAUNCH(1, false); break;
@@ -205,6 +227,18 @@ void launch_nn_sweep(hipStream_t st, int S, bool fma, const NNWork* d_work, int 
         }
     }
 #undef KSS_NN_LAUNCH
+}
+
+void launch_nn_sweep(hipStream_t st, int S, bool fma, const NNWork* d_work, int n_work,
+                     const PairState* d_state, const float4* d_src_in, float4* d_src_out,
+                     const float4* d_tgt4, unsigned long long* d_keys) {
+    nn_sweep_dispatch<false>(st, S, fma, d_work, n_work, d_state, d_src_in, d_src_out, d_tgt4, d_keys, nullptr, nullptr);
+}
+
+void launch_nn_sweep_list(hipStream_t st, int S, bool fma, const NNWork* d_work, int n_work,
+                          const PairState* d_state, float4* d_src_cur, const float4* d_tgt4,
+                          unsigned long long* d_keys, const int32_t* d_list, const int32_t* d_count) {
+    nn_sweep_dispatch<true>(st, S, fma, d_work, n_work, d_state, d_src_cur, d_src_cur, d_tgt4, d_keys, d_list, d_count);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -244,8 +278,9 @@ __global__ __launch_bounds__(256) void corr_reduce_kernel(const RedWork* __restr
 #pragma unroll
     for (int c = 0; c < NSUMS; ++c) acc[c] = 0.0;
     const bool active = state[w.pair].active != 0;
-    const int t = threadIdx.x;
-    if (active && t < w.src_count) {
+    const int t0 = threadIdx.x;
+    if (active)
+    for (int t = t0; t < w.src_count; t += 256) {
         unsigned long long key = ~0ull;
         for (int s = 0; s < w.n_split; ++s) {
             const unsigned long long k = keys[w.key_begin + (int64_t)s * w.key_stride + t];
@@ -260,7 +295,7 @@ __global__ __launch_bounds__(256) void corr_reduce_kernel(const RedWork* __restr
         if (d2_out) d2_out[w.src_begin + t] = d2;
     }
     const double r = block_sum<NSUMS>(acc, sh);
-    if (t < NSUMS) partials[(int64_t)w.partial_index * NSUMS + t] = r;
+    if (t0 < NSUMS) partials[(int64_t)w.partial_index * NSUMS + t0] = r;
 }
 
 void launch_corr_reduce(hipStream_t st, const RedWork* d_work, int n_work, const PairState* d_state,

@@ -1,0 +1,77 @@
+"""GPU tests of the exact cell-list NN (KSS_NN_GRID): bit-identical to the brute-force sweep and to the
+oracle on every input class, including the ones that force the brute-force list fallback."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def gctx(ctx, pkg):
+    ctx.set_nn_mode(pkg.NN_GRID)
+    yield ctx
+    ctx.set_nn_mode(pkg.NN_AUTO)
+
+
+def _check(gctx, O, s, t):
+    idx, d2 = gctx.nn(s, t)
+    if len(t) * len(s) <= 4e8:
+        oi, od = O.nn_brute(s, t)
+    else:
+        oi, od = O.KdTree(t).nn(s, nthreads=8)
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(d2.view(np.uint32), od.view(np.uint32))
+
+
+@pytest.mark.parametrize("ns,nt", [(1, 1), (3, 2), (1000, 5), (257, 4097), (5000, 20000), (20000, 5000)])
+def test_grid_nn_random_clouds(gctx, O, ns, nt):
+    rng = np.random.default_rng(ns + 3 * nt)
+    _check(gctx, O, rng.normal(size=(ns, 3)).astype(np.float32), rng.normal(size=(nt, 3)).astype(np.float32))
+
+
+def test_grid_nn_surface_and_far_queries(gctx, O, pkg):
+    S = pkg.synth
+    tgt = S.bumpy(1, 30000).astype(np.float32)
+    near = (S.bumpy(2, 8000) + S.normal(3, 24000).reshape(-1, 3) * 1e-3).astype(np.float32)
+    _check(gctx, O, near, tgt)
+    # rotated by 25 degrees: many queries need several shells, some fall back to the brute-force list
+    R = S.rot_axis_angle([1, 1, 0], np.deg2rad(25.0))
+    _check(gctx, O, (S.bumpy(2, 8000) @ R.T).astype(np.float32), tgt)
+    # far outside the bbox (every query unresolved by the cell search) and straddling it
+    _check(gctx, O, (S.bumpy(2, 3000) + np.array([7.0, -3.0, 2.0])).astype(np.float32), tgt)
+    _check(gctx, O, (S.bumpy(2, 3000) * 3.0).astype(np.float32), tgt)
+    # large coordinates: rounding slack scales with the magnitude
+    off = np.array([1000.0, -2000.0, 500.0])
+    _check(gctx, O, (S.bumpy(2, 3000) * 1.01 + off).astype(np.float32), (S.bumpy(1, 30000) + off).astype(np.float32))
+
+
+def test_grid_nn_degenerate_targets(gctx, O):
+    rng = np.random.default_rng(4)
+    q = rng.normal(size=(2000, 3)).astype(np.float32)
+    plane = rng.normal(size=(6000, 3)).astype(np.float32); plane[:, 2] = 0.25          # zero extent in z
+    _check(gctx, O, q, plane)
+    line = np.zeros((5000, 3), np.float32); line[:, 0] = np.linspace(-1, 1, 5000)      # zero extent in y and z
+    _check(gctx, O, q, line)
+    same = np.ones((4100, 3), np.float32) * 0.5                                         # all targets coincide
+    _check(gctx, O, q, same)
+    lattice = np.stack(np.meshgrid(*[np.arange(17, dtype=np.float32)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    _check(gctx, O, lattice[::2] + np.float32(0.5), lattice)                            # exact ties everywhere
+    dup = rng.normal(size=(5000, 3)).astype(np.float32); dup[2500:] = dup[:2500]        # every point twice
+    _check(gctx, O, dup[::3], dup)
+
+
+def test_grid_nn_full_size(gctx, O, pkg):
+    src, tgt = pkg.synth.config_c2(100000)
+    _check(gctx, O, src, tgt)
+
+
+def test_grid_icp_bitwise_equals_brute(ctx, pkg):
+    S = pkg.synth
+    src, tgt = S.make_pair(31, 20000, R=S.rot_axis_angle([0.3, 0.2, 1.0], np.deg2rad(12.0)), t=(0.02, 0.0, -0.01), shape="bumpy")
+    a = ctx.icp(src, tgt, ctx.icp_params(max_iterations=12, fixed_iterations=1, nn_mode=pkg.NN_BRUTE), trace_cap=16)
+    b = ctx.icp(src, tgt, ctx.icp_params(max_iterations=12, fixed_iterations=1, nn_mode=pkg.NN_GRID), trace_cap=16)
+    assert np.array_equal(a["trace_sums"], b["trace_sums"])       # same NN bits, same fixed-order reduction
+    assert np.array_equal(a["T"], b["T"]) and a["fitness"] == b["fitness"]
+    c = ctx.icp(src, tgt, ctx.icp_params(nn_mode=pkg.NN_GRID))
+    d = ctx.icp(src, tgt, ctx.icp_params(nn_mode=pkg.NN_BRUTE))
+    assert c["iterations"] == d["iterations"] and np.array_equal(c["T"], d["T"])
