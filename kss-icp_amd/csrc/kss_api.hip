@@ -40,7 +40,8 @@ struct kss_ctx {
         scratch_b, scratch_c, stage_src, stage_tgt, stage_idx, stage_d2, stage_out, g_counts, g_start, g_cursor,
         g_bsums, g_sorted, g_list, g_count, g_bbox;
     // pinned host staging
-    void* h_sums = nullptr;  size_t h_sums_cap = 0;
+    void* h_sums = nullptr;  size_t h_sums_cap = 0;   // host-mapped: kernels write it through h_sums_dev
+    void* h_sums_dev = nullptr;
     void* h_state = nullptr; size_t h_state_cap = 0;
 
     // profiling
@@ -83,9 +84,14 @@ static int ensure_pinned(kss_ctx* c, void*& p, size_t& cap, size_t bytes) {
     if (bytes <= cap) return KSS_OK;
     if (p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipHostFree(p)); p = nullptr; cap = 0; }
     size_t want = bytes * 2 + 256;
-    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocMapped);
     if (e != hipSuccess) { p = nullptr; return set_err(c, KSS_ERR_NOMEM, "hipHostMalloc", e); }
     cap = want;
+    if (&p == &c->h_sums) {
+        void* d = nullptr;
+        HIPCHK(c, hipHostGetDevicePointer(&d, p, 0));
+        c->h_sums_dev = d;
+    }
     return KSS_OK;
 }
 
@@ -431,6 +437,14 @@ int grid_setup(kss_ctx* c, IcpPlan& pl) {
     KCHK(ensure(c, c->g_sorted, (size_t)nt * sizeof(float4)));
     KCHK(ensure(c, c->g_list, (size_t)ns * sizeof(int32_t)));
     KCHK(ensure(c, c->g_count, 64));
+    HIPCHK(c, hipMemsetAsync(c->g_count.p, 0, 64, c->stream));
+    {
+        PairState one;
+        std::memset(&one, 0, sizeof one);
+        one.active = 1;
+        HIPCHK(c, hipMemcpyAsync(c->state.p, &one, sizeof one, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     launch_grid_build(c->stream, tgt, nt, gp, (int32_t*)c->g_counts.p, (int32_t*)c->g_start.p, (int32_t*)c->g_cursor.p,
                       (int32_t*)c->g_bsums.p, (float4*)c->g_sorted.p);
     HIPCHK(c, hipGetLastError());
@@ -441,35 +455,51 @@ int grid_setup(kss_ctx* c, IcpPlan& pl) {
 int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, float4* d_out, double max_d2,
             int32_t* d_idx_out, float* d_d2_out) {
     PairState* hs = (PairState*)c->h_state;
-    HIPCHK(c, hipMemcpyAsync(c->state.p, hs, (size_t)pl.npairs * sizeof(PairState), hipMemcpyHostToDevice, c->stream));
-    if (pl.grid) {
-        HIPCHK(c, hipMemsetAsync(c->g_count.p, 0, sizeof(int32_t), c->stream));
-        {
-            ProfScope ps(c, KSS_K_GRID_NN);
-            launch_grid_nn(c->stream, fma, (const PairState*)c->state.p, d_in, d_out, (int)pl.g[0].ns, pl.gp,
-                           (const int32_t*)c->g_start.p, (const float4*)c->g_sorted.p, (unsigned long long*)c->keys.p,
-                           (int32_t*)c->g_list.p, (int32_t*)c->g_count.p);
-        }
-        {   // queries the cell search gave up on (far from the target): brute-force sweep over the list
-            ProfScope ps(c, KSS_K_NN_SWEEP);
-            launch_nn_sweep_list(c->stream, pl.S, fma, (const NNWork*)c->nn_work.p, (int)pl.nn.size(), (const PairState*)c->state.p,
-                                 d_out, (const float4*)c->tgt4.p, (unsigned long long*)c->keys.p, (const int32_t*)c->g_list.p,
-                                 (const int32_t*)c->g_count.p);
-        }
-    } else {
-        ProfScope ps(c, KSS_K_NN_SWEEP);
-        launch_nn_sweep(c->stream, pl.S, fma, (const NNWork*)c->nn_work.p, (int)pl.nn.size(), (const PairState*)c->state.p,
-                        d_in, d_out, (const float4*)c->tgt4.p, (unsigned long long*)c->keys.p);
-    }
-    {
+    auto reduce = [&](const int32_t* unresolved, int32_t* reset) {
         ProfScope ps(c, KSS_K_CORR_REDUCE);
         launch_corr_reduce(c->stream, (const RedWork*)c->red_work.p, (int)pl.red.size(), (const PairState*)c->state.p,
                            d_out, (const float4*)c->tgt4.p, (const unsigned long long*)c->keys.p, max_d2,
                            (double*)c->partials.p, d_idx_out, d_d2_out);
-        launch_finalize_sums(c->stream, (const PairRed*)c->pair_red.p, pl.npairs, (const double*)c->partials.p, (double*)c->sums.p);
+        // the last kernel of the pass writes the sums straight into host-mapped pinned memory
+        launch_finalize_sums(c->stream, (const PairRed*)c->pair_red.p, pl.npairs, (const double*)c->partials.p,
+                             (double*)c->h_sums_dev, unresolved, reset);
+    };
+    if (pl.grid) {
+        // single pair: the transform rides in the kernel arguments, the device-side state (active = 1) was
+        // uploaded once by grid_setup
+        {
+            ProfScope ps(c, KSS_K_GRID_NN);
+            launch_grid_nn(c->stream, fma, hs[0], d_in, d_out, (int)pl.g[0].ns, pl.gp, (const int32_t*)c->g_start.p,
+                           (const float4*)c->g_sorted.p, (unsigned long long*)c->keys.p, (int32_t*)c->g_list.p,
+                           (int32_t*)c->g_count.p);
+        }
+        reduce((const int32_t*)c->g_count.p, nullptr);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (((const double*)c->h_sums)[NSUMS - 1] > 0.0) {
+            // queries the cell search gave up on (far from the target): brute-force sweep over the list,
+            // then the reduce again over every source
+            {
+                ProfScope ps(c, KSS_K_NN_SWEEP);
+                launch_nn_sweep_list(c->stream, pl.S, fma, (const NNWork*)c->nn_work.p, (int)pl.nn.size(), (const PairState*)c->state.p,
+                                     d_out, (const float4*)c->tgt4.p, (unsigned long long*)c->keys.p, (const int32_t*)c->g_list.p,
+                                     (const int32_t*)c->g_count.p);
+            }
+            reduce((const int32_t*)c->g_count.p, (int32_t*)c->g_count.p);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        ((double*)c->h_sums)[NSUMS - 1] = 0.0;
+        return KSS_OK;
     }
+    HIPCHK(c, hipMemcpyAsync(c->state.p, hs, (size_t)pl.npairs * sizeof(PairState), hipMemcpyHostToDevice, c->stream));
+    {
+        ProfScope ps(c, KSS_K_NN_SWEEP);
+        launch_nn_sweep(c->stream, pl.S, fma, (const NNWork*)c->nn_work.p, (int)pl.nn.size(), (const PairState*)c->state.p,
+                        d_in, d_out, (const float4*)c->tgt4.p, (unsigned long long*)c->keys.p);
+    }
+    reduce(nullptr, nullptr);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->h_sums, c->sums.p, (size_t)pl.npairs * NSUMS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return KSS_OK;
 }

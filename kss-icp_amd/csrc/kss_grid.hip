@@ -173,30 +173,46 @@ void launch_grid_build(hipStream_t st, const float4* d_tgt, int n, const GridPar
 }
 
 // ---- query -----------------------------------------------------------------------------------------------
+// GRID_LPQ lanes cooperate on one query: the rows of a shell are dealt round-robin to the lanes, each
+// lane keeps its own best (d2, idx) packed as ONE unsigned 64-bit key (bits(d2) << 32 | idx: unsigned
+// order == smaller distance first, then lower index; d2 >= +0 so its bit pattern is monotone), and a
+// 4-step xor-shuffle min merges them.  A single lane per query is latency bound (a chain of ~60
+// dependent L2 loads over only 1.5 waves per SIMD at 100k queries); 16 lanes cut the chain to ~4 loads
+// and fill the machine with 16x the waves.
+constexpr int GRID_LPQ = 16;
+
 template <bool FMA>
 __device__ __forceinline__ void scan_range(const float4* __restrict__ sorted, int lo, int hi, float qx, float qy, float qz,
-                                           float& best, int& bidx) {
+                                           unsigned long long& key) {
     for (int k = lo; k < hi; ++k) {
         const float4 p = sorted[k];
         const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
         float d;
         if constexpr (FMA) d = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
         else d = (dx * dx + dy * dy) + dz * dz;
-        const int id = __float_as_int(p.w);
-        if (d < best || (d == best && id < bidx)) { best = d; bidx = id; }
+        const unsigned long long kk = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(unsigned)__float_as_int(p.w);
+        key = kk < key ? kk : key;
     }
 }
 
+__device__ __forceinline__ unsigned long long group_min(unsigned long long k) {
+#pragma unroll
+    for (int m = GRID_LPQ / 2; m > 0; m >>= 1) {
+        const unsigned long long o = __shfl_xor(k, m, GRID_LPQ);
+        k = o < k ? o : k;
+    }
+    return k;
+}
+
 template <bool FMA>
-__global__ __launch_bounds__(256) void grid_nn_kernel(const PairState* __restrict__ state, const float4* __restrict__ src_in,
+__global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const float4* __restrict__ src_in,
                                                       float4* __restrict__ src_out, int ns, GridParams gp,
                                                       const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
                                                       unsigned long long* __restrict__ keys, int32_t* __restrict__ list,
                                                       int32_t* __restrict__ list_count) {
-    const PairState ps = state[0];
-    if (!ps.active) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ns) return;
+    const int sub = threadIdx.x % GRID_LPQ;   // ps travels as a kernel argument: no per-iteration upload
+    const int i = blockIdx.x * (256 / GRID_LPQ) + threadIdx.x / GRID_LPQ;
+    if (i >= ns) return;   // uniform over the query's lane group
     float4 p = src_in[i];
     if (ps.apply) {   // pcl transformCloud with the previous iteration's Matrix4f, as nn_sweep_kernel does
         const float x = p.x, y = p.y, z = p.z;
@@ -204,31 +220,33 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState* __restric
         p.y = ((ps.m[4] * x + ps.m[5] * y) + ps.m[6] * z) + ps.m[7];
         p.z = ((ps.m[8] * x + ps.m[9] * y) + ps.m[10] * z) + ps.m[11];
     }
-    src_out[i] = p;
+    if (sub == 0) src_out[i] = p;
     const float qx = p.x, qy = p.y, qz = p.z;
     const int cx = cell_coord(qx, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(qy, gp.oy, gp.inv_h, gp.gy),
               cz = cell_coord(qz, gp.oz, gp.inv_h, gp.gz);
-    float best = __builtin_inff();
-    int bidx = 0x7fffffff;
+    unsigned long long key = ~0ull;
     bool done = false;
-    for (int r = 0; r <= gp.rcap && !done; ++r) {
-        const int z0 = max(cz - r, 0), z1 = min(cz + r, gp.gz - 1);
-        const int y0 = max(cy - r, 0), y1 = min(cy + r, gp.gy - 1);
+    // r = 1 visits the whole 3x3x3 block at once (9 rows of <= 3 cells, one lane each); r >= 2 adds shells
+    for (int r = 1; r <= gp.rcap && !done; ++r) {
+        const int w = 2 * r + 1;
         const int x0 = max(cx - r, 0), x1 = min(cx + r, gp.gx - 1);
-        for (int z = z0; z <= z1; ++z) {
-            const bool zface = (z == cz - r) || (z == cz + r);
-            for (int y = y0; y <= y1; ++y) {
-                const int row = (z * gp.gy + y) * gp.gx;
-                if (zface || y == cy - r || y == cy + r) {
-                    // a row on the shell's y/z faces: the whole x extent is new -> one contiguous range
-                    scan_range<FMA>(sorted, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, best, bidx);
-                } else {
-                    // interior row: only the two x end cells belong to shell r
-                    if (cx - r >= 0) scan_range<FMA>(sorted, cell_start[row + cx - r], cell_start[row + cx - r + 1], qx, qy, qz, best, bidx);
-                    if (cx + r < gp.gx) scan_range<FMA>(sorted, cell_start[row + cx + r], cell_start[row + cx + r + 1], qx, qy, qz, best, bidx);
-                }
+        for (int t = sub; t < w * w; t += GRID_LPQ) {
+            const int dz = t / w - r, dy = t % w - r;
+            const int z = cz + dz, y = cy + dy;
+            if (z < 0 || z >= gp.gz || y < 0 || y >= gp.gy) continue;
+            const int row = (z * gp.gy + y) * gp.gx;
+            const bool face = r == 1 || dz == -r || dz == r || dy == -r || dy == r;
+            if (face) {
+                // the whole x extent of this row is new: ONE contiguous range of the cell-ordered array
+                scan_range<FMA>(sorted, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, key);
+            } else {
+                // interior row of shell r: only its two x end cells are new
+                if (cx - r >= 0) scan_range<FMA>(sorted, cell_start[row + cx - r], cell_start[row + cx - r + 1], qx, qy, qz, key);
+                if (cx + r < gp.gx) scan_range<FMA>(sorted, cell_start[row + cx + r], cell_start[row + cx + r + 1], qx, qy, qz, key);
             }
         }
+        key = group_min(key);
+        const float best = __uint_as_float((unsigned)(key >> 32));
         // distance from the query to the faces of the visited block; faces on the grid border are open
         float b = __builtin_inff();
         if (cx - r > 0) b = fminf(b, qx - (gp.ox + (float)(cx - r) * gp.h));
@@ -238,22 +256,25 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState* __restric
         if (cz - r > 0) b = fminf(b, qz - (gp.oz + (float)(cz - r) * gp.h));
         if (cz + r < gp.gz - 1) b = fminf(b, (gp.oz + (float)(cz + r + 1) * gp.h) - qz);
         const float bs = b - gp.eps;
-        if (b == __builtin_inff()) done = true;                       // the whole grid has been visited
-        else if (bs > 0.f && best < bs * bs * 0.999999f) done = true; // every unvisited point is strictly farther
+        if (b == __builtin_inff()) done = key != ~0ull;                 // the whole grid has been visited
+        else if (bs > 0.f && best < bs * bs * 0.999999f) done = true;   // every unvisited point is strictly farther
     }
-    if (done) {
-        keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(unsigned)bidx;
-    } else {
-        keys[i] = ~0ull;   // resolved by the brute-force list pass through atomicMin
-        const int slot = atomicAdd(list_count, 1);
-        list[slot] = i;
+    if (sub == 0) {
+        if (done) {
+            keys[i] = key;
+        } else {
+            keys[i] = ~0ull;   // resolved by the brute-force list pass through atomicMin
+            const int slot = atomicAdd(list_count, 1);
+            list[slot] = i;
+        }
     }
 }
 
-void launch_grid_nn(hipStream_t st, bool fma, const PairState* d_state, const float4* d_src_in, float4* d_src_out, int ns,
+void launch_grid_nn(hipStream_t st, bool fma, const PairState& d_state, const float4* d_src_in, float4* d_src_out, int ns,
                     const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted, unsigned long long* d_keys,
                     int32_t* d_list, int32_t* d_list_count) {
-    const dim3 grid((ns + 255) / 256), block(256);
+    const int qpb = 256 / GRID_LPQ;
+    const dim3 grid((ns + qpb - 1) / qpb), block(256);
     if (fma)
         hipLaunchKernelGGL(grid_nn_kernel<true>, grid, block, 0, st, d_state, d_src_in, d_src_out, ns, gp, d_cell_start, d_sorted, d_keys, d_list, d_list_count);
     else

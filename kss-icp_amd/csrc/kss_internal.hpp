@@ -78,7 +78,7 @@ void launch_nn_sweep_list(hipStream_t st, int S, bool fma, const NNWork* d_work,
 void launch_grid_bbox(hipStream_t st, const float4* d_tgt, int n, float* d_partial, int n_blocks);
 void launch_grid_build(hipStream_t st, const float4* d_tgt, int n, const GridParams& gp, int32_t* d_counts,
                        int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums, float4* d_sorted);
-void launch_grid_nn(hipStream_t st, bool fma, const PairState* d_state, const float4* d_src_in, float4* d_src_out, int ns,
+void launch_grid_nn(hipStream_t st, bool fma, const PairState& state, const float4* d_src_in, float4* d_src_out, int ns,
                     const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted, unsigned long long* d_keys,
                     int32_t* d_list, int32_t* d_list_count);
 
@@ -89,7 +89,8 @@ void launch_corr_reduce(hipStream_t st, const RedWork* d_work, int n_work, const
 void launch_corr_reduce_idx(hipStream_t st, const float* d_src3, const float* d_tgt3, const int32_t* d_idx,
                             int64_t n, double max_d2, double* d_partials, int n_blocks);
 void launch_finalize_sums(hipStream_t st, const PairRed* d_pairs, int n_pairs, const double* d_partials,
-                          double* d_out /* n_pairs * NSUMS, device or host-mapped */);
+                          double* d_out /* n_pairs * NSUMS, device or host-mapped */,
+                          const int32_t* d_unresolved /* may be null */, int32_t* d_unresolved_reset /* may be null */);
 
 void launch_preshape_sum(hipStream_t st, const void* d_xyz, int dtype, int64_t n, double* d_partials, int n_blocks);
 void launch_preshape_centroid(hipStream_t st, const double* d_partials, int n_blocks, int64_t n, double* d_centroid);

@@ -286,6 +286,7 @@ __global__ __launch_bounds__(256) void corr_reduce_kernel(const RedWork* __restr
             const unsigned long long k = keys[w.key_begin + (int64_t)s * w.key_stride + t];
             key = k < key ? k : key;
         }
+        if (key == ~0ull) continue;   // grid search gave up on this source: the list pass fills it, then we run again
         const float d2 = __uint_as_float((unsigned)(key >> 32));
         const int idx = (int)(unsigned)(key & 0xffffffffull);
         const float4 p = src[w.src_begin + t];
@@ -335,7 +336,8 @@ void launch_corr_reduce_idx(hipStream_t st, const float* d_src3, const float* d_
 // final stage: sums[pair][c] = sum over that pair's partial rows, in row order (deterministic)
 __global__ __launch_bounds__(64) void finalize_sums_kernel(const PairRed* __restrict__ pairs,
                                                            const double* __restrict__ partials,
-                                                           double* __restrict__ out) {
+                                                           double* __restrict__ out, const int32_t* __restrict__ unresolved,
+                                                           int32_t* __restrict__ unresolved_reset) {
     const PairRed pr = pairs[blockIdx.x];
     const int c = threadIdx.x;
     if (c >= NSUMS) return;
@@ -349,12 +351,20 @@ __global__ __launch_bounds__(64) void finalize_sums_kernel(const PairRed* __rest
         a3 += base[(int64_t)(r + 3) * NSUMS];
     }
     for (; r < pr.count; ++r) a0 += base[(int64_t)r * NSUMS];
-    out[(int64_t)blockIdx.x * NSUMS + c] = (a0 + a1) + (a2 + a3);
+    double v = (a0 + a1) + (a2 + a3);
+    if (c == NSUMS - 1 && unresolved) {
+        // slot 19 reports how many sources the cell search left to the brute-force list pass
+        v = (double)*unresolved;
+        if (unresolved_reset) *unresolved_reset = 0;
+    }
+    out[(int64_t)blockIdx.x * NSUMS + c] = v;
 }
 
-void launch_finalize_sums(hipStream_t st, const PairRed* d_pairs, int n_pairs, const double* d_partials, double* d_out) {
+void launch_finalize_sums(hipStream_t st, const PairRed* d_pairs, int n_pairs, const double* d_partials, double* d_out,
+                          const int32_t* d_unresolved, int32_t* d_unresolved_reset) {
     if (n_pairs <= 0) return;
-    hipLaunchKernelGGL(finalize_sums_kernel, dim3(n_pairs), dim3(64), 0, st, d_pairs, d_partials, d_out);
+    hipLaunchKernelGGL(finalize_sums_kernel, dim3(n_pairs), dim3(64), 0, st, d_pairs, d_partials, d_out, d_unresolved,
+                       d_unresolved_reset);
 }
 
 // ---------------------------------------------------------------------------------------------
