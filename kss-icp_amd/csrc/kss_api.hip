@@ -38,7 +38,7 @@ struct kss_ctx {
     // grow-only device workspace
     DevBuf tgt4, src0, cur[2], keys, partials, sums, nn_work, red_work, pair_red, state, cs, scratch_a,
         scratch_b, scratch_c, stage_src, stage_tgt, stage_idx, stage_d2, stage_out, g_counts, g_start, g_cursor,
-        g_bsums, g_sorted, g_list, g_count, g_bbox;
+        g_bsums, g_sorted, g_list, g_count, g_bbox, g_partials;
     // pinned host staging
     void* h_sums = nullptr;  size_t h_sums_cap = 0;   // host-mapped: kernels write it through h_sums_dev
     void* h_sums_dev = nullptr;
@@ -180,7 +180,7 @@ int kss_ctx_destroy(kss_ctx* c) {
     DevBuf* bufs[] = {&c->tgt4, &c->src0, &c->cur[0], &c->cur[1], &c->keys, &c->partials, &c->sums, &c->nn_work,
                       &c->red_work, &c->pair_red, &c->state, &c->cs, &c->scratch_a, &c->scratch_b, &c->scratch_c,
                       &c->stage_src, &c->stage_tgt, &c->stage_idx, &c->stage_d2, &c->stage_out, &c->g_counts, &c->g_start,
-                      &c->g_cursor, &c->g_bsums, &c->g_sorted, &c->g_list, &c->g_count, &c->g_bbox};
+                      &c->g_cursor, &c->g_bsums, &c->g_sorted, &c->g_list, &c->g_count, &c->g_bbox, &c->g_partials};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (c->h_sums) hipHostFree(c->h_sums);
@@ -436,7 +436,8 @@ int grid_setup(kss_ctx* c, IcpPlan& pl) {
     KCHK(ensure(c, c->g_bsums, ((ncells + 4095) / 4096 + 1) * sizeof(int32_t)));
     KCHK(ensure(c, c->g_sorted, (size_t)nt * sizeof(float4)));
     KCHK(ensure(c, c->g_list, (size_t)ns * sizeof(int32_t)));
-    KCHK(ensure(c, c->g_count, 64));
+    KCHK(ensure(c, c->g_count, 64));   // [0] unresolved-list length, [1] last-workgroup ticket
+    KCHK(ensure(c, c->g_partials, (size_t)grid_nn_blocks(ns) * NSUMS * sizeof(double)));
     HIPCHK(c, hipMemsetAsync(c->g_count.p, 0, 64, c->stream));
     {
         PairState one;
@@ -469,11 +470,12 @@ int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, float4*
         // uploaded once by grid_setup
         {
             ProfScope ps(c, KSS_K_GRID_NN);
+            // search + correspondence sums + final reduction in ONE launch; sums land in host-mapped memory
             launch_grid_nn(c->stream, fma, hs[0], d_in, d_out, (int)pl.g[0].ns, pl.gp, (const int32_t*)c->g_start.p,
-                           (const float4*)c->g_sorted.p, (unsigned long long*)c->keys.p, (int32_t*)c->g_list.p,
-                           (int32_t*)c->g_count.p);
+                           (const float4*)c->g_sorted.p, (const float4*)c->tgt4.p + pl.g[0].tgt_base,
+                           (unsigned long long*)c->keys.p, (int32_t*)c->g_list.p, (int32_t*)c->g_count.p, max_d2,
+                           (double*)c->g_partials.p, (int32_t*)c->g_count.p + 1, (double*)c->h_sums_dev, d_idx_out, d_d2_out);
         }
-        reduce((const int32_t*)c->g_count.p, nullptr);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (((const double*)c->h_sums)[NSUMS - 1] > 0.0) {

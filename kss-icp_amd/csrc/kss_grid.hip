@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kss_internal.hpp"
+#include "kss_device.hpp"
 
 namespace kss {
 
@@ -204,81 +205,152 @@ __device__ __forceinline__ unsigned long long group_min(unsigned long long k) {
     return k;
 }
 
+// One launch per ICP iteration: cell search + correspondence sums + the final reduction.
+//   - persistent workgroups stride over the query groups and keep the 20 f64 sums in registers;
+//   - each workgroup publishes one partial row, then takes a ticket on a device counter; the workgroup that
+//     draws the last ticket adds the rows up IN ROW ORDER (bitwise reproducible) and writes the result --
+//     normally straight into host-mapped pinned memory -- and re-arms the counter;
+//   - cross-workgroup visibility follows cdna_hip_programming.md Guideline 16: storing lanes release at agent
+//     scope (+ explicit s_waitcnt vmcnt(0), the ROCm 7.2 compiler hazard), one lane takes the ticket, acquires
+//     at agent scope, and the workgroup barrier publishes that to the other lanes before they load.
+//   Sources the search gives up on are excluded from the sums and counted in slot 19: the host then runs the
+//   brute-force list pass + the stand-alone reduce (rare: only for sources far from the target).
 template <bool FMA>
 __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const float4* __restrict__ src_in,
                                                       float4* __restrict__ src_out, int ns, GridParams gp,
                                                       const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
-                                                      unsigned long long* __restrict__ keys, int32_t* __restrict__ list,
-                                                      int32_t* __restrict__ list_count) {
+                                                      const float4* __restrict__ tgt, unsigned long long* __restrict__ keys,
+                                                      int32_t* __restrict__ list, int32_t* __restrict__ list_count,
+                                                      double max_d2, double* __restrict__ partials, int32_t* __restrict__ ticket,
+                                                      double* __restrict__ sums_out, int32_t* __restrict__ idx_out,
+                                                      float* __restrict__ d2_out) {
+    __shared__ double sh[4][NSUMS];
+    __shared__ int s_last;
     const int sub = threadIdx.x % GRID_LPQ;   // ps travels as a kernel argument: no per-iteration upload
-    const int i = blockIdx.x * (256 / GRID_LPQ) + threadIdx.x / GRID_LPQ;
-    if (i >= ns) return;   // uniform over the query's lane group
-    float4 p = src_in[i];
-    if (ps.apply) {   // pcl transformCloud with the previous iteration's Matrix4f, as nn_sweep_kernel does
-        const float x = p.x, y = p.y, z = p.z;
-        p.x = ((ps.m[0] * x + ps.m[1] * y) + ps.m[2] * z) + ps.m[3];
-        p.y = ((ps.m[4] * x + ps.m[5] * y) + ps.m[6] * z) + ps.m[7];
-        p.z = ((ps.m[8] * x + ps.m[9] * y) + ps.m[10] * z) + ps.m[11];
-    }
-    if (sub == 0) src_out[i] = p;
-    const float qx = p.x, qy = p.y, qz = p.z;
-    const int cx = cell_coord(qx, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(qy, gp.oy, gp.inv_h, gp.gy),
-              cz = cell_coord(qz, gp.oz, gp.inv_h, gp.gz);
-    unsigned long long key = ~0ull;
-    bool done = false;
-    // r = 1 visits the whole 3x3x3 block at once (9 rows of <= 3 cells, one lane each); r >= 2 adds shells
-    for (int r = 1; r <= gp.rcap && !done; ++r) {
-        const int w = 2 * r + 1;
-        const int x0 = max(cx - r, 0), x1 = min(cx + r, gp.gx - 1);
-        for (int t = sub; t < w * w; t += GRID_LPQ) {
-            const int dz = t / w - r, dy = t % w - r;
-            const int z = cz + dz, y = cy + dy;
-            if (z < 0 || z >= gp.gz || y < 0 || y >= gp.gy) continue;
-            const int row = (z * gp.gy + y) * gp.gx;
-            const bool face = r == 1 || dz == -r || dz == r || dy == -r || dy == r;
-            if (face) {
-                // the whole x extent of this row is new: ONE contiguous range of the cell-ordered array
-                scan_range<FMA>(sorted, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, key);
+    constexpr int QPB = 256 / GRID_LPQ;
+    double acc[NSUMS];
+#pragma unroll
+    for (int c = 0; c < NSUMS; ++c) acc[c] = 0.0;
+
+    for (int i = blockIdx.x * QPB + threadIdx.x / GRID_LPQ; i < ns; i += gridDim.x * QPB) {   // uniform per lane group
+        float4 p = src_in[i];
+        if (ps.apply) {   // pcl transformCloud with the previous iteration's Matrix4f, as nn_sweep_kernel does
+            const float x = p.x, y = p.y, z = p.z;
+            p.x = ((ps.m[0] * x + ps.m[1] * y) + ps.m[2] * z) + ps.m[3];
+            p.y = ((ps.m[4] * x + ps.m[5] * y) + ps.m[6] * z) + ps.m[7];
+            p.z = ((ps.m[8] * x + ps.m[9] * y) + ps.m[10] * z) + ps.m[11];
+        }
+        if (sub == 0) src_out[i] = p;
+        const float qx = p.x, qy = p.y, qz = p.z;
+        const int cx = cell_coord(qx, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(qy, gp.oy, gp.inv_h, gp.gy),
+                  cz = cell_coord(qz, gp.oz, gp.inv_h, gp.gz);
+        unsigned long long key = ~0ull;
+        bool done = false;
+        // r = 1 visits the whole 3x3x3 block at once (9 rows of <= 3 cells, one lane each); r >= 2 adds shells
+        for (int r = 1; r <= gp.rcap && !done; ++r) {
+            const int w = 2 * r + 1;
+            const int x0 = max(cx - r, 0), x1 = min(cx + r, gp.gx - 1);
+            for (int t = sub; t < w * w; t += GRID_LPQ) {
+                const int dz = t / w - r, dy = t % w - r;
+                const int z = cz + dz, y = cy + dy;
+                if (z < 0 || z >= gp.gz || y < 0 || y >= gp.gy) continue;
+                const int row = (z * gp.gy + y) * gp.gx;
+                const bool face = r == 1 || dz == -r || dz == r || dy == -r || dy == r;
+                if (face) {
+                    // the whole x extent of this row is new: ONE contiguous range of the cell-ordered array
+                    scan_range<FMA>(sorted, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, key);
+                } else {
+                    // interior row of shell r: only its two x end cells are new
+                    if (cx - r >= 0) scan_range<FMA>(sorted, cell_start[row + cx - r], cell_start[row + cx - r + 1], qx, qy, qz, key);
+                    if (cx + r < gp.gx) scan_range<FMA>(sorted, cell_start[row + cx + r], cell_start[row + cx + r + 1], qx, qy, qz, key);
+                }
+            }
+            key = group_min(key);
+            const float best = __uint_as_float((unsigned)(key >> 32));
+            // distance from the query to the faces of the visited block; faces on the grid border are open
+            float b = __builtin_inff();
+            if (cx - r > 0) b = fminf(b, qx - (gp.ox + (float)(cx - r) * gp.h));
+            if (cx + r < gp.gx - 1) b = fminf(b, (gp.ox + (float)(cx + r + 1) * gp.h) - qx);
+            if (cy - r > 0) b = fminf(b, qy - (gp.oy + (float)(cy - r) * gp.h));
+            if (cy + r < gp.gy - 1) b = fminf(b, (gp.oy + (float)(cy + r + 1) * gp.h) - qy);
+            if (cz - r > 0) b = fminf(b, qz - (gp.oz + (float)(cz - r) * gp.h));
+            if (cz + r < gp.gz - 1) b = fminf(b, (gp.oz + (float)(cz + r + 1) * gp.h) - qz);
+            const float bs = b - gp.eps;
+            if (b == __builtin_inff()) done = key != ~0ull;                 // the whole grid has been visited
+            else if (bs > 0.f && best < bs * bs * 0.999999f) done = true;   // every unvisited point is strictly farther
+        }
+        if (sub == 0) {
+            if (done) {
+                keys[i] = key;
+                const float d2 = __uint_as_float((unsigned)(key >> 32));
+                const int idx = (int)(unsigned)(key & 0xffffffffull);
+                const float4 q = tgt[idx];
+                accumulate_corr(acc, qx, qy, qz, q.x, q.y, q.z, d2, max_d2);
+                if (idx_out) idx_out[i] = idx;
+                if (d2_out) d2_out[i] = d2;
             } else {
-                // interior row of shell r: only its two x end cells are new
-                if (cx - r >= 0) scan_range<FMA>(sorted, cell_start[row + cx - r], cell_start[row + cx - r + 1], qx, qy, qz, key);
-                if (cx + r < gp.gx) scan_range<FMA>(sorted, cell_start[row + cx + r], cell_start[row + cx + r + 1], qx, qy, qz, key);
+                keys[i] = ~0ull;   // resolved by the brute-force list pass through atomicMin
+                const int slot = atomicAdd(list_count, 1);
+                list[slot] = i;
             }
         }
-        key = group_min(key);
-        const float best = __uint_as_float((unsigned)(key >> 32));
-        // distance from the query to the faces of the visited block; faces on the grid border are open
-        float b = __builtin_inff();
-        if (cx - r > 0) b = fminf(b, qx - (gp.ox + (float)(cx - r) * gp.h));
-        if (cx + r < gp.gx - 1) b = fminf(b, (gp.ox + (float)(cx + r + 1) * gp.h) - qx);
-        if (cy - r > 0) b = fminf(b, qy - (gp.oy + (float)(cy - r) * gp.h));
-        if (cy + r < gp.gy - 1) b = fminf(b, (gp.oy + (float)(cy + r + 1) * gp.h) - qy);
-        if (cz - r > 0) b = fminf(b, qz - (gp.oz + (float)(cz - r) * gp.h));
-        if (cz + r < gp.gz - 1) b = fminf(b, (gp.oz + (float)(cz + r + 1) * gp.h) - qz);
-        const float bs = b - gp.eps;
-        if (b == __builtin_inff()) done = key != ~0ull;                 // the whole grid has been visited
-        else if (bs > 0.f && best < bs * bs * 0.999999f) done = true;   // every unvisited point is strictly farther
     }
-    if (sub == 0) {
-        if (done) {
-            keys[i] = key;
-        } else {
-            keys[i] = ~0ull;   // resolved by the brute-force list pass through atomicMin
-            const int slot = atomicAdd(list_count, 1);
-            list[slot] = i;
+
+    // ---- workgroup partial row, then the last workgroup finishes the job ----
+    const double r = block_sum<NSUMS>(acc, sh);
+    if (threadIdx.x < NSUMS) {
+        partials[(int64_t)blockIdx.x * NSUMS + threadIdx.x] = r;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tk = atomicAdd(ticket, 1);
+        const int last = tk == (int)gridDim.x - 1;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        s_last = last;
     }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x < NSUMS) {
+        const int c = threadIdx.x;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int k = 0;
+        const int nb = gridDim.x;
+        for (; k + 4 <= nb; k += 4) {
+            a0 += partials[(int64_t)(k + 0) * NSUMS + c];
+            a1 += partials[(int64_t)(k + 1) * NSUMS + c];
+            a2 += partials[(int64_t)(k + 2) * NSUMS + c];
+            a3 += partials[(int64_t)(k + 3) * NSUMS + c];
+        }
+        for (; k < nb; ++k) a0 += partials[(int64_t)k * NSUMS + c];
+        double v = (a0 + a1) + (a2 + a3);
+        if (c == NSUMS - 1) v = (double)__hip_atomic_load(list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sums_out[c] = v;
+    }
+    if (threadIdx.x == 0) *ticket = 0;   // re-arm for the next launch (stream order makes it visible)
 }
 
-void launch_grid_nn(hipStream_t st, bool fma, const PairState& d_state, const float4* d_src_in, float4* d_src_out, int ns,
-                    const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted, unsigned long long* d_keys,
-                    int32_t* d_list, int32_t* d_list_count) {
+int grid_nn_blocks(int ns) {
     const int qpb = 256 / GRID_LPQ;
-    const dim3 grid((ns + qpb - 1) / qpb), block(256);
+    const int need = (ns + qpb - 1) / qpb;
+    return need < 1024 ? need : 1024;   // persistent: 4 workgroups per CU
+}
+
+void launch_grid_nn(hipStream_t st, bool fma, const PairState& state, const float4* d_src_in, float4* d_src_out, int ns,
+                    const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted, const float4* d_tgt,
+                    unsigned long long* d_keys, int32_t* d_list, int32_t* d_list_count, double max_d2, double* d_partials,
+                    int32_t* d_ticket, double* d_sums_out, int32_t* d_idx_out, float* d_d2_out) {
+    const dim3 grid(grid_nn_blocks(ns)), block(256);
     if (fma)
-        hipLaunchKernelGGL(grid_nn_kernel<true>, grid, block, 0, st, d_state, d_src_in, d_src_out, ns, gp, d_cell_start, d_sorted, d_keys, d_list, d_list_count);
+        hipLaunchKernelGGL(grid_nn_kernel<true>, grid, block, 0, st, state, d_src_in, d_src_out, ns, gp, d_cell_start, d_sorted,
+                           d_tgt, d_keys, d_list, d_list_count, max_d2, d_partials, d_ticket, d_sums_out, d_idx_out, d_d2_out);
     else
-        hipLaunchKernelGGL(grid_nn_kernel<false>, grid, block, 0, st, d_state, d_src_in, d_src_out, ns, gp, d_cell_start, d_sorted, d_keys, d_list, d_list_count);
+        hipLaunchKernelGGL(grid_nn_kernel<false>, grid, block, 0, st, state, d_src_in, d_src_out, ns, gp, d_cell_start, d_sorted,
+                           d_tgt, d_keys, d_list, d_list_count, max_d2, d_partials, d_ticket, d_sums_out, d_idx_out, d_d2_out);
 }
 
 }  // namespace kss

@@ -79,8 +79,10 @@ void launch_grid_bbox(hipStream_t st, const float4* d_tgt, int n, float* d_parti
 void launch_grid_build(hipStream_t st, const float4* d_tgt, int n, const GridParams& gp, int32_t* d_counts,
                        int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums, float4* d_sorted);
 void launch_grid_nn(hipStream_t st, bool fma, const PairState& state, const float4* d_src_in, float4* d_src_out, int ns,
-                    const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted, unsigned long long* d_keys,
-                    int32_t* d_list, int32_t* d_list_count);
+                    const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted, const float4* d_tgt,
+                    unsigned long long* d_keys, int32_t* d_list, int32_t* d_list_count, double max_d2, double* d_partials,
+                    int32_t* d_ticket, double* d_sums_out, int32_t* d_idx_out, float* d_d2_out);
+int grid_nn_blocks(int ns);
 
 void launch_corr_reduce(hipStream_t st, const RedWork* d_work, int n_work, const PairState* d_state,
                         const float4* d_src, const float4* d_tgt4, const unsigned long long* d_keys,

@@ -70,8 +70,27 @@ def test_grid_icp_bitwise_equals_brute(ctx, pkg):
     src, tgt = S.make_pair(31, 20000, R=S.rot_axis_angle([0.3, 0.2, 1.0], np.deg2rad(12.0)), t=(0.02, 0.0, -0.01), shape="bumpy")
     a = ctx.icp(src, tgt, ctx.icp_params(max_iterations=12, fixed_iterations=1, nn_mode=pkg.NN_BRUTE), trace_cap=16)
     b = ctx.icp(src, tgt, ctx.icp_params(max_iterations=12, fixed_iterations=1, nn_mode=pkg.NN_GRID), trace_cap=16)
-    assert np.array_equal(a["trace_sums"], b["trace_sums"])       # same NN bits, same fixed-order reduction
-    assert np.array_equal(a["T"], b["T"]) and a["fitness"] == b["fitness"]
+    # same NN bits; the f64 sums are grouped differently (fused persistent workgroups vs 256*R chunks)
+    assert np.array_equal(a["trace_sums"][:, 0], b["trace_sums"][:, 0])
+    assert np.allclose(a["trace_sums"], b["trace_sums"], rtol=1e-12, atol=1e-12)
+    assert np.abs(a["T"] - b["T"]).max() < 1e-6 and abs(a["fitness"] - b["fitness"]) < 1e-12
     c = ctx.icp(src, tgt, ctx.icp_params(nn_mode=pkg.NN_GRID))
     d = ctx.icp(src, tgt, ctx.icp_params(nn_mode=pkg.NN_BRUTE))
-    assert c["iterations"] == d["iterations"] and np.array_equal(c["T"], d["T"])
+    assert c["iterations"] == d["iterations"] and np.abs(c["T"] - d["T"]).max() < 1e-6
+    # run to run the grid path is bitwise reproducible (row-ordered final reduction)
+    c2 = ctx.icp(src, tgt, ctx.icp_params(nn_mode=pkg.NN_GRID), trace_cap=64)
+    c3 = ctx.icp(src, tgt, ctx.icp_params(nn_mode=pkg.NN_GRID), trace_cap=64)
+    assert np.array_equal(c2["trace_sums"], c3["trace_sums"]) and np.array_equal(c2["T"], c3["T"])
+
+
+def test_grid_icp_with_unresolved_sources(ctx, O, pkg):
+    """A source far from the target: the cell search gives up on most points in the first iterations, the
+    brute-force list pass resolves them, later iterations stay inside the grid."""
+    S = pkg.synth
+    src, tgt = S.make_pair(32, 8000, R=S.rot_axis_angle([0, 1, 0], np.deg2rad(5.0)), t=(0.45, -0.3, 0.2), shape="bumpy")
+    g = ctx.icp(src, tgt, ctx.icp_params(nn_mode=pkg.NN_GRID), trace_cap=200)
+    r = O.icp(src, tgt, trace_cap=200)
+    assert g["iterations"] == r["iterations"] and g["state"] == r["state"]
+    assert np.array_equal(g["trace_sums"][:, 0], r["trace_sums"][:, 0])
+    assert np.allclose(g["trace_sums"], r["trace_sums"], rtol=1e-9, atol=1e-12)
+    assert np.abs(g["T"] - r["T"]).max() < 1e-5 and abs(g["fitness"] - r["fitness"]) < 1e-9

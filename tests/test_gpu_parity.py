@@ -207,10 +207,10 @@ def test_icp_not_enough_correspondences(ctx, O):
 def test_icp_tuning_knobs_do_not_change_results(ctx, pkg):
     S = pkg.synth
     src, tgt = S.make_pair(5, 6000, R=S.rot_axis_angle([0, 1, 1], np.deg2rad(7.0)), shape="bumpy")
-    base = ctx.icp(src, tgt, ctx.icp_params(max_iterations=5, fixed_iterations=1), trace_cap=8)
+    base = ctx.icp(src, tgt, ctx.icp_params(max_iterations=5, fixed_iterations=1, nn_mode=pkg.NN_BRUTE), trace_cap=8)
     for spt, split in [(1, 1), (2, 3), (4, 7), (8, 2)]:
         r = ctx.icp(src, tgt, ctx.icp_params(max_iterations=5, fixed_iterations=1, nn_sources_per_thread=spt,
-                                             nn_target_splits=split), trace_cap=8)
+                                             nn_target_splits=split, nn_mode=pkg.NN_BRUTE), trace_cap=8)
         assert np.array_equal(r["trace_sums"], base["trace_sums"])      # bitwise: exact NN + fixed-order sums
         assert np.array_equal(r["T"], base["T"])
 
