@@ -41,6 +41,32 @@ __device__ __forceinline__ double block_sum(const double (&v)[NV], double (*sh)[
 }
 
 
+// Column sums of `nrows` partial rows (NSUMS doubles each) by one 256-lane workgroup, bitwise reproducible:
+// lane (g, c) = (tid / NSUMS, tid % NSUMS) adds rows g, g+12, g+24, ... of column c with four independent
+// accumulators (many loads in flight: the rows come from other CUs' L2 / HBM), then the 12 group totals are
+// added in group order.  Returns the column total in lanes tid < NSUMS.  Needs blockDim.x == 256.
+constexpr int ROWSUM_GROUPS = 12;   // 12 * 20 = 240 of the 256 lanes
+__device__ __forceinline__ double rows_column_sum(const double* __restrict__ rows, int nrows, double (*shg)[NSUMS]) {
+    const int g = threadIdx.x / NSUMS, c = threadIdx.x % NSUMS;
+    if (g < ROWSUM_GROUPS) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int k = g;
+        for (; k + 3 * ROWSUM_GROUPS < nrows; k += 4 * ROWSUM_GROUPS) {
+            a0 += rows[(int64_t)(k) * NSUMS + c];
+            a1 += rows[(int64_t)(k + ROWSUM_GROUPS) * NSUMS + c];
+            a2 += rows[(int64_t)(k + 2 * ROWSUM_GROUPS) * NSUMS + c];
+            a3 += rows[(int64_t)(k + 3 * ROWSUM_GROUPS) * NSUMS + c];
+        }
+        for (; k < nrows; k += ROWSUM_GROUPS) a0 += rows[(int64_t)k * NSUMS + c];
+        shg[g][c] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    double v = 0.0;
+    if (threadIdx.x < NSUMS)
+        for (int gg = 0; gg < ROWSUM_GROUPS; ++gg) v += shg[gg][threadIdx.x];
+    return v;
+}
+
 // correspondence sums of one (source, matched target) pair; see KSS_NSUMS in include/kssicp.h
 __device__ __forceinline__ void accumulate_corr(double (&acc)[NSUMS], float px, float py, float pz,
                                                 float qx, float qy, float qz, float d2f, double max_d2) {

@@ -225,6 +225,7 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const 
                                                       double* __restrict__ sums_out, int32_t* __restrict__ idx_out,
                                                       float* __restrict__ d2_out) {
     __shared__ double sh[4][NSUMS];
+    __shared__ double shg[ROWSUM_GROUPS][NSUMS];
     __shared__ int s_last;
     const int sub = threadIdx.x % GRID_LPQ;   // ps travels as a kernel argument: no per-iteration upload
     constexpr int QPB = 256 / GRID_LPQ;
@@ -315,21 +316,10 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const 
     }
     __syncthreads();
     if (!s_last) return;
+    double v = rows_column_sum(partials, (int)gridDim.x, shg);
     if (threadIdx.x < NSUMS) {
-        const int c = threadIdx.x;
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        int k = 0;
-        const int nb = gridDim.x;
-        for (; k + 4 <= nb; k += 4) {
-            a0 += partials[(int64_t)(k + 0) * NSUMS + c];
-            a1 += partials[(int64_t)(k + 1) * NSUMS + c];
-            a2 += partials[(int64_t)(k + 2) * NSUMS + c];
-            a3 += partials[(int64_t)(k + 3) * NSUMS + c];
-        }
-        for (; k < nb; ++k) a0 += partials[(int64_t)k * NSUMS + c];
-        double v = (a0 + a1) + (a2 + a3);
-        if (c == NSUMS - 1) v = (double)__hip_atomic_load(list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sums_out[c] = v;
+        if (threadIdx.x == NSUMS - 1) v = (double)__hip_atomic_load(list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sums_out[threadIdx.x] = v;
     }
     if (threadIdx.x == 0) *ticket = 0;   // re-arm for the next launch (stream order makes it visible)
 }

@@ -279,24 +279,15 @@ void launch_corr_reduce_idx(hipStream_t st, const float* d_src3, const float* d_
 }
 
 // final stage: sums[pair][c] = sum over that pair's partial rows, in row order (deterministic)
-__global__ __launch_bounds__(64) void finalize_sums_kernel(const PairRed* __restrict__ pairs,
-                                                           const double* __restrict__ partials,
-                                                           double* __restrict__ out, const int32_t* __restrict__ unresolved,
-                                                           int32_t* __restrict__ unresolved_reset) {
+__global__ __launch_bounds__(256) void finalize_sums_kernel(const PairRed* __restrict__ pairs,
+                                                            const double* __restrict__ partials,
+                                                            double* __restrict__ out, const int32_t* __restrict__ unresolved,
+                                                            int32_t* __restrict__ unresolved_reset) {
+    __shared__ double shg[ROWSUM_GROUPS][NSUMS];
     const PairRed pr = pairs[blockIdx.x];
+    double v = rows_column_sum(partials + (int64_t)pr.first * NSUMS, pr.count, shg);
     const int c = threadIdx.x;
     if (c >= NSUMS) return;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int r = 0;
-    const double* base = partials + (int64_t)pr.first * NSUMS + c;
-    for (; r + 4 <= pr.count; r += 4) {
-        a0 += base[(int64_t)(r + 0) * NSUMS];
-        a1 += base[(int64_t)(r + 1) * NSUMS];
-        a2 += base[(int64_t)(r + 2) * NSUMS];
-        a3 += base[(int64_t)(r + 3) * NSUMS];
-    }
-    for (; r < pr.count; ++r) a0 += base[(int64_t)r * NSUMS];
-    double v = (a0 + a1) + (a2 + a3);
     if (c == NSUMS - 1 && unresolved) {
         // slot 19 reports how many sources the cell search left to the brute-force list pass
         v = (double)*unresolved;
@@ -308,7 +299,7 @@ __global__ __launch_bounds__(64) void finalize_sums_kernel(const PairRed* __rest
 void launch_finalize_sums(hipStream_t st, const PairRed* d_pairs, int n_pairs, const double* d_partials, double* d_out,
                           const int32_t* d_unresolved, int32_t* d_unresolved_reset) {
     if (n_pairs <= 0) return;
-    hipLaunchKernelGGL(finalize_sums_kernel, dim3(n_pairs), dim3(64), 0, st, d_pairs, d_partials, d_out, d_unresolved,
+    hipLaunchKernelGGL(finalize_sums_kernel, dim3(n_pairs), dim3(256), 0, st, d_pairs, d_partials, d_out, d_unresolved,
                        d_unresolved_reset);
 }
 
