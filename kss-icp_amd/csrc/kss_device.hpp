@@ -49,15 +49,24 @@ constexpr int ROWSUM_GROUPS = 12;   // 12 * 20 = 240 of the 256 lanes
 __device__ __forceinline__ double rows_column_sum(const double* __restrict__ rows, int nrows, double (*shg)[NSUMS]) {
     const int g = threadIdx.x / NSUMS, c = threadIdx.x % NSUMS;
     if (g < ROWSUM_GROUPS) {
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
         int k = g;
-        for (; k + 3 * ROWSUM_GROUPS < nrows; k += 4 * ROWSUM_GROUPS) {
+        constexpr int G = ROWSUM_GROUPS;
+        for (; k + 7 * G < nrows; k += 8 * G) {
             a0 += rows[(int64_t)(k) * NSUMS + c];
-            a1 += rows[(int64_t)(k + ROWSUM_GROUPS) * NSUMS + c];
-            a2 += rows[(int64_t)(k + 2 * ROWSUM_GROUPS) * NSUMS + c];
-            a3 += rows[(int64_t)(k + 3 * ROWSUM_GROUPS) * NSUMS + c];
+            a1 += rows[(int64_t)(k + G) * NSUMS + c];
+            a2 += rows[(int64_t)(k + 2 * G) * NSUMS + c];
+            a3 += rows[(int64_t)(k + 3 * G) * NSUMS + c];
+            a4 += rows[(int64_t)(k + 4 * G) * NSUMS + c];
+            a5 += rows[(int64_t)(k + 5 * G) * NSUMS + c];
+            a6 += rows[(int64_t)(k + 6 * G) * NSUMS + c];
+            a7 += rows[(int64_t)(k + 7 * G) * NSUMS + c];
         }
-        for (; k < nrows; k += ROWSUM_GROUPS) a0 += rows[(int64_t)k * NSUMS + c];
+        for (; k < nrows; k += G) a0 += rows[(int64_t)k * NSUMS + c];
+        a0 = (a0 + a1) + (a2 + a3);
+        a2 = (a4 + a5) + (a6 + a7);
+        a1 = 0.0; a3 = 0.0;
+        a0 = a0 + a2; a2 = 0.0;
         shg[g][c] = (a0 + a1) + (a2 + a3);
     }
     __syncthreads();

@@ -229,9 +229,13 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const 
     __shared__ int s_last;
     const int sub = threadIdx.x % GRID_LPQ;   // ps travels as a kernel argument: no per-iteration upload
     constexpr int QPB = 256 / GRID_LPQ;
-    double acc[NSUMS];
-#pragma unroll
-    for (int c = 0; c < NSUMS; ++c) acc[c] = 0.0;
+    // The 20 correspondence sums are spread over the 16 lanes of a query group: lane `sub` owns sums[sub] and,
+    // for sub < 4, sums[16 + sub] -- two f64 accumulators per lane instead of twenty (register pressure
+    // decides how many waves hide the L2 latency of the search).  sums[c] = keep * pv * qv with pv in
+    // {1, px, py, pz} and qv in {1, qx, qy, qz}: c = 0 count, 1..3 src, 4..6 tgt, 7..15 src_i * tgt_j.
+    const int pa = (sub >= 1 && sub <= 3) ? sub - 1 : (sub >= 7 ? (sub - 7) / 3 : -1);
+    const int qb = (sub >= 4 && sub <= 6) ? sub - 4 : (sub >= 7 ? (sub - 7) % 3 : -1);
+    double acc_a = 0.0, acc_b = 0.0;
 
     for (int i = blockIdx.x * QPB + threadIdx.x / GRID_LPQ; i < ns; i += gridDim.x * QPB) {   // uniform per lane group
         float4 p = src_in[i];
@@ -280,26 +284,42 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const 
             if (b == __builtin_inff()) done = key != ~0ull;                 // the whole grid has been visited
             else if (bs > 0.f && best < bs * bs * 0.999999f) done = true;   // every unvisited point is strictly farther
         }
-        if (sub == 0) {
-            if (done) {
+        if (done) {
+            const float d2 = __uint_as_float((unsigned)(key >> 32));
+            const int idx = (int)(unsigned)(key & 0xffffffffull);
+            const float4 q = tgt[idx];   // one address per lane group
+            const double dd = (double)d2;
+            const bool keep = !(dd > max_d2);   // PCL: `if (distance[0] > max_dist_sqr) continue;`
+            const double pv = pa == 0 ? (double)qx : pa == 1 ? (double)qy : pa == 2 ? (double)qz : 1.0;
+            const double qv = qb == 0 ? (double)q.x : qb == 1 ? (double)q.y : qb == 2 ? (double)q.z : 1.0;
+            acc_a += keep ? pv * qv : 0.0;
+            acc_b += sub == 0 ? (keep ? dd : 0.0) : sub == 1 ? dd : sub == 2 ? sqrt(dd) : 0.0;
+            if (sub == 0) {
                 keys[i] = key;
-                const float d2 = __uint_as_float((unsigned)(key >> 32));
-                const int idx = (int)(unsigned)(key & 0xffffffffull);
-                const float4 q = tgt[idx];
-                accumulate_corr(acc, qx, qy, qz, q.x, q.y, q.z, d2, max_d2);
                 if (idx_out) idx_out[i] = idx;
                 if (d2_out) d2_out[i] = d2;
-            } else {
-                keys[i] = ~0ull;   // resolved by the brute-force list pass through atomicMin
-                const int slot = atomicAdd(list_count, 1);
-                list[slot] = i;
             }
+        } else if (sub == 0) {
+            keys[i] = ~0ull;   // resolved by the brute-force list pass through atomicMin
+            const int slot = atomicAdd(list_count, 1);
+            list[slot] = i;
         }
     }
 
     // ---- workgroup partial row, then the last workgroup finishes the job ----
-    const double r = block_sum<NSUMS>(acc, sh);
+    // the 4 query groups of a wave hold the same component in lanes of equal `sub`
+    acc_a += __shfl_xor(acc_a, 16, 64);
+    acc_a += __shfl_xor(acc_a, 32, 64);
+    acc_b += __shfl_xor(acc_b, 16, 64);
+    acc_b += __shfl_xor(acc_b, 32, 64);
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane < 16) sh[wave][lane] = acc_a;
+        if (lane < 4) sh[wave][16 + lane] = acc_b;
+    }
+    __syncthreads();
     if (threadIdx.x < NSUMS) {
+        const double r = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
         partials[(int64_t)blockIdx.x * NSUMS + threadIdx.x] = r;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -327,7 +347,7 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const 
 int grid_nn_blocks(int ns) {
     const int qpb = 256 / GRID_LPQ;
     const int need = (ns + qpb - 1) / qpb;
-    return need < 1024 ? need : 1024;   // persistent: 4 workgroups per CU
+    return need < 1792 ? need : 1792;   // persistent: 7 workgroups per CU (106 SGPRs cap residency at 7 waves per SIMD)
 }
 
 void launch_grid_nn(hipStream_t st, bool fma, const PairState& state, const float4* d_src_in, float4* d_src_out, int ns,
