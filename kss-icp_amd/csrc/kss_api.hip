@@ -38,7 +38,7 @@ struct kss_ctx {
     // grow-only device workspace
     DevBuf tgt4, src0, cur[2], keys, partials, sums, nn_work, red_work, pair_red, state, cs, scratch_a,
         scratch_b, scratch_c, stage_src, stage_tgt, stage_idx, stage_d2, stage_out, g_counts, g_start, g_cursor,
-        g_bsums, g_sorted, g_list, g_count, g_bbox, g_partials;
+        g_bsums, g_sorted, g_list, g_count, g_bbox, g_partials, g_start2;
     // pinned host staging
     void* h_sums = nullptr;  size_t h_sums_cap = 0;   // host-mapped: kernels write it through h_sums_dev
     void* h_sums_dev = nullptr;
@@ -180,7 +180,7 @@ int kss_ctx_destroy(kss_ctx* c) {
     DevBuf* bufs[] = {&c->tgt4, &c->src0, &c->cur[0], &c->cur[1], &c->keys, &c->partials, &c->sums, &c->nn_work,
                       &c->red_work, &c->pair_red, &c->state, &c->cs, &c->scratch_a, &c->scratch_b, &c->scratch_c,
                       &c->stage_src, &c->stage_tgt, &c->stage_idx, &c->stage_d2, &c->stage_out, &c->g_counts, &c->g_start,
-                      &c->g_cursor, &c->g_bsums, &c->g_sorted, &c->g_list, &c->g_count, &c->g_bbox, &c->g_partials};
+                      &c->g_cursor, &c->g_bsums, &c->g_sorted, &c->g_list, &c->g_count, &c->g_bbox, &c->g_partials, &c->g_start2};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (c->h_sums) hipHostFree(c->h_sums);
@@ -448,6 +448,12 @@ int grid_setup(kss_ctx* c, IcpPlan& pl) {
     }
     launch_grid_build(c->stream, tgt, nt, gp, (int32_t*)c->g_counts.p, (int32_t*)c->g_start.p, (int32_t*)c->g_cursor.p,
                       (int32_t*)c->g_bsums.p, (float4*)c->g_sorted.p);
+    // sources into the same cell order (original index in .w): cur[0] is the scratch of the scatter
+    KCHK(ensure(c, c->g_start2, (ncells + 1) * sizeof(int32_t)));
+    launch_grid_sort_sources(c->stream, (const float4*)c->src0.p + g.src_base, ns, gp, (int32_t*)c->g_counts.p,
+                             (int32_t*)c->g_start2.p, (int32_t*)c->g_cursor.p, (int32_t*)c->g_bsums.p,
+                             (float4*)c->cur[0].p, (float4*)c->cur[1].p);
+    HIPCHK(c, hipMemcpyAsync((float4*)c->src0.p + g.src_base, c->cur[1].p, (size_t)ns * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipGetLastError());
     return KSS_OK;
 }
@@ -460,7 +466,7 @@ int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, float4*
         ProfScope ps(c, KSS_K_CORR_REDUCE);
         launch_corr_reduce(c->stream, (const RedWork*)c->red_work.p, (int)pl.red.size(), (const PairState*)c->state.p,
                            d_out, (const float4*)c->tgt4.p, (const unsigned long long*)c->keys.p, max_d2,
-                           (double*)c->partials.p, d_idx_out, d_d2_out);
+                           (double*)c->partials.p, d_idx_out, d_d2_out, pl.grid ? 1 : 0);
         // the last kernel of the pass writes the sums straight into host-mapped pinned memory
         launch_finalize_sums(c->stream, (const PairRed*)c->pair_red.p, pl.npairs, (const double*)c->partials.p,
                              (double*)c->h_sums_dev, unresolved, reset);
@@ -472,8 +478,7 @@ int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, float4*
             ProfScope ps(c, KSS_K_GRID_NN);
             // search + correspondence sums + final reduction in ONE launch; sums land in host-mapped memory
             launch_grid_nn(c->stream, fma, hs[0], d_in, d_out, (int)pl.g[0].ns, pl.gp, (const int32_t*)c->g_start.p,
-                           (const float4*)c->g_sorted.p, (const float4*)c->tgt4.p + pl.g[0].tgt_base,
-                           (unsigned long long*)c->keys.p, (int32_t*)c->g_list.p, (int32_t*)c->g_count.p, max_d2,
+                           (const float4*)c->g_sorted.p, (unsigned long long*)c->keys.p, (int32_t*)c->g_list.p, (int32_t*)c->g_count.p, max_d2,
                            (double*)c->g_partials.p, (int32_t*)c->g_count.p + 1, (double*)c->h_sums_dev, d_idx_out, d_d2_out);
         }
         HIPCHK(c, hipGetLastError());

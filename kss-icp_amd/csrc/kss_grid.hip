@@ -18,6 +18,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "kss_internal.hpp"
 #include "kss_device.hpp"
 
@@ -183,26 +185,65 @@ void launch_grid_build(hipStream_t st, const float4* d_tgt, int n, const GridPar
 constexpr int GRID_LPQ = 16;
 
 template <bool FMA>
+__device__ __forceinline__ unsigned long long point_key(const float4 p, float qx, float qy, float qz) {
+    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+    float d;
+    if constexpr (FMA) d = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+    else d = (dx * dx + dy * dy) + dz * dz;
+    return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(unsigned)__float_as_int(p.w);
+}
+
+// Scan the cell-ordered points [lo, hi): four independent loads in flight per step (indices clamped to the
+// last point: a duplicate cannot change a minimum), tracking where the best point sits in `sorted`.
+template <bool FMA>
 __device__ __forceinline__ void scan_range(const float4* __restrict__ sorted, int lo, int hi, float qx, float qy, float qz,
-                                           unsigned long long& key) {
-    for (int k = lo; k < hi; ++k) {
-        const float4 p = sorted[k];
-        const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
-        float d;
-        if constexpr (FMA) d = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
-        else d = (dx * dx + dy * dy) + dz * dz;
-        const unsigned long long kk = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(unsigned)__float_as_int(p.w);
-        key = kk < key ? kk : key;
+                                           unsigned long long& key, int& kpos) {
+    for (int k = lo; k < hi; k += 4) {
+        const int k1 = min(k + 1, hi - 1), k2 = min(k + 2, hi - 1), k3 = min(k + 3, hi - 1);
+        const float4 p0 = sorted[k], p1 = sorted[k1], p2 = sorted[k2], p3 = sorted[k3];
+        const unsigned long long e0 = point_key<FMA>(p0, qx, qy, qz), e1 = point_key<FMA>(p1, qx, qy, qz),
+                                 e2 = point_key<FMA>(p2, qx, qy, qz), e3 = point_key<FMA>(p3, qx, qy, qz);
+        if (e0 < key) { key = e0; kpos = k; }
+        if (e1 < key) { key = e1; kpos = k1; }
+        if (e2 < key) { key = e2; kpos = k2; }
+        if (e3 < key) { key = e3; kpos = k3; }
     }
 }
 
-__device__ __forceinline__ unsigned long long group_min(unsigned long long k) {
+__device__ __forceinline__ void group_min(unsigned long long& k, int& kpos) {
 #pragma unroll
     for (int m = GRID_LPQ / 2; m > 0; m >>= 1) {
         const unsigned long long o = __shfl_xor(k, m, GRID_LPQ);
-        k = o < k ? o : k;
+        const int op = __shfl_xor(kpos, m, GRID_LPQ);
+        if (o < k) { k = o; kpos = op; }
     }
-    return k;
+}
+
+// ---- spatial order for the SOURCES: same cell order as the target, original index in .w ------------------
+// Sources are scattered into cell order with atomics (arbitrary order inside a cell) and then every element
+// computes its rank among the elements of its cell by original index, which makes the final order -- and
+// with it every f64 sum of the run -- independent of the atomics' arrival order.  A rigid ICP update keeps
+// neighbours neighbours, so ONE sort per registration keeps the queries of a wave / workgroup / XCD in the
+// same few cells (L1 / L2 hits instead of Infinity-Cache trips) for all iterations.
+__global__ __launch_bounds__(256) void grid_rank_fix_kernel(const float4* __restrict__ tmp, int n, GridParams gp,
+                                                            const int32_t* __restrict__ start, float4* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const float4 p = tmp[j];
+    const int cx = cell_coord(p.x, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(p.y, gp.oy, gp.inv_h, gp.gy),
+              cz = cell_coord(p.z, gp.oz, gp.inv_h, gp.gz);
+    const int c = (cz * gp.gy + cy) * gp.gx + cx;
+    const int lo = start[c], hi = start[c + 1];
+    const int me = __float_as_int(p.w);
+    int rank = 0;
+    for (int k = lo; k < hi; ++k) rank += __float_as_int(tmp[k].w) < me ? 1 : 0;
+    out[lo + rank] = p;
+}
+
+void launch_grid_sort_sources(hipStream_t st, const float4* d_src, int n, const GridParams& gp, int32_t* d_counts,
+                              int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums, float4* d_tmp, float4* d_out) {
+    launch_grid_build(st, d_src, n, gp, d_counts, d_start, d_cursor, d_block_sums, d_tmp);
+    hipLaunchKernelGGL(grid_rank_fix_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_tmp, n, gp, d_start, d_out);
 }
 
 // One launch per ICP iteration: cell search + correspondence sums + the final reduction.
@@ -219,7 +260,7 @@ template <bool FMA>
 __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const float4* __restrict__ src_in,
                                                       float4* __restrict__ src_out, int ns, GridParams gp,
                                                       const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
-                                                      const float4* __restrict__ tgt, unsigned long long* __restrict__ keys,
+                                                      unsigned long long* __restrict__ keys,
                                                       int32_t* __restrict__ list, int32_t* __restrict__ list_count,
                                                       double max_d2, double* __restrict__ partials, int32_t* __restrict__ ticket,
                                                       double* __restrict__ sums_out, int32_t* __restrict__ idx_out,
@@ -237,7 +278,17 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const 
     const int qb = (sub >= 4 && sub <= 6) ? sub - 4 : (sub >= 7 ? (sub - 7) % 3 : -1);
     double acc_a = 0.0, acc_b = 0.0;
 
-    for (int i = blockIdx.x * QPB + threadIdx.x / GRID_LPQ; i < ns; i += gridDim.x * QPB) {   // uniform per lane group
+    // XCD-aware, contiguous chunks: workgroups b and b+8 share an XCD (round-robin dispatch), so the virtual
+    // index below hands every XCD one contiguous eighth of the (spatially sorted) sources and its L2 then
+    // holds one eighth of the cell list; a different placement only changes speed, never results.
+    const int per_xcd = ((int)gridDim.x + 7) / 8;
+    const int vb = ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8;
+    const int nrounds_total = (ns + QPB - 1) / QPB;             // one "round" = QPB queries of one workgroup
+    const int rounds = (nrounds_total + 8 * per_xcd - 1) / (8 * per_xcd);
+    const int first = vb * rounds;
+    for (int rr = 0; rr < rounds; ++rr) {
+        const int i = (first + rr) * QPB + (int)threadIdx.x / GRID_LPQ;   // uniform per lane group
+        if (i >= ns) break;
         float4 p = src_in[i];
         if (ps.apply) {   // pcl transformCloud with the previous iteration's Matrix4f, as nn_sweep_kernel does
             const float x = p.x, y = p.y, z = p.z;
@@ -250,6 +301,7 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const 
         const int cx = cell_coord(qx, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(qy, gp.oy, gp.inv_h, gp.gy),
                   cz = cell_coord(qz, gp.oz, gp.inv_h, gp.gz);
         unsigned long long key = ~0ull;
+        int kpos = 0;
         bool done = false;
         // r = 1 visits the whole 3x3x3 block at once (9 rows of <= 3 cells, one lane each); r >= 2 adds shells
         for (int r = 1; r <= gp.rcap && !done; ++r) {
@@ -263,14 +315,14 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const 
                 const bool face = r == 1 || dz == -r || dz == r || dy == -r || dy == r;
                 if (face) {
                     // the whole x extent of this row is new: ONE contiguous range of the cell-ordered array
-                    scan_range<FMA>(sorted, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, key);
+                    scan_range<FMA>(sorted, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, key, kpos);
                 } else {
                     // interior row of shell r: only its two x end cells are new
-                    if (cx - r >= 0) scan_range<FMA>(sorted, cell_start[row + cx - r], cell_start[row + cx - r + 1], qx, qy, qz, key);
-                    if (cx + r < gp.gx) scan_range<FMA>(sorted, cell_start[row + cx + r], cell_start[row + cx + r + 1], qx, qy, qz, key);
+                    if (cx - r >= 0) scan_range<FMA>(sorted, cell_start[row + cx - r], cell_start[row + cx - r + 1], qx, qy, qz, key, kpos);
+                    if (cx + r < gp.gx) scan_range<FMA>(sorted, cell_start[row + cx + r], cell_start[row + cx + r + 1], qx, qy, qz, key, kpos);
                 }
             }
-            key = group_min(key);
+            group_min(key, kpos);
             const float best = __uint_as_float((unsigned)(key >> 32));
             // distance from the query to the faces of the visited block; faces on the grid border are open
             float b = __builtin_inff();
@@ -287,7 +339,7 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const 
         if (done) {
             const float d2 = __uint_as_float((unsigned)(key >> 32));
             const int idx = (int)(unsigned)(key & 0xffffffffull);
-            const float4 q = tgt[idx];   // one address per lane group
+            const float4 q = sorted[kpos];   // the winner's line was just read by a lane of this group: L1 hit
             const double dd = (double)d2;
             const bool keep = !(dd > max_d2);   // PCL: `if (distance[0] > max_dist_sqr) continue;`
             const double pv = pa == 0 ? (double)qx : pa == 1 ? (double)qy : pa == 2 ? (double)qz : 1.0;
@@ -296,8 +348,9 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const 
             acc_b += sub == 0 ? (keep ? dd : 0.0) : sub == 1 ? dd : sub == 2 ? sqrt(dd) : 0.0;
             if (sub == 0) {
                 keys[i] = key;
-                if (idx_out) idx_out[i] = idx;
-                if (d2_out) d2_out[i] = d2;
+                const int oi = __float_as_int(p.w);   // original source index (sources are in cell order)
+                if (idx_out) idx_out[oi] = idx;
+                if (d2_out) d2_out[oi] = d2;
             }
         } else if (sub == 0) {
             keys[i] = ~0ull;   // resolved by the brute-force list pass through atomicMin
@@ -347,20 +400,24 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const 
 int grid_nn_blocks(int ns) {
     const int qpb = 256 / GRID_LPQ;
     const int need = (ns + qpb - 1) / qpb;
-    return need < 1792 ? need : 1792;   // persistent: 7 workgroups per CU (106 SGPRs cap residency at 7 waves per SIMD)
+    if (const char* e = getenv("KSS_GRID_BLOCKS")) {   // tuning hook
+        const int v = atoi(e);
+        if (v > 0) return need < v ? need : v;
+    }
+    return need < 1024 ? need : 1024;   // persistent: 4 workgroups per CU (measured best of 256/512/1024/1792)
 }
 
 void launch_grid_nn(hipStream_t st, bool fma, const PairState& state, const float4* d_src_in, float4* d_src_out, int ns,
-                    const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted, const float4* d_tgt,
+                    const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted,
                     unsigned long long* d_keys, int32_t* d_list, int32_t* d_list_count, double max_d2, double* d_partials,
                     int32_t* d_ticket, double* d_sums_out, int32_t* d_idx_out, float* d_d2_out) {
     const dim3 grid(grid_nn_blocks(ns)), block(256);
     if (fma)
         hipLaunchKernelGGL(grid_nn_kernel<true>, grid, block, 0, st, state, d_src_in, d_src_out, ns, gp, d_cell_start, d_sorted,
-                           d_tgt, d_keys, d_list, d_list_count, max_d2, d_partials, d_ticket, d_sums_out, d_idx_out, d_d2_out);
+                           d_keys, d_list, d_list_count, max_d2, d_partials, d_ticket, d_sums_out, d_idx_out, d_d2_out);
     else
         hipLaunchKernelGGL(grid_nn_kernel<false>, grid, block, 0, st, state, d_src_in, d_src_out, ns, gp, d_cell_start, d_sorted,
-                           d_tgt, d_keys, d_list, d_list_count, max_d2, d_partials, d_ticket, d_sums_out, d_idx_out, d_d2_out);
+                           d_keys, d_list, d_list_count, max_d2, d_partials, d_ticket, d_sums_out, d_idx_out, d_d2_out);
 }
 
 }  // namespace kss

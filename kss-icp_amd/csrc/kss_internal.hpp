@@ -79,14 +79,16 @@ void launch_grid_bbox(hipStream_t st, const float4* d_tgt, int n, float* d_parti
 void launch_grid_build(hipStream_t st, const float4* d_tgt, int n, const GridParams& gp, int32_t* d_counts,
                        int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums, float4* d_sorted);
 void launch_grid_nn(hipStream_t st, bool fma, const PairState& state, const float4* d_src_in, float4* d_src_out, int ns,
-                    const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted, const float4* d_tgt,
+                    const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted,
                     unsigned long long* d_keys, int32_t* d_list, int32_t* d_list_count, double max_d2, double* d_partials,
                     int32_t* d_ticket, double* d_sums_out, int32_t* d_idx_out, float* d_d2_out);
 int grid_nn_blocks(int ns);
+void launch_grid_sort_sources(hipStream_t st, const float4* d_src, int n, const GridParams& gp, int32_t* d_counts,
+                              int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums, float4* d_tmp, float4* d_out);
 
 void launch_corr_reduce(hipStream_t st, const RedWork* d_work, int n_work, const PairState* d_state,
                         const float4* d_src, const float4* d_tgt4, const unsigned long long* d_keys,
-                        double max_d2, double* d_partials, int32_t* d_idx_out, float* d_d2_out);
+                        double max_d2, double* d_partials, int32_t* d_idx_out, float* d_d2_out, int index_in_w);
 // idx-driven variant for kss_cov: d2 recomputed with the reference arithmetic
 void launch_corr_reduce_idx(hipStream_t st, const float* d_src3, const float* d_tgt3, const int32_t* d_idx,
                             int64_t n, double max_d2, double* d_partials, int n_blocks);

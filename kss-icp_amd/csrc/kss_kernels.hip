@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void corr_reduce_kernel(const RedWork* __restr
                                                           const unsigned long long* __restrict__ keys,
                                                           double max_d2, double* __restrict__ partials,
                                                           int32_t* __restrict__ idx_out,
-                                                          float* __restrict__ d2_out) {
+                                                          float* __restrict__ d2_out, int index_in_w) {
     __shared__ double sh[4][NSUMS];
     const RedWork w = work[blockIdx.x];
     double acc[NSUMS];
@@ -237,8 +237,9 @@ __global__ __launch_bounds__(256) void corr_reduce_kernel(const RedWork* __restr
         const float4 p = src[w.src_begin + t];
         const float4 q = tgt[w.tgt_pair_base + idx];
         accumulate_corr(acc, p.x, p.y, p.z, q.x, q.y, q.z, d2, max_d2);
-        if (idx_out) idx_out[w.src_begin + t] = idx;
-        if (d2_out) d2_out[w.src_begin + t] = d2;
+        const int oi = index_in_w ? __float_as_int(p.w) : w.src_begin + t;   // grid mode keeps sources in cell order
+        if (idx_out) idx_out[oi] = idx;
+        if (d2_out) d2_out[oi] = d2;
     }
     const double r = block_sum<NSUMS>(acc, sh);
     if (t0 < NSUMS) partials[(int64_t)w.partial_index * NSUMS + t0] = r;
@@ -246,10 +247,10 @@ __global__ __launch_bounds__(256) void corr_reduce_kernel(const RedWork* __restr
 
 void launch_corr_reduce(hipStream_t st, const RedWork* d_work, int n_work, const PairState* d_state,
                         const float4* d_src, const float4* d_tgt4, const unsigned long long* d_keys,
-                        double max_d2, double* d_partials, int32_t* d_idx_out, float* d_d2_out) {
+                        double max_d2, double* d_partials, int32_t* d_idx_out, float* d_d2_out, int index_in_w) {
     if (n_work <= 0) return;
     hipLaunchKernelGGL(corr_reduce_kernel, dim3(n_work), dim3(256), 0, st, d_work, d_state, d_src, d_tgt4,
-                       d_keys, max_d2, d_partials, d_idx_out, d_d2_out);
+                       d_keys, max_d2, d_partials, d_idx_out, d_d2_out, index_in_w);
 }
 
 // idx-driven variant behind kss_cov(): packed float3 clouds + an index array
