@@ -281,10 +281,10 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const 
     // XCD-aware, contiguous chunks: workgroups b and b+8 share an XCD (round-robin dispatch), so the virtual
     // index below hands every XCD one contiguous eighth of the (spatially sorted) sources and its L2 then
     // holds one eighth of the cell list; a different placement only changes speed, never results.
-    const int per_xcd = ((int)gridDim.x + 7) / 8;
-    const int vb = ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8;
+    const int per_xcd = (int)gridDim.x / 8;                     // the launcher makes gridDim.x a multiple of 8
+    const int vb = ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8;   // bijection on [0, gridDim.x)
     const int nrounds_total = (ns + QPB - 1) / QPB;             // one "round" = QPB queries of one workgroup
-    const int rounds = (nrounds_total + 8 * per_xcd - 1) / (8 * per_xcd);
+    const int rounds = (nrounds_total + (int)gridDim.x - 1) / (int)gridDim.x;
     const int first = vb * rounds;
     for (int rr = 0; rr < rounds; ++rr) {
         const int i = (first + rr) * QPB + (int)threadIdx.x / GRID_LPQ;   // uniform per lane group
@@ -400,11 +400,13 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const 
 int grid_nn_blocks(int ns) {
     const int qpb = 256 / GRID_LPQ;
     const int need = (ns + qpb - 1) / qpb;
+    int cap = 1024;   // persistent: 4 workgroups per CU (measured best of 256/512/1024/1792/2048)
     if (const char* e = getenv("KSS_GRID_BLOCKS")) {   // tuning hook
         const int v = atoi(e);
-        if (v > 0) return need < v ? need : v;
+        if (v > 0) cap = v;
     }
-    return need < 1024 ? need : 1024;   // persistent: 4 workgroups per CU (measured best of 256/512/1024/1792)
+    const int nb = need < cap ? need : cap;
+    return (nb + 7) / 8 * 8;   // multiple of 8: the XCD-aware block remap in the kernel is then a bijection
 }
 
 void launch_grid_nn(hipStream_t st, bool fma, const PairState& state, const float4* d_src_in, float4* d_src_out, int ns,
