@@ -182,7 +182,7 @@ void launch_grid_build(hipStream_t st, const float4* d_tgt, int n, const GridPar
 // 4-step xor-shuffle min merges them.  A single lane per query is latency bound (a chain of ~60
 // dependent L2 loads over only 1.5 waves per SIMD at 100k queries); 16 lanes cut the chain to ~4 loads
 // and fill the machine with 16x the waves.
-constexpr int GRID_LPQ = 16;
+constexpr int GRID_LPQ_DEFAULT = 8;   // measured on C2 (100k x 100k): 4 / 8 / 16 lanes per query
 
 template <bool FMA>
 __device__ __forceinline__ unsigned long long point_key(const float4 p, float qx, float qy, float qz) {
@@ -210,11 +210,12 @@ __device__ __forceinline__ void scan_range(const float4* __restrict__ sorted, in
     }
 }
 
+template <int LPQ>
 __device__ __forceinline__ void group_min(unsigned long long& k, int& kpos) {
 #pragma unroll
-    for (int m = GRID_LPQ / 2; m > 0; m >>= 1) {
-        const unsigned long long o = __shfl_xor(k, m, GRID_LPQ);
-        const int op = __shfl_xor(kpos, m, GRID_LPQ);
+    for (int m = LPQ / 2; m > 0; m >>= 1) {
+        const unsigned long long o = __shfl_xor(k, m, LPQ);
+        const int op = __shfl_xor(kpos, m, LPQ);
         if (o < k) { k = o; kpos = op; }
     }
 }
@@ -256,7 +257,7 @@ void launch_grid_sort_sources(hipStream_t st, const float4* d_src, int n, const 
 //     at agent scope, and the workgroup barrier publishes that to the other lanes before they load.
 //   Sources the search gives up on are excluded from the sums and counted in slot 19: the host then runs the
 //   brute-force list pass + the stand-alone reduce (rare: only for sources far from the target).
-template <bool FMA>
+template <bool FMA, int LPQ>
 __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const float4* __restrict__ src_in,
                                                       float4* __restrict__ src_out, int ns, GridParams gp,
                                                       const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
@@ -268,15 +269,16 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const 
     __shared__ double sh[4][NSUMS];
     __shared__ double shg[ROWSUM_GROUPS][NSUMS];
     __shared__ int s_last;
-    const int sub = threadIdx.x % GRID_LPQ;   // ps travels as a kernel argument: no per-iteration upload
-    constexpr int QPB = 256 / GRID_LPQ;
-    // The 20 correspondence sums are spread over the 16 lanes of a query group: lane `sub` owns sums[sub] and,
-    // for sub < 4, sums[16 + sub] -- two f64 accumulators per lane instead of twenty (register pressure
-    // decides how many waves hide the L2 latency of the search).  sums[c] = keep * pv * qv with pv in
-    // {1, px, py, pz} and qv in {1, qx, qy, qz}: c = 0 count, 1..3 src, 4..6 tgt, 7..15 src_i * tgt_j.
-    const int pa = (sub >= 1 && sub <= 3) ? sub - 1 : (sub >= 7 ? (sub - 7) / 3 : -1);
-    const int qb = (sub >= 4 && sub <= 6) ? sub - 4 : (sub >= 7 ? (sub - 7) % 3 : -1);
-    double acc_a = 0.0, acc_b = 0.0;
+    const int sub = threadIdx.x % LPQ;   // ps travels as a kernel argument: no per-iteration upload
+    constexpr int QPB = 256 / LPQ;
+    // The 20 correspondence sums are spread over the LPQ lanes of a query group: lane `sub` owns sums[sub + j*LPQ]
+    // (NACC accumulators per lane instead of twenty: register pressure decides how many waves hide the
+    // latency of the search).  sums[c] = keep * pv * qv with pv in {1, px, py, pz}, qv in {1, qx, qy, qz}
+    // for c < 16 (0 count, 1..3 src, 4..6 tgt, 7..15 src_i * tgt_j); 16 = d2 kept, 17 = d2, 18 = sqrt(d2).
+    constexpr int NACC = (NSUMS + LPQ - 1) / LPQ;
+    double acc[NACC];
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) acc[j] = 0.0;
 
     // XCD-aware, contiguous chunks: workgroups b and b+8 share an XCD (round-robin dispatch), so the virtual
     // index below hands every XCD one contiguous eighth of the (spatially sorted) sources and its L2 then
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const 
     const int rounds = (nrounds_total + (int)gridDim.x - 1) / (int)gridDim.x;
     const int first = vb * rounds;
     for (int rr = 0; rr < rounds; ++rr) {
-        const int i = (first + rr) * QPB + (int)threadIdx.x / GRID_LPQ;   // uniform per lane group
+        const int i = (first + rr) * QPB + (int)threadIdx.x / LPQ;   // uniform per lane group
         if (i >= ns) break;
         float4 p = src_in[i];
         if (ps.apply) {   // pcl transformCloud with the previous iteration's Matrix4f, as nn_sweep_kernel does
@@ -303,26 +305,38 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const 
         unsigned long long key = ~0ull;
         int kpos = 0;
         bool done = false;
-        // r = 1 visits the whole 3x3x3 block at once (9 rows of <= 3 cells, one lane each); r >= 2 adds shells
-        for (int r = 1; r <= gp.rcap && !done; ++r) {
-            const int w = 2 * r + 1;
-            const int x0 = max(cx - r, 0), x1 = min(cx + r, gp.gx - 1);
-            for (int t = sub; t < w * w; t += GRID_LPQ) {
-                const int dz = t / w - r, dy = t % w - r;
-                const int z = cz + dz, y = cy + dy;
-                if (z < 0 || z >= gp.gz || y < 0 || y >= gp.gy) continue;
-                const int row = (z * gp.gy + y) * gp.gx;
-                const bool face = r == 1 || dz == -r || dz == r || dy == -r || dy == r;
-                if (face) {
-                    // the whole x extent of this row is new: ONE contiguous range of the cell-ordered array
+        // ---- r = 1: the whole 3x3x3 block, 9 rows of <= 3 cells each, every row ONE contiguous range ----
+        {
+            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, gp.gx - 1);
+#pragma unroll
+            for (int t = sub; t < 9; t += LPQ) {
+                const int z = cz + t / 3 - 1, y = cy + t % 3 - 1;
+                if (z >= 0 && z < gp.gz && y >= 0 && y < gp.gy) {
+                    const int row = (z * gp.gy + y) * gp.gx;
                     scan_range<FMA>(sorted, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, key, kpos);
-                } else {
-                    // interior row of shell r: only its two x end cells are new
-                    if (cx - r >= 0) scan_range<FMA>(sorted, cell_start[row + cx - r], cell_start[row + cx - r + 1], qx, qy, qz, key, kpos);
-                    if (cx + r < gp.gx) scan_range<FMA>(sorted, cell_start[row + cx + r], cell_start[row + cx + r + 1], qx, qy, qz, key, kpos);
                 }
             }
-            group_min(key, kpos);
+        }
+        for (int r = 1; r <= gp.rcap; ++r) {
+            if (r > 1) {   // shell r: its (2r+1)^2 rows are dealt round-robin to the lanes
+                const int w = 2 * r + 1;
+                const int x0 = max(cx - r, 0), x1 = min(cx + r, gp.gx - 1);
+                for (int t = sub; t < w * w; t += LPQ) {
+                    const int dz = t / w - r, dy = t % w - r;
+                    const int z = cz + dz, y = cy + dy;
+                    if (z < 0 || z >= gp.gz || y < 0 || y >= gp.gy) continue;
+                    const int row = (z * gp.gy + y) * gp.gx;
+                    if (dz == -r || dz == r || dy == -r || dy == r) {
+                        // a row on the shell's y/z faces: the whole x extent is new
+                        scan_range<FMA>(sorted, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, key, kpos);
+                    } else {
+                        // interior row of shell r: only its two x end cells are new
+                        if (cx - r >= 0) scan_range<FMA>(sorted, cell_start[row + cx - r], cell_start[row + cx - r + 1], qx, qy, qz, key, kpos);
+                        if (cx + r < gp.gx) scan_range<FMA>(sorted, cell_start[row + cx + r], cell_start[row + cx + r + 1], qx, qy, qz, key, kpos);
+                    }
+                }
+            }
+            group_min<LPQ>(key, kpos);
             const float best = __uint_as_float((unsigned)(key >> 32));
             // distance from the query to the faces of the visited block; faces on the grid border are open
             float b = __builtin_inff();
@@ -335,6 +349,7 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const 
             const float bs = b - gp.eps;
             if (b == __builtin_inff()) done = key != ~0ull;                 // the whole grid has been visited
             else if (bs > 0.f && best < bs * bs * 0.999999f) done = true;   // every unvisited point is strictly farther
+            if (done) break;
         }
         if (done) {
             const float d2 = __uint_as_float((unsigned)(key >> 32));
@@ -342,10 +357,21 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const 
             const float4 q = sorted[kpos];   // the winner's line was just read by a lane of this group: L1 hit
             const double dd = (double)d2;
             const bool keep = !(dd > max_d2);   // PCL: `if (distance[0] > max_dist_sqr) continue;`
-            const double pv = pa == 0 ? (double)qx : pa == 1 ? (double)qy : pa == 2 ? (double)qz : 1.0;
-            const double qv = qb == 0 ? (double)q.x : qb == 1 ? (double)q.y : qb == 2 ? (double)q.z : 1.0;
-            acc_a += keep ? pv * qv : 0.0;
-            acc_b += sub == 0 ? (keep ? dd : 0.0) : sub == 1 ? dd : sub == 2 ? sqrt(dd) : 0.0;
+#pragma unroll
+            for (int j = 0; j < NACC; ++j) {
+                const int c = sub + j * LPQ;   // the component this lane owns in slot j
+                const int pa = (c >= 1 && c <= 3) ? c - 1 : ((c >= 7 && c <= 15) ? (c - 7) / 3 : -1);
+                const int qb = (c >= 4 && c <= 6) ? c - 4 : ((c >= 7 && c <= 15) ? (c - 7) % 3 : -1);
+                const double pv = pa == 0 ? (double)qx : pa == 1 ? (double)qy : pa == 2 ? (double)qz : 1.0;
+                const double qv = qb == 0 ? (double)q.x : qb == 1 ? (double)q.y : qb == 2 ? (double)q.z : 1.0;
+                double v;
+                if (c < 16) v = keep ? pv * qv : 0.0;
+                else if (c == 16) v = keep ? dd : 0.0;
+                else if (c == 17) v = dd;
+                else if (c == 18) v = sqrt(dd);
+                else v = 0.0;
+                acc[j] += v;
+            }
             if (sub == 0) {
                 keys[i] = key;
                 const int oi = __float_as_int(p.w);   // original source index (sources are in cell order)
@@ -360,15 +386,19 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const 
     }
 
     // ---- workgroup partial row, then the last workgroup finishes the job ----
-    // the 4 query groups of a wave hold the same component in lanes of equal `sub`
-    acc_a += __shfl_xor(acc_a, 16, 64);
-    acc_a += __shfl_xor(acc_a, 32, 64);
-    acc_b += __shfl_xor(acc_b, 16, 64);
-    acc_b += __shfl_xor(acc_b, 32, 64);
+    // lanes of equal `sub` in the wave's 64/LPQ query groups hold the same components
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) {
+#pragma unroll
+        for (int m = LPQ; m < 64; m <<= 1) acc[j] += __shfl_xor(acc[j], m, 64);
+    }
     {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        if (lane < 16) sh[wave][lane] = acc_a;
-        if (lane < 4) sh[wave][16 + lane] = acc_b;
+        if (lane < LPQ) {
+#pragma unroll
+            for (int j = 0; j < NACC; ++j)
+                if (lane + j * LPQ < NSUMS) sh[wave][lane + j * LPQ] = acc[j];
+        }
     }
     __syncthreads();
     if (threadIdx.x < NSUMS) {
@@ -397,8 +427,17 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const 
     if (threadIdx.x == 0) *ticket = 0;   // re-arm for the next launch (stream order makes it visible)
 }
 
+static int grid_lpq() {
+    int lpq = GRID_LPQ_DEFAULT;
+    if (const char* e = getenv("KSS_GRID_LPQ")) {   // tuning hook
+        const int v = atoi(e);
+        if (v == 4 || v == 8 || v == 16) lpq = v;
+    }
+    return lpq;
+}
+
 int grid_nn_blocks(int ns) {
-    const int qpb = 256 / GRID_LPQ;
+    const int qpb = 256 / grid_lpq();
     const int need = (ns + qpb - 1) / qpb;
     int cap = 1024;   // persistent: 4 workgroups per CU (measured best of 256/512/1024/1792/2048)
     if (const char* e = getenv("KSS_GRID_BLOCKS")) {   // tuning hook
@@ -414,12 +453,16 @@ void launch_grid_nn(hipStream_t st, bool fma, const PairState& state, const floa
                     unsigned long long* d_keys, int32_t* d_list, int32_t* d_list_count, double max_d2, double* d_partials,
                     int32_t* d_ticket, double* d_sums_out, int32_t* d_idx_out, float* d_d2_out) {
     const dim3 grid(grid_nn_blocks(ns)), block(256);
-    if (fma)
-        hipLaunchKernelGGL(grid_nn_kernel<true>, grid, block, 0, st, state, d_src_in, d_src_out, ns, gp, d_cell_start, d_sorted,
-                           d_keys, d_list, d_list_count, max_d2, d_partials, d_ticket, d_sums_out, d_idx_out, d_d2_out);
-    else
-        hipLaunchKernelGGL(grid_nn_kernel<false>, grid, block, 0, st, state, d_src_in, d_src_out, ns, gp, d_cell_start, d_sorted,
-                           d_keys, d_list, d_list_count, max_d2, d_partials, d_ticket, d_sums_out, d_idx_out, d_d2_out);
+    const int lpq = grid_lpq();
+#define KSS_GRID_LAUNCH(FV, LV)                                                                                       \
+    hipLaunchKernelGGL((grid_nn_kernel<FV, LV>), grid, block, 0, st, state, d_src_in, d_src_out, ns, gp, d_cell_start, \
+                       d_sorted, d_keys, d_list, d_list_count, max_d2, d_partials, d_ticket, d_sums_out, d_idx_out, d_d2_out)
+    if (fma) {
+        if (lpq == 4) KSS_GRID_LAUNCH(true, 4); else if (lpq == 16) KSS_GRID_LAUNCH(true, 16); else KSS_GRID_LAUNCH(true, 8);
+    } else {
+        if (lpq == 4) KSS_GRID_LAUNCH(false, 4); else if (lpq == 16) KSS_GRID_LAUNCH(false, 16); else KSS_GRID_LAUNCH(false, 8);
+    }
+#undef KSS_GRID_LAUNCH
 }
 
 }  // namespace kss
