@@ -417,7 +417,9 @@ int grid_setup(kss_ctx* c, IcpPlan& pl) {
     const float emax = std::max(ext[0], std::max(ext[1], ext[2]));
     GridParams gp;
     // cell edge: ~3 points per occupied cell if the target is a surface (area ~ emax^2 * few)
-    float h = emax * 1.5f * std::sqrt(3.0f / (float)nt);
+    float hscale = 2.0f;
+    if (const char* e = getenv("KSS_GRID_HSCALE")) { const float v = (float)atof(e); if (v > 0.05f && v < 50.f) hscale = v; }   // tuning hook
+    float h = emax * hscale * std::sqrt(3.0f / (float)nt);
     h = std::max(h, emax / 255.5f);
     if (!(h > 0.f)) h = 1.f;   // all targets coincide
     gp.ox = mn[0]; gp.oy = mn[1]; gp.oz = mn[2];

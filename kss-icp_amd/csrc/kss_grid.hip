@@ -182,7 +182,8 @@ void launch_grid_build(hipStream_t st, const float4* d_tgt, int n, const GridPar
 // 4-step xor-shuffle min merges them.  A single lane per query is latency bound (a chain of ~60
 // dependent L2 loads over only 1.5 waves per SIMD at 100k queries); 16 lanes cut the chain to ~4 loads
 // and fill the machine with 16x the waves.
-constexpr int GRID_LPQ_DEFAULT = 8;   // measured on C2 (100k x 100k): 4 / 8 / 16 lanes per query
+constexpr int GRID_LPQ_DEFAULT = 1;   // lanes per query; measured on C2 (100k x 100k): 1 / 2 / 4 / 8 / 16
+constexpr int GRID_BS_DEFAULT = 512;  // workgroup size
 
 template <bool FMA>
 __device__ __forceinline__ unsigned long long point_key(const float4 p, float qx, float qy, float qz) {
@@ -257,8 +258,8 @@ void launch_grid_sort_sources(hipStream_t st, const float4* d_src, int n, const 
 //     at agent scope, and the workgroup barrier publishes that to the other lanes before they load.
 //   Sources the search gives up on are excluded from the sums and counted in slot 19: the host then runs the
 //   brute-force list pass + the stand-alone reduce (rare: only for sources far from the target).
-template <bool FMA, int LPQ>
-__global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const float4* __restrict__ src_in,
+template <bool FMA, int LPQ, int BS>
+__global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const float4* __restrict__ src_in,
                                                       float4* __restrict__ src_out, int ns, GridParams gp,
                                                       const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
                                                       unsigned long long* __restrict__ keys,
@@ -266,11 +267,11 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const 
                                                       double max_d2, double* __restrict__ partials, int32_t* __restrict__ ticket,
                                                       double* __restrict__ sums_out, int32_t* __restrict__ idx_out,
                                                       float* __restrict__ d2_out) {
-    __shared__ double sh[4][NSUMS];
+    __shared__ double sh[BS / 64][NSUMS];
     __shared__ double shg[ROWSUM_GROUPS][NSUMS];
     __shared__ int s_last;
     const int sub = threadIdx.x % LPQ;   // ps travels as a kernel argument: no per-iteration upload
-    constexpr int QPB = 256 / LPQ;
+    constexpr int QPB = BS / LPQ;
     // The 20 correspondence sums are spread over the LPQ lanes of a query group: lane `sub` owns sums[sub + j*LPQ]
     // (NACC accumulators per lane instead of twenty: register pressure decides how many waves hide the
     // latency of the search).  sums[c] = keep * pv * qv with pv in {1, px, py, pz}, qv in {1, qx, qy, qz}
@@ -286,8 +287,9 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const 
     const int per_xcd = (int)gridDim.x / 8;                     // the launcher makes gridDim.x a multiple of 8
     const int vb = ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8;   // bijection on [0, gridDim.x)
     const int nrounds_total = (ns + QPB - 1) / QPB;             // one "round" = QPB queries of one workgroup
-    const int rounds = (nrounds_total + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int first = vb * rounds;
+    const int base = nrounds_total / (int)gridDim.x, rem = nrounds_total % (int)gridDim.x;
+    const int rounds = base + (vb < rem ? 1 : 0);               // balanced: the first `rem` chunks are one longer
+    const int first = vb * base + min(vb, rem);
     for (int rr = 0; rr < rounds; ++rr) {
         const int i = (first + rr) * QPB + (int)threadIdx.x / LPQ;   // uniform per lane group
         if (i >= ns) break;
@@ -402,7 +404,9 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const 
     }
     __syncthreads();
     if (threadIdx.x < NSUMS) {
-        const double r = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
+        double r = 0.0;
+#pragma unroll
+        for (int w = 0; w < BS / 64; ++w) r += sh[w][threadIdx.x];   // wave order: reproducible
         partials[(int64_t)blockIdx.x * NSUMS + threadIdx.x] = r;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -427,42 +431,63 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const PairState ps, const 
     if (threadIdx.x == 0) *ticket = 0;   // re-arm for the next launch (stream order makes it visible)
 }
 
-static int grid_lpq() {
-    int lpq = GRID_LPQ_DEFAULT;
-    if (const char* e = getenv("KSS_GRID_LPQ")) {   // tuning hook
+static int env_int(const char* name, int dflt) {
+    if (const char* e = getenv(name)) {
         const int v = atoi(e);
-        if (v == 4 || v == 8 || v == 16) lpq = v;
+        if (v > 0) return v;
     }
-    return lpq;
+    return dflt;
 }
+// tuning hooks (defaults measured on C2, 100k x 100k; profiles/): lanes per query, workgroup size, workgroup cap
+static int grid_lpq() { const int v = env_int("KSS_GRID_LPQ", GRID_LPQ_DEFAULT); return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? v : GRID_LPQ_DEFAULT; }
+static int grid_bs() { const int v = env_int("KSS_GRID_BS", GRID_BS_DEFAULT); return (v == 256 || v == 512 || v == 1024) ? v : GRID_BS_DEFAULT; }
 
 int grid_nn_blocks(int ns) {
-    const int qpb = 256 / grid_lpq();
+    const int qpb = grid_bs() / grid_lpq();
     const int need = (ns + qpb - 1) / qpb;
-    int cap = 1024;   // persistent: 4 workgroups per CU (measured best of 256/512/1024/1792/2048)
-    if (const char* e = getenv("KSS_GRID_BLOCKS")) {   // tuning hook
-        const int v = atoi(e);
-        if (v > 0) cap = v;
-    }
+    const int cap = env_int("KSS_GRID_BLOCKS", 131072 / grid_bs());   // one 512-lane workgroup per CU
     const int nb = need < cap ? need : cap;
     return (nb + 7) / 8 * 8;   // multiple of 8: the XCD-aware block remap in the kernel is then a bijection
+}
+
+template <bool FMA, int LPQ>
+static void grid_launch_bs(hipStream_t st, int bs, dim3 grid, const PairState& state, const float4* d_src_in, float4* d_src_out, int ns,
+                           const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted, unsigned long long* d_keys,
+                           int32_t* d_list, int32_t* d_list_count, double max_d2, double* d_partials, int32_t* d_ticket,
+                           double* d_sums_out, int32_t* d_idx_out, float* d_d2_out) {
+#define KSS_GRID_LAUNCH(BV)                                                                                                  \
+    hipLaunchKernelGGL((grid_nn_kernel<FMA, LPQ, BV>), grid, dim3(BV), 0, st, state, d_src_in, d_src_out, ns, gp, d_cell_start, \
+                       d_sorted, d_keys, d_list, d_list_count, max_d2, d_partials, d_ticket, d_sums_out, d_idx_out, d_d2_out)
+    if (bs == 1024) KSS_GRID_LAUNCH(1024); else if (bs == 512) KSS_GRID_LAUNCH(512); else KSS_GRID_LAUNCH(256);
+#undef KSS_GRID_LAUNCH
 }
 
 void launch_grid_nn(hipStream_t st, bool fma, const PairState& state, const float4* d_src_in, float4* d_src_out, int ns,
                     const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted,
                     unsigned long long* d_keys, int32_t* d_list, int32_t* d_list_count, double max_d2, double* d_partials,
                     int32_t* d_ticket, double* d_sums_out, int32_t* d_idx_out, float* d_d2_out) {
-    const dim3 grid(grid_nn_blocks(ns)), block(256);
-    const int lpq = grid_lpq();
-#define KSS_GRID_LAUNCH(FV, LV)                                                                                       \
-    hipLaunchKernelGGL((grid_nn_kernel<FV, LV>), grid, block, 0, st, state, d_src_in, d_src_out, ns, gp, d_cell_start, \
-                       d_sorted, d_keys, d_list, d_list_count, max_d2, d_partials, d_ticket, d_sums_out, d_idx_out, d_d2_out)
+    const dim3 grid(grid_nn_blocks(ns));
+    const int lpq = grid_lpq(), bs = grid_bs();
+#define KSS_GRID_ARGS st, bs, grid, state, d_src_in, d_src_out, ns, gp, d_cell_start, d_sorted, d_keys, d_list, d_list_count, max_d2, \
+                      d_partials, d_ticket, d_sums_out, d_idx_out, d_d2_out
     if (fma) {
-        if (lpq == 4) KSS_GRID_LAUNCH(true, 4); else if (lpq == 16) KSS_GRID_LAUNCH(true, 16); else KSS_GRID_LAUNCH(true, 8);
+        switch (lpq) {
+            case 1: grid_launch_bs<true, 1>(KSS_GRID_ARGS); break;
+            case 2: grid_launch_bs<true, 2>(KSS_GRID_ARGS); break;
+            case 4: grid_launch_bs<true, 4>(KSS_GRID_ARGS); break;
+            case 16: grid_launch_bs<true, 16>(KSS_GRID_ARGS); break;
+            default: grid_launch_bs<true, 8>(KSS_GRID_ARGS); break;
+        }
     } else {
-        if (lpq == 4) KSS_GRID_LAUNCH(false, 4); else if (lpq == 16) KSS_GRID_LAUNCH(false, 16); else KSS_GRID_LAUNCH(false, 8);
+        switch (lpq) {
+            case 1: grid_launch_bs<false, 1>(KSS_GRID_ARGS); break;
+            case 2: grid_launch_bs<false, 2>(KSS_GRID_ARGS); break;
+            case 4: grid_launch_bs<false, 4>(KSS_GRID_ARGS); break;
+            case 16: grid_launch_bs<false, 16>(KSS_GRID_ARGS); break;
+            default: grid_launch_bs<false, 8>(KSS_GRID_ARGS); break;
+        }
     }
-#undef KSS_GRID_LAUNCH
+#undef KSS_GRID_ARGS
 }
 
 }  // namespace kss
