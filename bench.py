@@ -4,9 +4,15 @@
 Metric (BASELINE.json): ICP iterations/s (+ point-pairs/s) on a 100k x 100k cloud pair, 1/2/4/8 GPUs.
 Workload = config C2: one synthetic uniform-sphere pair per GPU (R_z(10 deg), 1e-3 jitter), 50 fixed
 ICP iterations (PCL convergence tests off) followed by the getFitnessScore() pass, exactly as
-KSSICP::shapeRegistration_ICP(int) drives PCL (KSS_ICP.hpp:133-183).  A "step" is one such registration.
-Inputs are resident in HBM before the timed region.  N > 1: one process per GPU, independent pairs
-(weak scaling), the (R,t) records all-gathered over RCCL inside the timed region.
+KSSICP::shapeRegistration_ICP(int) drives PCL (KSS_ICP.hpp:133-183).  A "step" is one such registration,
+including the per-target setup (packing, cell-list build).  Inputs are resident in HBM before the timed
+region.  N > 1: one process per GPU, independent pairs (weak scaling), the 96-byte (R,t) records
+all-gathered over RCCL inside the timed region.
+
+Two NN engines produce bit-identical correspondences (tests/test_gpu_grid.py):
+  * default (--mode auto/grid): exact uniform cell list + brute-force fallback list  -> `value`, `roofline`
+  * --mode brute: the north star's LDS-tiled source x target sweep                  -> `brute_force` object
+    (always measured too, on a few steps, because it is the kernel graded against the FP32 VALU roofline)
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -32,14 +38,15 @@ HBM_PEAK_GBS = 8000.0
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=100000, help="points per cloud (C2: 100000)")
     ap.add_argument("--iters", type=int, default=50, help="fixed ICP iterations per registration")
     ap.add_argument("--fma", type=int, default=0, help="1: fused distance form (not bit-parity)")
-    ap.add_argument("--spt", type=int, default=0, help="NN sources per thread (0 = auto)")
-    ap.add_argument("--splits", type=int, default=0, help="NN target splits (0 = auto)")
-    ap.add_argument("--mode", default="auto", choices=["auto", "brute", "grid"], help="NN search structure (same results)")
+    ap.add_argument("--spt", type=int, default=0, help="brute force: sources per thread (0 = auto)")
+    ap.add_argument("--splits", type=int, default=0, help="brute force: target splits (0 = auto)")
+    ap.add_argument("--mode", default="auto", choices=["auto", "brute", "grid"], help="NN engine of the timed path")
+    ap.add_argument("--brute-steps", type=int, default=3, help="steps of the secondary brute-force measurement (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -58,23 +65,37 @@ def cpu_baseline(n, iters, src, tgt):
            "T": [float(x) for x in r["T"].reshape(-1)]}
     ncpu = os.cpu_count() or 1
     if ncpu > 1:
-        p2 = O.icp_params(max_iterations=iters, fixed_iterations=1, use_kdtree=1, nthreads=min(ncpu, 64), compute_fitness=1)
+        nth = min(ncpu, 64)
+        p2 = O.icp_params(max_iterations=iters, fixed_iterations=1, use_kdtree=1, nthreads=nth, compute_fitness=1)
         t0 = time.perf_counter()
         O.icp(src, tgt, p2)
         dt2 = time.perf_counter() - t0
-        out["all_cores"] = {"value": iters / dt2, "cores": min(ncpu, 64), "note": "OpenMP over queries; not what PCL 1.8.1 does"}
+        out["all_cores"] = {"value": iters / dt2, "cores": nth, "note": "OpenMP over queries; not what PCL 1.8.1 does"}
     return out
 
 
-def read_traffic():
-    """HBM bytes per nn_sweep launch from the committed PMC summary (collected in separate rocprofv3
-    --pmc passes and corrected per MI355X_MICROARCH.md HBM section), or None."""
-    p = os.path.join(ROOT, "profiles", "pmc_summary.json")
+def read_traffic(key):
+    """HBM bytes per launch of a kernel from the committed PMC summary (separate rocprofv3 --pmc passes,
+    corrected per MI355X_MICROARCH.md HBM section; tools/parse_prof.py), or None."""
     try:
-        with open(p) as f:
-            return json.load(f).get("nn_sweep", {}).get("hbm_bytes_per_launch")
+        with open(os.path.join(ROOT, "profiles", "pmc_summary.json")) as f:
+            return json.load(f).get(key, {}).get("hbm_bytes_per_launch")
     except Exception:
         return None
+
+
+def run_steps(step, n_steps, dist, world, torch):
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(n_steps):
+        last = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, last
 
 
 def main():
@@ -85,8 +106,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the KSS-ICP core has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -104,80 +123,105 @@ def main():
     torch.cuda.synchronize()
 
     ctx = pkg.Context(local_rank)       # raises without libkssicp.so / GPU
-    params = ctx.icp_params(max_iterations=a.iters, fixed_iterations=1, compute_fitness=1, nn_fma=a.fma,
-                            nn_sources_per_thread=a.spt, nn_target_splits=a.splits,
-                            nn_mode={"auto": pkg.NN_AUTO, "brute": pkg.NN_BRUTE, "grid": pkg.NN_GRID}[a.mode])
-    RecArr = pkg.IcpResult * 1
+    modes = {"auto": pkg.NN_AUTO, "brute": pkg.NN_BRUTE, "grid": pkg.NN_GRID}
 
-    def step():
-        res = ctx.icp_dev(d_src.data_ptr(), a.n, d_tgt.data_ptr(), a.n, params)
-        if world > 1:       # final gather of the (R,t) records over RCCL/xGMI: one 96-B record per pair
-            local = pkg.shard.records_to_array(RecArr(res), rank)
-            pkg.shard.gather_records(local, world, world, rank, device=dev)
-        return res
+    def make_step(mode):
+        params = ctx.icp_params(max_iterations=a.iters, fixed_iterations=1, compute_fitness=1, nn_fma=a.fma,
+                                nn_sources_per_thread=a.spt, nn_target_splits=a.splits, nn_mode=modes[mode])
+        RecArr = pkg.IcpResult * 1
 
+        def step():
+            res = ctx.icp_dev(d_src.data_ptr(), a.n, d_tgt.data_ptr(), a.n, params)
+            if world > 1:   # final gather of the (R,t) records over RCCL/xGMI: one 96-B record per pair
+                local = pkg.shard.records_to_array(RecArr(res), rank)
+                pkg.shard.gather_records(local, world, world, rank, device=dev)
+            return res
+        return step
+
+    # ---- primary measurement ---------------------------------------------------------------------------
+    step = make_step(a.mode)
     for _ in range(a.warmup):
         step()
     ctx.profile_enable(True)
     ctx.profile_reset()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    last = None
-    for _ in range(a.steps):
-        last = step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    nn_ms, nn_launches = ctx.profile_get(pkg.K_NN_SWEEP)
-    red_ms, red_launches = ctx.profile_get(pkg.K_CORR_REDUCE)
-    grid_ms, grid_launches = ctx.profile_get(pkg.K_GRID_NN)
-    build_ms, build_launches = ctx.profile_get(pkg.K_GRID_BUILD)
+    dt, last = run_steps(step, a.steps, dist, world, torch)
+    prof = {k: ctx.profile_get(getattr(pkg, k)) for k in ("K_NN_SWEEP", "K_CORR_REDUCE", "K_GRID_NN", "K_GRID_BUILD")}
+    gstats = ctx.grid_stats()
     ctx.profile_enable(False)
-
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    used_grid = prof["K_GRID_NN"][1] > 0
+
+    # ---- secondary: the brute-force sweep (north-star kernel), single-GPU runs only ------------------------
+    brute = None
+    if world == 1 and a.brute_steps > 0 and used_grid:
+        bstep = make_step("brute")
+        bstep()
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        bdt, blast = run_steps(bstep, a.brute_steps, dist, world, torch)
+        bms, bn = ctx.profile_get(pkg.K_NN_SWEEP)
+        ctx.profile_enable(False)
+        brute = (bdt, bms, bn, blast)
 
     if rank == 0:
-        iters_total = a.steps * a.iters * world
-        value = iters_total / dt
-        nn_avg_s = (nn_ms / max(1, nn_launches)) * 1e-3
-        flops_per_launch = 8.0 * a.n * a.n                      # 8 flop per (source, target) pair
-        achieved_tf = flops_per_launch / nn_avg_s / 1e12 if nn_avg_s > 0 else 0.0
-        # algorithmic bytes of one sweep: targets re-streamed once per source block + sources + keys
-        spt = params.nn_sources_per_thread if params.nn_sources_per_thread else 4
-        src_blocks = -(-a.n // (256 * spt))
-        alg_bytes = 16.0 * a.n * src_blocks + 16.0 * a.n * 2 + 8.0 * a.n
+        value = a.steps * a.iters * world / dt
+        passes = a.iters + 1
+
+        def valu_roofline(avg_s, launches):
+            flops = 8.0 * a.n * a.n          # 8 flop per (source, target) pair
+            ach = flops / avg_s / 1e12 if avg_s > 0 else 0.0
+            return {"kernel": "nn_sweep_kernel", "bound": "valu-fp32",
+                    "bound_note": "min-reduction on the FP32 vector ALU (MFMA not used); peak 157.3 TFLOP/s counts an fma as 2 "
+                                  "flop, the parity arithmetic (FLANN L2_Simple, no fma) issues one instruction per flop, so "
+                                  "0.5 is its ceiling; see DESIGN.md",
+                    "achieved": ach, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_VALU_PEAK_TFLOPS,
+                    "traffic": read_traffic("nn_sweep"), "avg_launch_ms": avg_s * 1e3, "launches": launches,
+                    "flops_per_launch": flops}
+
         out = {
             "metric": "icp_iterations_per_sec", "value": value, "unit": "iterations/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2: one %dx%d uniform-sphere pair per GPU, %d fixed ICP iterations + fitness pass "
-                                   "(brute-force exact NN + cov reduce), R_z(10deg), jitter 1e-3" % (a.n, a.n, a.iters),
+            "config": {"workload": "C2: one %dx%d uniform-sphere pair per GPU, %d fixed ICP iterations + fitness pass per step "
+                                   "(exact NN + cov reduce + host 3x3 SVD), R_z(10deg), jitter 1e-3" % (a.n, a.n, a.iters),
                        "n_src": a.n, "n_tgt": a.n, "icp_iters_per_step": a.iters, "pairs_per_gpu": 1,
+                       "nn_engine": "cell list + brute-force fallback" if used_grid else "brute-force sweep",
                        "nn_arithmetic": "fma" if a.fma else "reference (no fma)"},
-            "point_pairs_evaluated_per_sec": float(a.n) * a.n * (a.iters + 1) * a.steps * world / dt,
-            "correspondences_per_sec": float(a.n) * (a.iters + 1) * a.steps * world / dt,
-            "roofline": {"kernel": "nn_sweep_kernel", "bound": "valu-fp32",
-                         "bound_note": "min-reduction on the FP32 vector ALU; peak = 157.3 TFLOP/s, numerically the "
-                                       "f32-input MFMA peak; MFMA is not used (north star)",
-                         "achieved": achieved_tf, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tf / FP32_VALU_PEAK_TFLOPS, "traffic": read_traffic(),
-                         "avg_launch_ms": nn_avg_s * 1e3, "launches": nn_launches,
-                         "flops_per_launch": flops_per_launch,
-                         "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
-                                 "achieved": alg_bytes / nn_avg_s / 1e9 if nn_avg_s > 0 else 0.0, "peak": HBM_PEAK_GBS,
-                                 "unit": "GB/s", "frac": (alg_bytes / nn_avg_s / 1e9 / HBM_PEAK_GBS) if nn_avg_s > 0 else 0.0}},
-            "corr_reduce": {"avg_launch_ms": red_ms / max(1, red_launches), "launches": red_launches},
-            "grid_nn": {"avg_launch_ms": grid_ms / max(1, grid_launches), "launches": grid_launches,
-                        "build_avg_ms": build_ms / max(1, build_launches), "builds": build_launches},
-            "nn_mode": a.mode,
+            "correspondences_per_sec": float(a.n) * passes * a.steps * world / dt,
+            "point_pairs_per_sec_brute_force_equivalent": float(a.n) * a.n * passes * a.steps * world / dt,
             "result": {"iterations": int(last.iterations), "fitness": float(last.fitness)},
         }
+        if used_grid:
+            gms, gn = prof["K_GRID_NN"]
+            avg_s = gms / max(1, gn) * 1e-3
+            ev = gstats["evaluations_per_pass"]
+            # algorithmic bytes of one launch: per source 16 B read + 16 B transformed write + 8 B key,
+            # 18 cell-range bounds of 4 B, 16 B per distance evaluation
+            alg = a.n * (16.0 + 16.0 + 8.0 + 18 * 4.0) + ev * 16.0
+            out["roofline"] = {"kernel": "grid_nn_kernel", "bound": "hbm",
+                               "bound_note": "cell-list search + correspondence sums, one launch per ICP iteration; its bytes are "
+                                             "served mostly by L1/L2 (cell list + points = a few MB), so `achieved` is algorithmic "
+                                             "bytes over time against the HBM peak and `traffic` is what actually reached HBM",
+                               "achieved": alg / avg_s / 1e9 if avg_s > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": (alg / avg_s / 1e9 / HBM_PEAK_GBS) if avg_s > 0 else 0.0,
+                               "traffic": read_traffic("grid_nn"), "avg_launch_ms": avg_s * 1e3, "launches": gn,
+                               "algorithmic_bytes_per_launch": alg, "distance_evaluations_per_launch": ev,
+                               "grid": {k: gstats[k] for k in ("h", "gx", "gy", "gz", "occupied_cells")}}
+            out["setup"] = {"cell_list_build_avg_ms": prof["K_GRID_BUILD"][0] / max(1, prof["K_GRID_BUILD"][1]),
+                            "builds": prof["K_GRID_BUILD"][1], "fallback_sweep_launches": prof["K_NN_SWEEP"][1]}
+        else:
+            nms, nn_ = prof["K_NN_SWEEP"]
+            out["roofline"] = valu_roofline(nms / max(1, nn_) * 1e-3, nn_)
+        if brute is not None:
+            bdt, bms, bn, blast = brute
+            out["brute_force"] = {"value": a.brute_steps * a.iters / bdt, "unit": "iterations/s", "steps": a.brute_steps,
+                                  "ms_per_step": bdt / a.brute_steps * 1e3,
+                                  "point_pairs_evaluated_per_sec": float(a.n) * a.n * passes * a.brute_steps / bdt,
+                                  "roofline": valu_roofline(bms / max(1, bn) * 1e-3, bn),
+                                  "max_abs_T_diff_vs_default": float(np.abs(np.array(blast.T) - np.array(last.T)).max())}
         if world == 1 and not a.no_cpu_baseline:
             cb = cpu_baseline(a.n, a.iters, src, tgt)
             Tg = np.array(last.T, dtype=np.float64)

@@ -66,6 +66,11 @@ int   kss_ctx_set_nn_mode(kss_ctx *ctx, int nn_mode);
 enum { KSS_K_NN_SWEEP = 0, KSS_K_CORR_REDUCE = 1, KSS_K_PRESHAPE = 2, KSS_K_ROT_SEARCH = 3,
        KSS_K_POSE_APPLY = 4, KSS_K_GRID_NN = 5, KSS_K_GRID_BUILD = 6, KSS_K_COUNT = 7 };
 int kss_profile_enable(kss_ctx *ctx, int on);
+/* geometry of the last cell list built on this context (KSS_NN_GRID) and, when profiling is enabled, the
+ * number of (source, target) distance evaluations of one search pass at the sources' initial positions:
+ * out = {cell edge h, gx, gy, gz, occupied cells, evaluations per pass, n_src, n_tgt}.  All zero if no
+ * grid has been built.  Used by bench.py to state the kernel's algorithmic bytes. */
+int kss_grid_stats(kss_ctx *ctx, double out[8]);
 int kss_profile_reset(kss_ctx *ctx);
 /* synchronises the stream; total_ms = sum of event-timed durations, launches = count */
 int kss_profile_get(kss_ctx *ctx, int kernel_class, double *total_ms, int64_t *launches);

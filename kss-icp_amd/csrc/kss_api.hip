@@ -34,6 +34,7 @@ struct kss_ctx {
     bool own_stream = false;
     std::string err;
     int nn_mode = KSS_NN_AUTO;
+    double grid_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
     // grow-only device workspace
     DevBuf tgt4, src0, cur[2], keys, partials, sums, nn_work, red_work, pair_red, state, cs, scratch_a,
@@ -207,6 +208,11 @@ int kss_ctx_set_nn_mode(kss_ctx* c, int nn_mode) {
 int kss_profile_enable(kss_ctx* c, int on) {
     if (!c) return KSS_ERR_ARG;
     c->prof = on != 0;
+    return KSS_OK;
+}
+int kss_grid_stats(kss_ctx* c, double out[8]) {
+    if (!c || !out) return KSS_ERR_ARG;
+    for (int k = 0; k < 8; ++k) out[k] = c->grid_stats[k];
     return KSS_OK;
 }
 int kss_profile_reset(kss_ctx* c) {
@@ -457,6 +463,18 @@ int grid_setup(kss_ctx* c, IcpPlan& pl) {
                              (float4*)c->cur[0].p, (float4*)c->cur[1].p);
     HIPCHK(c, hipMemcpyAsync((float4*)c->src0.p + g.src_base, c->cur[1].p, (size_t)ns * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipGetLastError());
+    c->grid_stats[0] = gp.h; c->grid_stats[1] = gp.gx; c->grid_stats[2] = gp.gy; c->grid_stats[3] = gp.gz;
+    c->grid_stats[4] = 0; c->grid_stats[5] = 0; c->grid_stats[6] = ns; c->grid_stats[7] = nt;
+    if (c->prof) {   // one extra small kernel, only while profiling
+        KCHK(ensure(c, c->scratch_c, 64));
+        HIPCHK(c, hipMemsetAsync(c->scratch_c.p, 0, 16, c->stream));
+        launch_grid_stats(c->stream, (const float4*)c->src0.p + g.src_base, ns, gp, (const int32_t*)c->g_start.p, (unsigned long long*)c->scratch_c.p);
+        unsigned long long hst[2] = {0, 0};
+        HIPCHK(c, hipMemcpyAsync(hst, c->scratch_c.p, 16, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->grid_stats[5] = (double)hst[0];
+        c->grid_stats[4] = (double)hst[1];
+    }
     return KSS_OK;
 }
 

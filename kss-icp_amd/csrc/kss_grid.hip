@@ -431,6 +431,35 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
     if (threadIdx.x == 0) *ticket = 0;   // re-arm for the next launch (stream order makes it visible)
 }
 
+// statistics for the roofline statement: evaluations of one r = 1 pass and occupied cells (profiling only)
+__global__ __launch_bounds__(256) void grid_stats_kernel(const float4* __restrict__ src, int ns, GridParams gp,
+                                                         const int32_t* __restrict__ cell_start, unsigned long long* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long ev = 0, occ = 0;
+    if (i < ns) {
+        const float4 p = src[i];
+        const int cx = cell_coord(p.x, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(p.y, gp.oy, gp.inv_h, gp.gy),
+                  cz = cell_coord(p.z, gp.oz, gp.inv_h, gp.gz);
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, gp.gx - 1);
+        for (int t = 0; t < 9; ++t) {
+            const int z = cz + t / 3 - 1, y = cy + t % 3 - 1;
+            if (z < 0 || z >= gp.gz || y < 0 || y >= gp.gy) continue;
+            const int row = (z * gp.gy + y) * gp.gx;
+            ev += (unsigned long long)(cell_start[row + x1 + 1] - cell_start[row + x0]);
+        }
+    }
+    const int ncells = gp.gx * gp.gy * gp.gz;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncells; c += gridDim.x * blockDim.x)
+        occ += cell_start[c + 1] > cell_start[c] ? 1 : 0;
+    atomicAdd(&out[0], ev);
+    atomicAdd(&out[1], occ);
+}
+
+void launch_grid_stats(hipStream_t st, const float4* d_src, int ns, const GridParams& gp, const int32_t* d_cell_start,
+                       unsigned long long* d_out) {
+    hipLaunchKernelGGL(grid_stats_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, d_src, ns, gp, d_cell_start, d_out);
+}
+
 static int env_int(const char* name, int dflt) {
     if (const char* e = getenv(name)) {
         const int v = atoi(e);
