@@ -334,8 +334,9 @@ int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npairs, boo
                 pl.nn.push_back(w);
             }
         pl.pred[p].first = prow;
-        // reduce workgroups own 256*R consecutive sources: ~100 partial rows per pair at most
-        int64_t R = (g.ns + 256 * 96 - 1) / (256 * 96);
+        // reduce workgroups own 256*R consecutive sources (R = 1 up to 131k sources: the reduce is latency bound,
+        // it wants many workgroups; the 240-lane final reduction handles hundreds of rows in a few microseconds)
+        int64_t R = (g.ns + 256 * 512 - 1) / (256 * 512);   // <= ~512 partial rows per pair
         R = std::max<int64_t>(1, std::min<int64_t>(R, 64));
         const int64_t rchunk = 256 * R;
         const int nrb = (int)((g.ns + rchunk - 1) / rchunk);

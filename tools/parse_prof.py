@@ -51,6 +51,9 @@ def main():
     fetch = read_counters(os.path.join(src, "pmc_fetch"))
     write = read_counters(os.path.join(src, "pmc_write"))
     sq = read_counters(os.path.join(src, "pmc_sq"))
+    for k, v in read_counters(os.path.join(src, "pmc_tcc")).items():
+        for c2, vals in v.items():
+            sq[k][c2] = vals
     lines += ["", "## HBM traffic per launch (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes)", "",
               "FETCH_SIZE and WRITE_SIZE are KiB; read side x2 (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section).", "",
               "| kernel | launches | FETCH_SIZE KiB (raw avg) | read bytes (x2 corrected) | WRITE_SIZE KiB (avg) | write bytes | HBM bytes / launch |",
