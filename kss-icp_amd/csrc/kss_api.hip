@@ -43,6 +43,9 @@ struct kss_ctx {
     // pinned host staging
     void* h_sums = nullptr;  size_t h_sums_cap = 0;   // host-mapped: kernels write it through h_sums_dev
     void* h_sums_dev = nullptr;
+    unsigned long long* h_seq = nullptr;       // host-mapped completion flag of the fused grid kernel
+    unsigned long long* h_seq_dev = nullptr;
+    unsigned long long seq = 0;
     void* h_state = nullptr; size_t h_state_cap = 0;
 
     // profiling
@@ -185,6 +188,7 @@ int kss_ctx_destroy(kss_ctx* c) {
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (c->h_sums) hipHostFree(c->h_sums);
+    if (c->h_seq) hipHostFree(c->h_seq);
     if (c->h_state) hipHostFree(c->h_state);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
@@ -445,6 +449,15 @@ int grid_setup(kss_ctx* c, IcpPlan& pl) {
     KCHK(ensure(c, c->g_bsums, ((ncells + 4095) / 4096 + 1) * sizeof(int32_t)));
     KCHK(ensure(c, c->g_sorted, (size_t)nt * sizeof(float4)));
     KCHK(ensure(c, c->g_list, (size_t)ns * sizeof(int32_t)));
+    if (!c->h_seq) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocMapped) != hipSuccess) return set_err(c, KSS_ERR_NOMEM, "hipHostMalloc(seq)");
+        c->h_seq = (unsigned long long*)p;
+        *c->h_seq = 0;
+        void* d = nullptr;
+        HIPCHK(c, hipHostGetDevicePointer(&d, p, 0));
+        c->h_seq_dev = (unsigned long long*)d;
+    }
     KCHK(ensure(c, c->g_count, 64));   // [0] unresolved-list length, [1] last-workgroup ticket
     KCHK(ensure(c, c->g_partials, (size_t)grid_nn_blocks(ns) * NSUMS * sizeof(double)));
     HIPCHK(c, hipMemsetAsync(c->g_count.p, 0, 64, c->stream));
@@ -479,6 +492,20 @@ int grid_setup(kss_ctx* c, IcpPlan& pl) {
     return KSS_OK;
 }
 
+// Wait for the fused grid kernel: spin on its host-mapped sequence number (a stream sync costs a 5-10 us
+// wake-up per ICP iteration); after ~2 ms without progress fall back to the stream sync, which also
+// surfaces a faulted kernel instead of spinning forever.
+int wait_seq(kss_ctx* c) {
+    const unsigned long long want = c->seq;
+    for (long spin = 0; spin < 2000000; ++spin) {
+        if (__atomic_load_n(c->h_seq, __ATOMIC_ACQUIRE) == want) return KSS_OK;
+        __builtin_ia32_pause();
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (__atomic_load_n(c->h_seq, __ATOMIC_ACQUIRE) != want) return set_err(c, KSS_ERR_HIP, "grid kernel finished without publishing its result");
+    return KSS_OK;
+}
+
 // One NN sweep + correspondence reduce over every active pair.  h_sums receives npairs*NSUMS.
 int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, float4* d_out, double max_d2,
             int32_t* d_idx_out, float* d_d2_out) {
@@ -500,10 +527,11 @@ int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, float4*
             // search + correspondence sums + final reduction in ONE launch; sums land in host-mapped memory
             launch_grid_nn(c->stream, fma, hs[0], d_in, d_out, (int)pl.g[0].ns, pl.gp, (const int32_t*)c->g_start.p,
                            (const float4*)c->g_sorted.p, (unsigned long long*)c->keys.p, (int32_t*)c->g_list.p, (int32_t*)c->g_count.p, max_d2,
-                           (double*)c->g_partials.p, (int32_t*)c->g_count.p + 1, (double*)c->h_sums_dev, d_idx_out, d_d2_out);
+                           (double*)c->g_partials.p, (int32_t*)c->g_count.p + 1, (double*)c->h_sums_dev, d_idx_out, d_d2_out,
+                           ++c->seq, c->h_seq_dev);
         }
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        KCHK(wait_seq(c));
         if (((const double*)c->h_sums)[NSUMS - 1] > 0.0) {
             // queries the cell search gave up on (far from the target): brute-force sweep over the list,
             // then the reduce again over every source

@@ -266,7 +266,8 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
                                                       int32_t* __restrict__ list, int32_t* __restrict__ list_count,
                                                       double max_d2, double* __restrict__ partials, int32_t* __restrict__ ticket,
                                                       double* __restrict__ sums_out, int32_t* __restrict__ idx_out,
-                                                      float* __restrict__ d2_out) {
+                                                      float* __restrict__ d2_out, unsigned long long seq,
+                                                      volatile unsigned long long* __restrict__ seq_out) {
     __shared__ double sh[BS / 64][NSUMS];
     __shared__ double shg[ROWSUM_GROUPS][NSUMS];
     __shared__ int s_last;
@@ -427,8 +428,14 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
     if (threadIdx.x < NSUMS) {
         if (threadIdx.x == NSUMS - 1) v = (double)__hip_atomic_load(list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sums_out[threadIdx.x] = v;
+        __threadfence_system();   // the sums are in host memory before the sequence number below
     }
-    if (threadIdx.x == 0) *ticket = 0;   // re-arm for the next launch (stream order makes it visible)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *ticket = 0;   // re-arm for the next launch (stream order makes it visible)
+        // host-mapped completion flag: the host spins on it instead of paying a stream-sync wake-up per iteration
+        if (seq_out) *seq_out = seq;
+    }
 }
 
 // statistics for the roofline statement: evaluations of one r = 1 pass and occupied cells (profiling only)
@@ -483,10 +490,12 @@ template <bool FMA, int LPQ>
 static void grid_launch_bs(hipStream_t st, int bs, dim3 grid, const PairState& state, const float4* d_src_in, float4* d_src_out, int ns,
                            const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted, unsigned long long* d_keys,
                            int32_t* d_list, int32_t* d_list_count, double max_d2, double* d_partials, int32_t* d_ticket,
-                           double* d_sums_out, int32_t* d_idx_out, float* d_d2_out) {
+                           double* d_sums_out, int32_t* d_idx_out, float* d_d2_out, unsigned long long seq,
+                           unsigned long long* d_seq_out) {
 #define KSS_GRID_LAUNCH(BV)                                                                                                  \
     hipLaunchKernelGGL((grid_nn_kernel<FMA, LPQ, BV>), grid, dim3(BV), 0, st, state, d_src_in, d_src_out, ns, gp, d_cell_start, \
-                       d_sorted, d_keys, d_list, d_list_count, max_d2, d_partials, d_ticket, d_sums_out, d_idx_out, d_d2_out)
+                       d_sorted, d_keys, d_list, d_list_count, max_d2, d_partials, d_ticket, d_sums_out, d_idx_out, d_d2_out, seq,  \
+                       d_seq_out)
     if (bs == 1024) KSS_GRID_LAUNCH(1024); else if (bs == 512) KSS_GRID_LAUNCH(512); else KSS_GRID_LAUNCH(256);
 #undef KSS_GRID_LAUNCH
 }
@@ -494,11 +503,12 @@ static void grid_launch_bs(hipStream_t st, int bs, dim3 grid, const PairState& s
 void launch_grid_nn(hipStream_t st, bool fma, const PairState& state, const float4* d_src_in, float4* d_src_out, int ns,
                     const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted,
                     unsigned long long* d_keys, int32_t* d_list, int32_t* d_list_count, double max_d2, double* d_partials,
-                    int32_t* d_ticket, double* d_sums_out, int32_t* d_idx_out, float* d_d2_out) {
+                    int32_t* d_ticket, double* d_sums_out, int32_t* d_idx_out, float* d_d2_out, unsigned long long seq,
+                    unsigned long long* d_seq_out) {
     const dim3 grid(grid_nn_blocks(ns));
     const int lpq = grid_lpq(), bs = grid_bs();
 #define KSS_GRID_ARGS st, bs, grid, state, d_src_in, d_src_out, ns, gp, d_cell_start, d_sorted, d_keys, d_list, d_list_count, max_d2, \
-                      d_partials, d_ticket, d_sums_out, d_idx_out, d_d2_out
+                      d_partials, d_ticket, d_sums_out, d_idx_out, d_d2_out, seq, d_seq_out
     if (fma) {
         switch (lpq) {
             case 1: grid_launch_bs<true, 1>(KSS_GRID_ARGS); break;

@@ -81,7 +81,8 @@ void launch_grid_build(hipStream_t st, const float4* d_tgt, int n, const GridPar
 void launch_grid_nn(hipStream_t st, bool fma, const PairState& state, const float4* d_src_in, float4* d_src_out, int ns,
                     const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted,
                     unsigned long long* d_keys, int32_t* d_list, int32_t* d_list_count, double max_d2, double* d_partials,
-                    int32_t* d_ticket, double* d_sums_out, int32_t* d_idx_out, float* d_d2_out);
+                    int32_t* d_ticket, double* d_sums_out, int32_t* d_idx_out, float* d_d2_out, unsigned long long seq,
+                    unsigned long long* d_seq_out);
 int grid_nn_blocks(int ns);
 void launch_grid_stats(hipStream_t st, const float4* d_src, int ns, const GridParams& gp, const int32_t* d_cell_start,
                        unsigned long long* d_out /* [0] evaluations of the 3x3x3 block, [1] occupied cells */);
