@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -35,6 +36,7 @@ struct kss_ctx {
     std::string err;
     int nn_mode = KSS_NN_AUTO;
     double grid_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double last_setup_ms = 0, last_loop_ms = 0;
 
     // grow-only device workspace
     DevBuf tgt4, src0, cur[2], keys, partials, sums, nn_work, red_work, pair_red, state, cs, scratch_a,
@@ -52,6 +54,7 @@ struct kss_ctx {
     bool prof = false;
     struct EvPair { hipEvent_t a, b; };
     std::vector<EvPair> ev[KSS_K_COUNT];
+    std::vector<EvPair> ev_pool;   // recycled event pairs: no hipEventCreate/Destroy inside timed loops
     double prof_ms[KSS_K_COUNT] = {0};
     int64_t prof_n[KSS_K_COUNT] = {0};
 };
@@ -109,7 +112,13 @@ struct ProfScope {   // records a start/stop event pair around a launch when pro
     kss_ctx* c; int k; kss_ctx::EvPair ep; bool on;
     ProfScope(kss_ctx* c_, int k_) : c(c_), k(k_), on(c_->prof) {
         if (!on) return;
-        if (hipEventCreate(&ep.a) != hipSuccess || hipEventCreate(&ep.b) != hipSuccess) { on = false; return; }
+        if (!c->ev_pool.empty()) {
+            ep = c->ev_pool.back();
+            c->ev_pool.pop_back();
+        } else if (hipEventCreate(&ep.a) != hipSuccess || hipEventCreate(&ep.b) != hipSuccess) {
+            on = false;
+            return;
+        }
         hipEventRecord(ep.a, c->stream);
     }
     ~ProfScope() {
@@ -124,8 +133,7 @@ static void prof_collect(kss_ctx* c) {
         for (auto& ep : c->ev[k]) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) { c->prof_ms[k] += ms; c->prof_n[k] += 1; }
-            hipEventDestroy(ep.a);
-            hipEventDestroy(ep.b);
+            c->ev_pool.push_back(ep);
         }
         c->ev[k].clear();
     }
@@ -181,6 +189,8 @@ int kss_ctx_destroy(kss_ctx* c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     prof_collect(c);
+    for (auto& ep : c->ev_pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
+    c->ev_pool.clear();
     DevBuf* bufs[] = {&c->tgt4, &c->src0, &c->cur[0], &c->cur[1], &c->keys, &c->partials, &c->sums, &c->nn_work,
                       &c->red_work, &c->pair_red, &c->state, &c->cs, &c->scratch_a, &c->scratch_b, &c->scratch_c,
                       &c->stage_src, &c->stage_tgt, &c->stage_idx, &c->stage_d2, &c->stage_out, &c->g_counts, &c->g_start,
@@ -212,6 +222,15 @@ int kss_ctx_set_nn_mode(kss_ctx* c, int nn_mode) {
 int kss_profile_enable(kss_ctx* c, int on) {
     if (!c) return KSS_ERR_ARG;
     c->prof = on != 0;
+    if (c->prof) {   // pre-create the event pairs a timed region will use
+        HIPCHK(c, hipSetDevice(c->device));
+        while (c->ev_pool.size() < 4096) {
+            kss_ctx::EvPair ep;
+            if (hipEventCreate(&ep.a) != hipSuccess) break;
+            if (hipEventCreate(&ep.b) != hipSuccess) { hipEventDestroy(ep.a); break; }
+            c->ev_pool.push_back(ep);
+        }
+    }
     return KSS_OK;
 }
 int kss_grid_stats(kss_ctx* c, double out[8]) {
@@ -652,11 +671,19 @@ int icp_run_dev(kss_ctx* c, const void* d_src, const int64_t* src_off, const voi
         nt[i] = shared_target ? tgt_off[1] - tgt_off[0] : tgt_off[i + 1] - tgt_off[i];
     }
     IcpPlan pl;
+    const auto t0 = std::chrono::steady_clock::now();
     KCHK(build_plan(c, ns.data(), nt.data(), npairs, shared_target, p->nn_sources_per_thread, p->nn_target_splits, p->nn_mode, pl));
     KCHK(stage_plan(c, pl));
     KCHK(pack_clouds(c, pl, d_src, src_off, d_tgt, tgt_off, dtype));
     KCHK(grid_setup(c, pl));
-    return icp_loop(c, pl, *p, results);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const auto t1 = std::chrono::steady_clock::now();
+    const int rc = icp_loop(c, pl, *p, results);
+    const auto t2 = std::chrono::steady_clock::now();
+    c->last_setup_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    c->last_loop_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    if (getenv("KSS_TIMING")) std::fprintf(stderr, "[kss] setup %.3f ms, loop+fitness %.3f ms\n", c->last_setup_ms, c->last_loop_ms);
+    return rc;
 }
 
 // host -> device staging of a packed cloud

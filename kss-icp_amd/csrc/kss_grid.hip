@@ -360,6 +360,9 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
             const float4 q = sorted[kpos];   // the winner's line was just read by a lane of this group: L1 hit
             const double dd = (double)d2;
             const bool keep = !(dd > max_d2);   // PCL: `if (distance[0] > max_dist_sqr) continue;`
+            if constexpr (LPQ == 1) {
+                accumulate_corr(acc, qx, qy, qz, q.x, q.y, q.z, d2, max_d2);   // one lane owns all 20 sums: no selects
+            } else {
 #pragma unroll
             for (int j = 0; j < NACC; ++j) {
                 const int c = sub + j * LPQ;   // the component this lane owns in slot j
@@ -375,6 +378,8 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
                 else v = 0.0;
                 acc[j] += v;
             }
+            }
+            (void)keep;
             if (sub == 0) {
                 keys[i] = key;
                 const int oi = __float_as_int(p.w);   // original source index (sources are in cell order)
