@@ -41,7 +41,7 @@ struct kss_ctx {
     // grow-only device workspace
     DevBuf tgt4, src0, cur[2], keys, partials, sums, nn_work, red_work, pair_red, state, cs, scratch_a,
         scratch_b, scratch_c, stage_src, stage_tgt, stage_idx, stage_d2, stage_out, g_counts, g_start, g_cursor,
-        g_bsums, g_sorted, g_list, g_count, g_bbox, g_partials, g_start2;
+        g_bsums, g_sorted, g_list, g_count, g_bbox, g_partials, g_start2, g_pairs;
     // pinned host staging
     void* h_sums = nullptr;  size_t h_sums_cap = 0;   // host-mapped: kernels write it through h_sums_dev
     void* h_sums_dev = nullptr;
@@ -194,7 +194,7 @@ int kss_ctx_destroy(kss_ctx* c) {
     DevBuf* bufs[] = {&c->tgt4, &c->src0, &c->cur[0], &c->cur[1], &c->keys, &c->partials, &c->sums, &c->nn_work,
                       &c->red_work, &c->pair_red, &c->state, &c->cs, &c->scratch_a, &c->scratch_b, &c->scratch_c,
                       &c->stage_src, &c->stage_tgt, &c->stage_idx, &c->stage_d2, &c->stage_out, &c->g_counts, &c->g_start,
-                      &c->g_cursor, &c->g_bsums, &c->g_sorted, &c->g_list, &c->g_count, &c->g_bbox, &c->g_partials, &c->g_start2};
+                      &c->g_cursor, &c->g_bsums, &c->g_sorted, &c->g_list, &c->g_count, &c->g_bbox, &c->g_partials, &c->g_start2, &c->g_pairs};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (c->h_sums) hipHostFree(c->h_sums);
@@ -280,7 +280,9 @@ struct IcpPlan {
     int64_t total_src = 0, total_tgt_pad = 0, total_keys = 0;
     bool shared_target = false;
     bool grid = false;      // exact cell-list search (single pair) with brute-force list fallback
+    bool gridb = false;     // batched cell lists, one per pair (no fallback: shells until the pair's grid is exhausted)
     GridParams gp;
+    int total_cells = 0;
 };
 
 int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npairs, bool shared_target,
@@ -289,7 +291,13 @@ int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npairs, boo
     pl.shared_target = shared_target;
     if (nn_mode == KSS_NN_AUTO) nn_mode = c->nn_mode;
     pl.grid = nn_mode == KSS_NN_GRID || (nn_mode == KSS_NN_AUTO && npairs == 1 && nt[0] >= 4096 && ns[0] >= 1024);
-    if (npairs != 1) pl.grid = false;   // the cell list is built per target; batches use the brute-force sweep
+    if (npairs != 1) pl.grid = false;
+    if (npairs > 1 && !shared_target) {   // batch: one cell list per pair when the pairs are big enough to pay for it
+        int64_t min_nt = nt[0], tot_ns = 0;
+        for (int p = 0; p < npairs; ++p) { min_nt = std::min(min_nt, nt[p]); tot_ns += ns[p]; }
+        pl.gridb = nn_mode == KSS_NN_GRID || (nn_mode == KSS_NN_AUTO && min_nt >= 2048 && tot_ns >= 8192);
+    }
+    const bool any_grid = pl.grid || pl.gridb;
     int64_t tot = 0;
     for (int p = 0; p < npairs; ++p) {
         if (ns[p] <= 0 || nt[p] <= 0) return set_err(c, KSS_ERR_ARG, "empty cloud in ICP pair");
@@ -328,7 +336,7 @@ int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npairs, boo
             tb += g.tgt_pad;
         }
         sb += ns[p];
-        kb += pl.grid ? ns[p] : (int64_t)g.n_split * ns[p];
+        kb += any_grid ? ns[p] : (int64_t)g.n_split * ns[p];
         if (sb > 0x7fff0000ll || tb > 0x7fff0000ll || kb > 0x7fff0000ll)
             return set_err(c, KSS_ERR_ARG, "problem too large for 32-bit indexing");
     }
@@ -338,7 +346,7 @@ int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npairs, boo
     int32_t prow = 0;
     for (int p = 0; p < npairs; ++p) {
         const PairGeom& g = pl.g[p];
-        for (int b = 0; b < g.n_src_blocks; ++b)
+        for (int b = 0; b < (pl.gridb ? 0 : g.n_src_blocks); ++b)
             for (int s = 0; s < g.n_split; ++s) {
                 NNWork w;
                 w.pair = p;
@@ -370,7 +378,7 @@ int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npairs, boo
             r.src_count = (int32_t)std::min<int64_t>(rchunk, g.ns - (int64_t)b * rchunk);
             r.key_begin = g.key_base + (int32_t)(b * rchunk);
             r.key_stride = (int32_t)g.ns;
-            r.n_split = pl.grid ? 1 : g.n_split;
+            r.n_split = any_grid ? 1 : g.n_split;
             r.tgt_pair_base = g.tgt_base;
             r.partial_index = prow++;
             pl.red.push_back(r);
@@ -425,6 +433,25 @@ int pack_clouds(kss_ctx* c, const IcpPlan& pl, const void* d_src, const int64_t*
     return KSS_OK;
 }
 
+static void choose_cells(const float mn[3], const float mx[3], int64_t nt, GridParams& gp) {
+    const float ext[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+    const float emax = std::max(ext[0], std::max(ext[1], ext[2]));
+    // cell edge: a handful of points per occupied cell if the target is a surface (area ~ emax^2 * few)
+    float hscale = 2.0f;
+    if (const char* e = getenv("KSS_GRID_HSCALE")) { const float v = (float)atof(e); if (v > 0.05f && v < 50.f) hscale = v; }   // tuning hook
+    float h = emax * hscale * std::sqrt(3.0f / (float)nt);
+    h = std::max(h, emax / 255.5f);
+    if (!(h > 0.f)) h = 1.f;   // all targets coincide
+    gp.ox = mn[0]; gp.oy = mn[1]; gp.oz = mn[2];
+    gp.h = h; gp.inv_h = 1.0f / h;
+    gp.gx = std::max(1, std::min(256, (int)std::floor(ext[0] / h) + 1));
+    gp.gy = std::max(1, std::min(256, (int)std::floor(ext[1] / h) + 1));
+    gp.gz = std::max(1, std::min(256, (int)std::floor(ext[2] / h) + 1));
+    const float mag = std::max(std::max(std::fabs(mn[0]), std::fabs(mx[0])), std::max(std::max(std::fabs(mn[1]), std::fabs(mx[1])), std::max(std::fabs(mn[2]), std::fabs(mx[2]))));
+    gp.eps = 2e-6f * (mag + emax) + 1e-30f;
+    gp.rcap = 12;
+}
+
 // Build the uniform cell list over the (single) target: bbox -> cell size -> counting sort.
 int grid_setup(kss_ctx* c, IcpPlan& pl) {
     if (!pl.grid) return KSS_OK;
@@ -443,23 +470,8 @@ int grid_setup(kss_ctx* c, IcpPlan& pl) {
         for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], hb[(size_t)b * 6 + k]); mx[k] = std::max(mx[k], hb[(size_t)b * 6 + 3 + k]); }
     if (!(std::isfinite(mn[0]) && std::isfinite(mn[1]) && std::isfinite(mn[2]) && std::isfinite(mx[0]) && std::isfinite(mx[1]) && std::isfinite(mx[2])))
         return set_err(c, KSS_ERR_ARG, "non-finite target coordinates");
-    const float ext[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
-    const float emax = std::max(ext[0], std::max(ext[1], ext[2]));
     GridParams gp;
-    // cell edge: ~3 points per occupied cell if the target is a surface (area ~ emax^2 * few)
-    float hscale = 2.0f;
-    if (const char* e = getenv("KSS_GRID_HSCALE")) { const float v = (float)atof(e); if (v > 0.05f && v < 50.f) hscale = v; }   // tuning hook
-    float h = emax * hscale * std::sqrt(3.0f / (float)nt);
-    h = std::max(h, emax / 255.5f);
-    if (!(h > 0.f)) h = 1.f;   // all targets coincide
-    gp.ox = mn[0]; gp.oy = mn[1]; gp.oz = mn[2];
-    gp.h = h; gp.inv_h = 1.0f / h;
-    gp.gx = std::max(1, std::min(256, (int)std::floor(ext[0] / h) + 1));
-    gp.gy = std::max(1, std::min(256, (int)std::floor(ext[1] / h) + 1));
-    gp.gz = std::max(1, std::min(256, (int)std::floor(ext[2] / h) + 1));
-    const float mag = std::max(std::max(std::fabs(mn[0]), std::fabs(mx[0])), std::max(std::max(std::fabs(mn[1]), std::fabs(mx[1])), std::max(std::fabs(mn[2]), std::fabs(mx[2]))));
-    gp.eps = 2e-6f * (mag + emax) + 1e-30f;
-    gp.rcap = 12;
+    choose_cells(mn, mx, nt, gp);
     pl.gp = gp;
     const size_t ncells = (size_t)gp.gx * gp.gy * gp.gz;
     KCHK(ensure(c, c->g_counts, ncells * sizeof(int32_t)));
@@ -511,6 +523,57 @@ int grid_setup(kss_ctx* c, IcpPlan& pl) {
     return KSS_OK;
 }
 
+// Batched cell lists: one per pair, all built by the same launches.
+int grid_setup_batch(kss_ctx* c, IcpPlan& pl) {
+    if (!pl.gridb) return KSS_OK;
+    const int np = pl.npairs;
+    std::vector<GridPairDev> hp(np);
+    int64_t sum_nt = 0;
+    for (int p = 0; p < np; ++p) {
+        std::memset(&hp[p], 0, sizeof(GridPairDev));
+        hp[p].tgt_base = pl.g[p].tgt_base; hp[p].tgt_n = (int32_t)pl.g[p].nt;
+        hp[p].src_base = pl.g[p].src_base; hp[p].src_n = (int32_t)pl.g[p].ns;
+        sum_nt += pl.g[p].nt;
+    }
+    ProfScope ps(c, KSS_K_GRID_BUILD);
+    KCHK(ensure(c, c->g_pairs, (size_t)np * sizeof(GridPairDev)));
+    KCHK(ensure(c, c->g_bbox, (size_t)np * 6 * sizeof(float)));
+    HIPCHK(c, hipMemcpyAsync(c->g_pairs.p, hp.data(), (size_t)np * sizeof(GridPairDev), hipMemcpyHostToDevice, c->stream));
+    launch_gridb_bbox(c->stream, (const float4*)c->tgt4.p, (const GridPairDev*)c->g_pairs.p, np, (float*)c->g_bbox.p);
+    std::vector<float> hb((size_t)np * 6);
+    HIPCHK(c, hipMemcpyAsync(hb.data(), c->g_bbox.p, hb.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int64_t cells = 0;
+    for (int p = 0; p < np; ++p) {
+        const float* b = &hb[(size_t)p * 6];
+        for (int k = 0; k < 6; ++k)
+            if (!std::isfinite(b[k])) return set_err(c, KSS_ERR_ARG, "non-finite target coordinates");
+        choose_cells(b, b + 3, pl.g[p].nt, hp[p].gp);
+        hp[p].cell_base = (int32_t)cells;
+        cells += (int64_t)hp[p].gp.gx * hp[p].gp.gy * hp[p].gp.gz;
+        if (cells > 0x7fff0000ll) return set_err(c, KSS_ERR_ARG, "batch cell lists exceed 32-bit indexing");
+    }
+    pl.total_cells = (int)cells;
+    HIPCHK(c, hipMemcpyAsync(c->g_pairs.p, hp.data(), (size_t)np * sizeof(GridPairDev), hipMemcpyHostToDevice, c->stream));
+    KCHK(ensure(c, c->g_counts, (size_t)cells * sizeof(int32_t)));
+    KCHK(ensure(c, c->g_start, ((size_t)cells + 1) * sizeof(int32_t)));
+    KCHK(ensure(c, c->g_start2, ((size_t)cells + 1) * sizeof(int32_t)));
+    KCHK(ensure(c, c->g_cursor, (size_t)cells * sizeof(int32_t)));
+    KCHK(ensure(c, c->g_bsums, (((size_t)cells + 4095) / 4096 + 1) * sizeof(int32_t)));
+    KCHK(ensure(c, c->g_sorted, (size_t)sum_nt * sizeof(float4)));
+    if ((cells + 4095) / 4096 > 1024 * 16) return set_err(c, KSS_ERR_ARG, "batch cell lists too large for the scan");
+    launch_gridb_build_targets(c->stream, (const float4*)c->tgt4.p, (int)pl.total_tgt_pad, (const GridPairDev*)c->g_pairs.p, np,
+                               (int)cells, (int32_t*)c->g_counts.p, (int32_t*)c->g_start.p, (int32_t*)c->g_cursor.p,
+                               (int32_t*)c->g_bsums.p, (float4*)c->g_sorted.p);
+    launch_gridb_sort_sources(c->stream, (const float4*)c->src0.p, (int)pl.total_src, (const GridPairDev*)c->g_pairs.p, np, (int)cells,
+                              (int32_t*)c->g_counts.p, (int32_t*)c->g_start2.p, (int32_t*)c->g_cursor.p, (int32_t*)c->g_bsums.p,
+                              (float4*)c->cur[0].p, (float4*)c->cur[1].p);
+    HIPCHK(c, hipMemcpyAsync(c->src0.p, c->cur[1].p, (size_t)pl.total_src * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // hp/hb are about to go out of scope
+    return KSS_OK;
+}
+
 // Wait for the fused grid kernel: spin on its host-mapped sequence number (a stream sync costs a 5-10 us
 // wake-up per ICP iteration); after ~2 ms without progress fall back to the stream sync, which also
 // surfaces a faulted kernel instead of spinning forever.
@@ -533,7 +596,7 @@ int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, float4*
         ProfScope ps(c, KSS_K_CORR_REDUCE);
         launch_corr_reduce(c->stream, (const RedWork*)c->red_work.p, (int)pl.red.size(), (const PairState*)c->state.p,
                            d_out, (const float4*)c->tgt4.p, (const unsigned long long*)c->keys.p, max_d2,
-                           (double*)c->partials.p, d_idx_out, d_d2_out, pl.grid ? 1 : 0);
+                           (double*)c->partials.p, d_idx_out, d_d2_out, (pl.grid || pl.gridb) ? 1 : 0);
         // the last kernel of the pass writes the sums straight into host-mapped pinned memory
         launch_finalize_sums(c->stream, (const PairRed*)c->pair_red.p, pl.npairs, (const double*)c->partials.p,
                              (double*)c->h_sums_dev, unresolved, reset);
@@ -568,7 +631,11 @@ int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, float4*
         return KSS_OK;
     }
     HIPCHK(c, hipMemcpyAsync(c->state.p, hs, (size_t)pl.npairs * sizeof(PairState), hipMemcpyHostToDevice, c->stream));
-    {
+    if (pl.gridb) {
+        ProfScope ps(c, KSS_K_GRID_NN);
+        launch_gridb_nn(c->stream, fma, (const PairState*)c->state.p, (const GridPairDev*)c->g_pairs.p, pl.npairs, d_in, d_out,
+                        (int)pl.total_src, (const int32_t*)c->g_start.p, (const float4*)c->g_sorted.p, (unsigned long long*)c->keys.p);
+    } else {
         ProfScope ps(c, KSS_K_NN_SWEEP);
         launch_nn_sweep(c->stream, pl.S, fma, (const NNWork*)c->nn_work.p, (int)pl.nn.size(), (const PairState*)c->state.p,
                         d_in, d_out, (const float4*)c->tgt4.p, (unsigned long long*)c->keys.p);
@@ -676,6 +743,7 @@ int icp_run_dev(kss_ctx* c, const void* d_src, const int64_t* src_off, const voi
     KCHK(stage_plan(c, pl));
     KCHK(pack_clouds(c, pl, d_src, src_off, d_tgt, tgt_off, dtype));
     KCHK(grid_setup(c, pl));
+    KCHK(grid_setup_batch(c, pl));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const auto t1 = std::chrono::steady_clock::now();
     const int rc = icp_loop(c, pl, *p, results);

@@ -443,6 +443,207 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
     }
 }
 
+// =============================================================================================
+// Batched variant (configs C3 / C5: many independent pairs): one cell list PER PAIR, all pairs built and
+// queried by the same launches.  Cells of pair p occupy [cell_base, cell_base + gx*gy*gz) of one global cell
+// array, so ONE exclusive scan yields global positions in the pair-by-pair sorted arrays.  There is no
+// brute-force fallback here: a query simply keeps adding shells until the pair's whole grid is visited.
+// =============================================================================================
+__device__ __forceinline__ int pair_of(int i, const GridPairDev* __restrict__ pairs, int npairs, bool by_src) {
+    int lo = 0, hi = npairs - 1;   // last pair whose base <= i
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        const int base = by_src ? pairs[mid].src_base : pairs[mid].tgt_base;
+        if (base <= i) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void gridb_bbox_kernel(const float4* __restrict__ tgt, const GridPairDev* __restrict__ pairs,
+                                                         float* __restrict__ bbox) {
+    __shared__ float sh[4][6];
+    const GridPairDev pr = pairs[blockIdx.x];
+    float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int i = threadIdx.x; i < pr.tgt_n; i += blockDim.x) {
+        const float4 p = tgt[pr.tgt_base + i];
+        mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+        mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = fminf(mn[k], __shfl_down(mn[k], off, 64));
+            mx[k] = fmaxf(mx[k], __shfl_down(mx[k], off, 64));
+        }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+        for (int k = 0; k < 3; ++k) { sh[wave][k] = mn[k]; sh[wave][3 + k] = mx[k]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = sh[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fminf(v, sh[w][threadIdx.x]) : fmaxf(v, sh[w][threadIdx.x]);
+        bbox[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+// counts (SCATTER = false) or scatter into cell order (SCATTER = true) of targets (BY_SRC = false: positions of
+// tgt4, padding skipped, .w = pair-relative index) or sources (BY_SRC = true: .w = global source index)
+template <bool SCATTER, bool BY_SRC>
+__global__ __launch_bounds__(256) void gridb_bin_kernel(const float4* __restrict__ pts, int total, const GridPairDev* __restrict__ pairs,
+                                                        int npairs, int32_t* __restrict__ counts_or_cursor, float4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int pi = pair_of(i, pairs, npairs, BY_SRC);
+    const GridPairDev pr = pairs[pi];
+    const int local = i - (BY_SRC ? pr.src_base : pr.tgt_base);
+    if (local >= (BY_SRC ? pr.src_n : pr.tgt_n)) return;   // sentinel padding of the target layout
+    float4 p = pts[i];
+    const GridParams& gp = pr.gp;
+    const int cx = cell_coord(p.x, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(p.y, gp.oy, gp.inv_h, gp.gy),
+              cz = cell_coord(p.z, gp.oz, gp.inv_h, gp.gz);
+    const int cell = pr.cell_base + (cz * gp.gy + cy) * gp.gx + cx;
+    if constexpr (SCATTER) {
+        const int pos = atomicAdd(&counts_or_cursor[cell], 1);
+        p.w = __int_as_float(BY_SRC ? i : local);
+        out[pos] = p;
+    } else {
+        atomicAdd(&counts_or_cursor[cell], 1);
+    }
+}
+
+// deterministic in-cell order for the sources (see grid_rank_fix_kernel)
+__global__ __launch_bounds__(256) void gridb_rank_fix_kernel(const float4* __restrict__ tmp, int total, const GridPairDev* __restrict__ pairs,
+                                                             int npairs, const int32_t* __restrict__ start, float4* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= total) return;
+    const float4 p = tmp[j];
+    const int pi = pair_of(j, pairs, npairs, true);   // sorted positions stay inside the pair's source segment
+    const GridPairDev pr = pairs[pi];
+    const GridParams& gp = pr.gp;
+    const int cx = cell_coord(p.x, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(p.y, gp.oy, gp.inv_h, gp.gy),
+              cz = cell_coord(p.z, gp.oz, gp.inv_h, gp.gz);
+    const int c = pr.cell_base + (cz * gp.gy + cy) * gp.gx + cx;
+    const int lo = start[c], hi = start[c + 1];
+    const int me = __float_as_int(p.w);
+    int rank = 0;
+    for (int k = lo; k < hi; ++k) rank += __float_as_int(tmp[k].w) < me ? 1 : 0;
+    out[lo + rank] = p;
+}
+
+static void launch_scan(hipStream_t st, const int32_t* d_counts, int ncells, int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums) {
+    const int nb = (ncells + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(256), 0, st, d_counts, ncells, d_block_sums);
+    hipLaunchKernelGGL(scan_of_block_sums_kernel, dim3(1), dim3(1024), 0, st, d_block_sums, nb);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, st, d_counts, ncells, d_block_sums, d_start, d_cursor);
+    hipLaunchKernelGGL(scan_tail_kernel, dim3(1), dim3(64), 0, st, d_counts, d_start, ncells);
+}
+
+void launch_gridb_bbox(hipStream_t st, const float4* d_tgt, const GridPairDev* d_pairs, int npairs, float* d_bbox) {
+    hipLaunchKernelGGL(gridb_bbox_kernel, dim3(npairs), dim3(256), 0, st, d_tgt, d_pairs, d_bbox);
+}
+
+// targets: tgt4 (padded layout, total_tgt_pad slots) -> d_sorted (pair by pair, sum of nt entries), d_start
+void launch_gridb_build_targets(hipStream_t st, const float4* d_tgt, int total_tgt_pad, const GridPairDev* d_pairs, int npairs,
+                                int total_cells, int32_t* d_counts, int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums,
+                                float4* d_sorted) {
+    hipMemsetAsync(d_counts, 0, (size_t)total_cells * sizeof(int32_t), st);
+    const dim3 grid((total_tgt_pad + 255) / 256), block(256);
+    hipLaunchKernelGGL((gridb_bin_kernel<false, false>), grid, block, 0, st, d_tgt, total_tgt_pad, d_pairs, npairs, d_counts, (float4*)nullptr);
+    launch_scan(st, d_counts, total_cells, d_start, d_cursor, d_block_sums);
+    hipLaunchKernelGGL((gridb_bin_kernel<true, false>), grid, block, 0, st, d_tgt, total_tgt_pad, d_pairs, npairs, d_cursor, d_sorted);
+}
+
+// sources: d_src (total_src float4) -> d_out in (pair, cell, original index) order; d_tmp is scratch
+void launch_gridb_sort_sources(hipStream_t st, const float4* d_src, int total_src, const GridPairDev* d_pairs, int npairs,
+                               int total_cells, int32_t* d_counts, int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums,
+                               float4* d_tmp, float4* d_out) {
+    hipMemsetAsync(d_counts, 0, (size_t)total_cells * sizeof(int32_t), st);
+    const dim3 grid((total_src + 255) / 256), block(256);
+    hipLaunchKernelGGL((gridb_bin_kernel<false, true>), grid, block, 0, st, d_src, total_src, d_pairs, npairs, d_counts, (float4*)nullptr);
+    launch_scan(st, d_counts, total_cells, d_start, d_cursor, d_block_sums);
+    hipLaunchKernelGGL((gridb_bin_kernel<true, true>), grid, block, 0, st, d_src, total_src, d_pairs, npairs, d_cursor, d_tmp);
+    hipLaunchKernelGGL(gridb_rank_fix_kernel, grid, block, 0, st, d_tmp, total_src, d_pairs, npairs, d_start, d_out);
+}
+
+// query: one lane per (sorted) source of the whole batch; writes keys[i] and the transformed source
+template <bool FMA>
+__global__ __launch_bounds__(256) void gridb_nn_kernel(const PairState* __restrict__ state, const GridPairDev* __restrict__ pairs,
+                                                       int npairs, const float4* __restrict__ src_in, float4* __restrict__ src_out,
+                                                       int total_src, const int32_t* __restrict__ cell_start,
+                                                       const float4* __restrict__ sorted, unsigned long long* __restrict__ keys) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total_src) return;
+    const int pi = pair_of(i, pairs, npairs, true);
+    const PairState ps = state[pi];
+    if (!ps.active) return;
+    const GridPairDev pr = pairs[pi];
+    const GridParams& gp = pr.gp;
+    float4 p = src_in[i];
+    if (ps.apply) {
+        const float x = p.x, y = p.y, z = p.z;
+        p.x = ((ps.m[0] * x + ps.m[1] * y) + ps.m[2] * z) + ps.m[3];
+        p.y = ((ps.m[4] * x + ps.m[5] * y) + ps.m[6] * z) + ps.m[7];
+        p.z = ((ps.m[8] * x + ps.m[9] * y) + ps.m[10] * z) + ps.m[11];
+    }
+    src_out[i] = p;
+    const float qx = p.x, qy = p.y, qz = p.z;
+    const int cx = cell_coord(qx, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(qy, gp.oy, gp.inv_h, gp.gy),
+              cz = cell_coord(qz, gp.oz, gp.inv_h, gp.gz);
+    const int32_t* __restrict__ cs = cell_start + pr.cell_base;
+    unsigned long long key = ~0ull;
+    int kpos = 0;
+    const int rmax = max(gp.gx, max(gp.gy, gp.gz));
+    for (int r = 1; r <= rmax; ++r) {
+        const int w = 2 * r + 1;
+        const int x0 = max(cx - r, 0), x1 = min(cx + r, gp.gx - 1);
+        if (r == 1) {
+            for (int t = 0; t < 9; ++t) {
+                const int z = cz + t / 3 - 1, y = cy + t % 3 - 1;
+                if (z < 0 || z >= gp.gz || y < 0 || y >= gp.gy) continue;
+                const int row = (z * gp.gy + y) * gp.gx;
+                scan_range<FMA>(sorted, cs[row + x0], cs[row + x1 + 1], qx, qy, qz, key, kpos);
+            }
+        } else {
+            for (int t = 0; t < w * w; ++t) {
+                const int dz = t / w - r, dy = t % w - r;
+                const int z = cz + dz, y = cy + dy;
+                if (z < 0 || z >= gp.gz || y < 0 || y >= gp.gy) continue;
+                const int row = (z * gp.gy + y) * gp.gx;
+                if (dz == -r || dz == r || dy == -r || dy == r) {
+                    scan_range<FMA>(sorted, cs[row + x0], cs[row + x1 + 1], qx, qy, qz, key, kpos);
+                } else {
+                    if (cx - r >= 0) scan_range<FMA>(sorted, cs[row + cx - r], cs[row + cx - r + 1], qx, qy, qz, key, kpos);
+                    if (cx + r < gp.gx) scan_range<FMA>(sorted, cs[row + cx + r], cs[row + cx + r + 1], qx, qy, qz, key, kpos);
+                }
+            }
+        }
+        const float best = __uint_as_float((unsigned)(key >> 32));
+        float b = __builtin_inff();
+        if (cx - r > 0) b = fminf(b, qx - (gp.ox + (float)(cx - r) * gp.h));
+        if (cx + r < gp.gx - 1) b = fminf(b, (gp.ox + (float)(cx + r + 1) * gp.h) - qx);
+        if (cy - r > 0) b = fminf(b, qy - (gp.oy + (float)(cy - r) * gp.h));
+        if (cy + r < gp.gy - 1) b = fminf(b, (gp.oy + (float)(cy + r + 1) * gp.h) - qy);
+        if (cz - r > 0) b = fminf(b, qz - (gp.oz + (float)(cz - r) * gp.h));
+        if (cz + r < gp.gz - 1) b = fminf(b, (gp.oz + (float)(cz + r + 1) * gp.h) - qz);
+        const float bs = b - gp.eps;
+        if (b == __builtin_inff()) break;                              // the pair's whole grid has been visited
+        if (bs > 0.f && best < bs * bs * 0.999999f) break;             // every unvisited point is strictly farther
+    }
+    keys[i] = key;
+}
+
+void launch_gridb_nn(hipStream_t st, bool fma, const PairState* d_state, const GridPairDev* d_pairs, int npairs,
+                     const float4* d_src_in, float4* d_src_out, int total_src, const int32_t* d_cell_start,
+                     const float4* d_sorted, unsigned long long* d_keys) {
+    const dim3 grid((total_src + 255) / 256), block(256);
+    if (fma)
+        hipLaunchKernelGGL(gridb_nn_kernel<true>, grid, block, 0, st, d_state, d_pairs, npairs, d_src_in, d_src_out, total_src, d_cell_start, d_sorted, d_keys);
+    else
+        hipLaunchKernelGGL(gridb_nn_kernel<false>, grid, block, 0, st, d_state, d_pairs, npairs, d_src_in, d_src_out, total_src, d_cell_start, d_sorted, d_keys);
+}
+
 // statistics for the roofline statement: evaluations of one r = 1 pass and occupied cells (profiling only)
 __global__ __launch_bounds__(256) void grid_stats_kernel(const float4* __restrict__ src, int ns, GridParams gp,
                                                          const int32_t* __restrict__ cell_start, unsigned long long* __restrict__ out) {

@@ -60,6 +60,15 @@ struct GridParams {
     int32_t rcap;       // shells searched before a query falls back to the brute-force list pass
 };
 
+// per-pair entry of the batched cell list (device table)
+struct alignas(16) GridPairDev {
+    GridParams gp;
+    int32_t cell_base;          // first cell of this pair in the global cell arrays
+    int32_t tgt_base, tgt_n;    // target segment in tgt4 (padded layout) and its real point count
+    int32_t src_base, src_n;    // source segment
+    int32_t pad;
+};
+
 constexpr int NN_TILE = 256;      // targets staged per LDS tile (one float4 per thread)
 constexpr int NN_SUB = 32;        // targets per sub-tile (arg-min bookkeeping granularity)
 constexpr int NN_THREADS = 256;
@@ -84,6 +93,16 @@ void launch_grid_nn(hipStream_t st, bool fma, const PairState& state, const floa
                     int32_t* d_ticket, double* d_sums_out, int32_t* d_idx_out, float* d_d2_out, unsigned long long seq,
                     unsigned long long* d_seq_out);
 int grid_nn_blocks(int ns);
+void launch_gridb_bbox(hipStream_t st, const float4* d_tgt, const GridPairDev* d_pairs, int npairs, float* d_bbox);
+void launch_gridb_build_targets(hipStream_t st, const float4* d_tgt, int total_tgt_pad, const GridPairDev* d_pairs, int npairs,
+                                int total_cells, int32_t* d_counts, int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums,
+                                float4* d_sorted);
+void launch_gridb_sort_sources(hipStream_t st, const float4* d_src, int total_src, const GridPairDev* d_pairs, int npairs,
+                               int total_cells, int32_t* d_counts, int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums,
+                               float4* d_tmp, float4* d_out);
+void launch_gridb_nn(hipStream_t st, bool fma, const PairState* d_state, const GridPairDev* d_pairs, int npairs,
+                     const float4* d_src_in, float4* d_src_out, int total_src, const int32_t* d_cell_start,
+                     const float4* d_sorted, unsigned long long* d_keys);
 void launch_grid_stats(hipStream_t st, const float4* d_src, int ns, const GridParams& gp, const int32_t* d_cell_start,
                        unsigned long long* d_out /* [0] evaluations of the 3x3x3 block, [1] occupied cells */);
 void launch_grid_sort_sources(hipStream_t st, const float4* d_src, int n, const GridParams& gp, int32_t* d_counts,

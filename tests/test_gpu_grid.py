@@ -94,3 +94,33 @@ def test_grid_icp_with_unresolved_sources(ctx, O, pkg):
     assert np.array_equal(g["trace_sums"][:, 0], r["trace_sums"][:, 0])
     assert np.allclose(g["trace_sums"], r["trace_sums"], rtol=1e-9, atol=1e-12)
     assert np.abs(g["T"] - r["T"]).max() < 1e-5 and abs(g["fitness"] - r["fitness"]) < 1e-9
+
+
+def test_grid_batch_matches_brute_batch_and_oracle(ctx, O, pkg):
+    """Batched cell lists (one per pair): ragged pairs, a degenerate pair, far sources -- against the
+    brute-force batch and the oracle."""
+    S = pkg.synth
+    specs = [(3000, 2500), (1200, 4000), (5000, 5000), (1, 2100), (2600, 2048), (700, 9000)]
+    pairs = []
+    for i, (ns, nt) in enumerate(specs):
+        R = S.rot_axis_angle([0.2 * i, 1.0, 0.3], np.deg2rad(4.0 + 2.0 * i))
+        s, t = S.make_pair(40 + i, nt, R=R, t=(0.01 * i, -0.02, 0.015), shape="bumpy", n_src=ns)
+        pairs.append((s, t))
+    pairs[4] = (pairs[4][0] + np.float32(0.35), pairs[4][1])      # displaced: needs several shells
+    src_all = np.concatenate([p[0] for p in pairs]); tgt_all = np.concatenate([p[1] for p in pairs])
+    so = np.cumsum([0] + [len(p[0]) for p in pairs]); to = np.cumsum([0] + [len(p[1]) for p in pairs])
+    g = ctx.icp_batch(src_all, so, tgt_all, to, ctx.icp_params(nn_mode=pkg.NN_GRID))
+    b = ctx.icp_batch(src_all, so, tgt_all, to, ctx.icp_params(nn_mode=pkg.NN_BRUTE))
+    for i, (s, t) in enumerate(pairs):
+        assert g[i].pair_id == i and g[i].iterations == b[i].iterations and g[i].state == b[i].state
+        assert np.abs(g[i].matrix() - b[i].matrix()).max() < 1e-6
+        assert abs(g[i].fitness - b[i].fitness) <= 1e-12 * max(1.0, abs(b[i].fitness))
+        r = O.icp(s, t)
+        assert g[i].iterations == r["iterations"] and g[i].state == r["state"]
+        assert np.abs(g[i].matrix() - r["T"]).max() < 1e-5
+    assert g[3].state == 5      # one source point: not enough correspondences
+    # fixed-iteration mode, correspondences counted: bit-identical NN means identical counts every iteration
+    g2 = ctx.icp_batch(src_all, so, tgt_all, to, ctx.icp_params(nn_mode=pkg.NN_GRID, max_iterations=4, fixed_iterations=1))
+    b2 = ctx.icp_batch(src_all, so, tgt_all, to, ctx.icp_params(nn_mode=pkg.NN_BRUTE, max_iterations=4, fixed_iterations=1))
+    for i in range(len(pairs)):
+        assert np.abs(g2[i].matrix() - b2[i].matrix()).max() < 1e-6 and abs(g2[i].last_mse - b2[i].last_mse) < 1e-12
