@@ -362,9 +362,66 @@ __global__ __launch_bounds__(64) void sum_columns_kernel(const double* __restric
     out[c] = a;
 }
 
+// ---- f32 fast path: the cloud is read as a flat array of float4 (16 B per lane, fully coalesced) -------------
+// float4 j holds flat floats 4j..4j+3; flat float f belongs to coordinate f % 3, and 4 == 1 (mod 3), so element e
+// of float4 j is coordinate (j + e) % 3: the sum pass needs no regrouping at all.
+__global__ __launch_bounds__(256) void preshape_sum_f32v_kernel(const float4* __restrict__ v, int64_t nf4, const float* __restrict__ xyz,
+                                                                int64_t nfloats, double* __restrict__ partials) {
+    __shared__ double sh[4][3];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;   // sums of the elements whose (j + e) % 3 is 0 / 1 / 2, relative to j % 3 == 0
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nf4; j += (int64_t)gridDim.x * blockDim.x) {
+        const float4 q = v[j];
+        const int m = (int)(j % 3);
+        // rotate: element e goes to coordinate (m + e) % 3
+        const double e0 = (double)q.x, e1 = (double)q.y, e2 = (double)q.z, e3 = (double)q.w;
+        if (m == 0) { acc[0] += e0; acc[1] += e1; acc[2] += e2; acc[0] += e3; }
+        else if (m == 1) { acc[1] += e0; acc[2] += e1; acc[0] += e2; acc[1] += e3; }
+        else { acc[2] += e0; acc[0] += e1; acc[1] += e2; acc[2] += e3; }
+    }
+    (void)a0; (void)a1; (void)a2;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t f = nf4 * 4; f < nfloats; ++f) acc[f % 3] += (double)xyz[f];   // < 4 trailing floats
+    const double r = block_sum<3>(acc, sh);
+    if (threadIdx.x < 3) partials[(int64_t)blockIdx.x * 3 + threadIdx.x] = r;
+}
+
+// radius pass: lane j reads float4 j and j+1 (32 contiguous bytes; the second is the neighbour's first: an L1/TA
+// hit, HBM traffic unchanged) and finishes the points that START inside float4 j: two when j % 3 == 0, else one.
+__global__ __launch_bounds__(256) void preshape_radius_f32v_kernel(const float4* __restrict__ v, int64_t nf4, const float* __restrict__ xyz,
+                                                                   int64_t n, const double* __restrict__ centroid,
+                                                                   double* __restrict__ partials) {
+    __shared__ double sh[4][1];
+    const double cx = centroid[0], cy = centroid[1], cz = centroid[2];
+    double acc[1] = {0.0};
+    auto add = [&](float x, float y, float z) {
+        const double xl = (double)x - cx, yl = (double)y - cy, zl = (double)z - cz;
+        acc[0] += sqrt((xl * xl + yl * yl) + zl * zl);
+    };
+    const int64_t nv = nf4 > 0 ? nf4 - 1 : 0;   // lanes that may read j + 1
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nv; j += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = v[j], b = v[j + 1];
+        const int m = (int)(j % 3);
+        if (m == 0) { add(a.x, a.y, a.z); add(a.w, b.x, b.y); }
+        else if (m == 1) add(a.z, a.w, b.x);
+        else add(a.y, a.z, a.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // points that start at or after float 4 * nv: at most three, plus everything if the cloud is tiny
+        for (int64_t k = (4 * nv + 2) / 3; k < n; ++k) add(xyz[3 * k], xyz[3 * k + 1], xyz[3 * k + 2]);
+    }
+    const double r = block_sum<1>(acc, sh);
+    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
+static bool f32_vector_ok(const void* p, int64_t n) { return ((uintptr_t)p & 15u) == 0 && n >= 1024; }
+
 void launch_preshape_sum(hipStream_t st, const void* d_xyz, int dtype, int64_t n, double* d_partials, int n_blocks) {
     if (dtype == KSS_F64)
         hipLaunchKernelGGL(preshape_sum_kernel<double>, dim3(n_blocks), dim3(256), 0, st, (const double*)d_xyz, n, d_partials);
+    else if (f32_vector_ok(d_xyz, n))
+        hipLaunchKernelGGL(preshape_sum_f32v_kernel, dim3(n_blocks), dim3(256), 0, st, (const float4*)d_xyz, (3 * n) / 4,
+                           (const float*)d_xyz, 3 * n, d_partials);
     else
         hipLaunchKernelGGL(preshape_sum_kernel<float>, dim3(n_blocks), dim3(256), 0, st, (const float*)d_xyz, n, d_partials);
 }
@@ -375,6 +432,9 @@ void launch_preshape_radius(hipStream_t st, const void* d_xyz, int dtype, int64_
                             double* d_partials, int n_blocks) {
     if (dtype == KSS_F64)
         hipLaunchKernelGGL(preshape_radius_kernel<double>, dim3(n_blocks), dim3(256), 0, st, (const double*)d_xyz, n, d_centroid, d_partials);
+    else if (f32_vector_ok(d_xyz, n))
+        hipLaunchKernelGGL(preshape_radius_f32v_kernel, dim3(n_blocks), dim3(256), 0, st, (const float4*)d_xyz, (3 * n) / 4,
+                           (const float*)d_xyz, n, d_centroid, d_partials);
     else
         hipLaunchKernelGGL(preshape_radius_kernel<float>, dim3(n_blocks), dim3(256), 0, st, (const float*)d_xyz, n, d_centroid, d_partials);
 }

@@ -115,6 +115,15 @@ def test_preshape_large_and_ragged(ctx, O, pkg):
         assert _close(c, ps.c_src, 1e-11) and _close(r, ps.r_src, 1e-11)
 
 
+def test_preshape_f32_vector_path(ctx, O, pkg):
+    """f32 clouds >= 1024 points take the float4 streaming kernels: every tail length (3n mod 4, n mod 3)."""
+    for n in (1024, 1025, 1026, 1027, 4099, 100003):
+        p = (pkg.synth.bumpy(n + 1, n) * 2.0 + np.array([3.0, -1.0, 0.25])).astype(np.float32)
+        c, r = ctx.preshape_stats(p)
+        ps = O.preshape_stats(p.astype(np.float64), p.astype(np.float64))
+        assert _close(c, ps.c_src, 1e-11) and _close(r, ps.r_src, 1e-11)
+
+
 # ---- (a3,a7) pose application ----------------------------------------------------------------------------------------
 def test_pose_apply_bit_exact(ctx, O):
     g = np.load(os.path.join(GOLDEN, "oracle_vectors.npz"))
