@@ -110,8 +110,12 @@ def main():
         raise SystemExit("bench.py needs a GPU: the KSS-ICP core has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = os.environ.get("KSS_BENCH_FORCE_DIST") == "1"     # exercise the RCCL path with a single rank
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
     pkg = graft.load_package()
@@ -132,7 +136,7 @@ def main():
 
         def step():
             res = ctx.icp_dev(d_src.data_ptr(), a.n, d_tgt.data_ptr(), a.n, params)
-            if world > 1:   # final gather of the (R,t) records over RCCL/xGMI: one 96-B record per pair
+            if world > 1 or force_dist:   # final gather of the (R,t) records over RCCL/xGMI: one 96-B record per pair
                 local = pkg.shard.records_to_array(RecArr(res), rank)
                 pkg.shard.gather_records(local, world, world, rank, device=dev)
             return res
@@ -230,7 +234,7 @@ def main():
             out["speedup_vs_cpu_1core"] = value / cb["value"]
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -328,14 +328,18 @@ __global__ __launch_bounds__(256) void preshape_sum_kernel(const T* __restrict__
     if (threadIdx.x < 3) partials[(int64_t)blockIdx.x * 3 + threadIdx.x] = r;
 }
 
-// centroid = (sum over partial rows) / n   (single wave)
-__global__ __launch_bounds__(64) void preshape_centroid_kernel(const double* __restrict__ partials, int n_blocks,
-                                                               int64_t n, double* __restrict__ centroid) {
-    const int c = threadIdx.x;
-    if (c >= 3) return;
-    double a = 0.0;
-    for (int r = 0; r < n_blocks; ++r) a += partials[(int64_t)r * 3 + c];
-    centroid[c] = a / (double)n;
+// centroid = (sum over partial rows) / n: 256 lanes stride over the rows, then a fixed-order block sum
+__global__ __launch_bounds__(256) void preshape_centroid_kernel(const double* __restrict__ partials, int n_blocks,
+                                                                int64_t n, double* __restrict__ centroid) {
+    __shared__ double sh[4][3];
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int r = threadIdx.x; r < n_blocks; r += 256) {
+        acc[0] += partials[(int64_t)r * 3];
+        acc[1] += partials[(int64_t)r * 3 + 1];
+        acc[2] += partials[(int64_t)r * 3 + 2];
+    }
+    const double v = block_sum<3>(acc, sh);
+    if (threadIdx.x < 3) centroid[threadIdx.x] = v / (double)n;
 }
 
 template <typename T>
@@ -353,13 +357,19 @@ __global__ __launch_bounds__(256) void preshape_radius_kernel(const T* __restric
     if (threadIdx.x == 0) partials[blockIdx.x] = r;
 }
 
-__global__ __launch_bounds__(64) void sum_columns_kernel(const double* __restrict__ partials, int n_rows, int n_cols,
-                                                         double* __restrict__ out) {
-    const int c = threadIdx.x;
-    if (c >= n_cols) return;
-    double a = 0.0;
-    for (int r = 0; r < n_rows; ++r) a += partials[(int64_t)r * n_cols + c];
-    out[c] = a;
+// out[c] = sum over rows of partials[r][c], n_cols <= NSUMS: lanes stride over the rows (many loads in flight)
+__global__ __launch_bounds__(256) void sum_columns_kernel(const double* __restrict__ partials, int n_rows, int n_cols,
+                                                          double* __restrict__ out) {
+    __shared__ double sh[4][NSUMS];
+    double acc[NSUMS];
+#pragma unroll
+    for (int c = 0; c < NSUMS; ++c) acc[c] = 0.0;
+    for (int r = threadIdx.x; r < n_rows; r += 256)
+#pragma unroll
+        for (int c = 0; c < NSUMS; ++c)
+            if (c < n_cols) acc[c] += partials[(int64_t)r * n_cols + c];
+    const double v = block_sum<NSUMS>(acc, sh);
+    if ((int)threadIdx.x < n_cols) out[threadIdx.x] = v;
 }
 
 // ---- f32 fast path: the cloud is read as a flat array of float4 (16 B per lane, fully coalesced) -------------
@@ -370,6 +380,7 @@ __global__ __launch_bounds__(256) void preshape_sum_f32v_kernel(const float4* __
     __shared__ double sh[4][3];
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;   // sums of the elements whose (j + e) % 3 is 0 / 1 / 2, relative to j % 3 == 0
     double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll 4
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nf4; j += (int64_t)gridDim.x * blockDim.x) {
         const float4 q = v[j];
         const int m = (int)(j % 3);
@@ -399,6 +410,7 @@ __global__ __launch_bounds__(256) void preshape_radius_f32v_kernel(const float4*
         acc[0] += sqrt((xl * xl + yl * yl) + zl * zl);
     };
     const int64_t nv = nf4 > 0 ? nf4 - 1 : 0;   // lanes that may read j + 1
+#pragma unroll 2
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nv; j += (int64_t)gridDim.x * blockDim.x) {
         const float4 a = v[j], b = v[j + 1];
         const int m = (int)(j % 3);
@@ -426,7 +438,7 @@ void launch_preshape_sum(hipStream_t st, const void* d_xyz, int dtype, int64_t n
         hipLaunchKernelGGL(preshape_sum_kernel<float>, dim3(n_blocks), dim3(256), 0, st, (const float*)d_xyz, n, d_partials);
 }
 void launch_preshape_centroid(hipStream_t st, const double* d_partials, int n_blocks, int64_t n, double* d_centroid) {
-    hipLaunchKernelGGL(preshape_centroid_kernel, dim3(1), dim3(64), 0, st, d_partials, n_blocks, n, d_centroid);
+    hipLaunchKernelGGL(preshape_centroid_kernel, dim3(1), dim3(256), 0, st, d_partials, n_blocks, n, d_centroid);
 }
 void launch_preshape_radius(hipStream_t st, const void* d_xyz, int dtype, int64_t n, const double* d_centroid,
                             double* d_partials, int n_blocks) {
@@ -439,7 +451,7 @@ void launch_preshape_radius(hipStream_t st, const void* d_xyz, int dtype, int64_
         hipLaunchKernelGGL(preshape_radius_kernel<float>, dim3(n_blocks), dim3(256), 0, st, (const float*)d_xyz, n, d_centroid, d_partials);
 }
 void launch_sum_columns(hipStream_t st, const double* d_partials, int n_rows, int n_cols, double* d_out) {
-    hipLaunchKernelGGL(sum_columns_kernel, dim3(1), dim3(64), 0, st, d_partials, n_rows, n_cols, d_out);
+    hipLaunchKernelGGL(sum_columns_kernel, dim3(1), dim3(256), 0, st, d_partials, n_rows, n_cols, d_out);
 }
 
 // out[r] = (sum_c partials[r][c]) * scale, one thread per row, columns added in order
