@@ -184,6 +184,7 @@ void launch_grid_build(hipStream_t st, const float4* d_tgt, int n, const GridPar
 // and fill the machine with 16x the waves.
 constexpr int GRID_LPQ_DEFAULT = 1;   // lanes per query; measured on C2 (100k x 100k): 1 / 2 / 4 / 8 / 16
 constexpr int GRID_BS_DEFAULT = 512;  // workgroup size
+constexpr int GRID_PF = 4;            // points of every row fetched up front by the one-lane-per-query path
 
 template <bool FMA>
 __device__ __forceinline__ unsigned long long point_key(const float4 p, float qx, float qy, float qz) {
@@ -309,7 +310,44 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
         int kpos = 0;
         bool done = false;
         // ---- r = 1: the whole 3x3x3 block, 9 rows of <= 3 cells each, every row ONE contiguous range ----
-        {
+        if constexpr (LPQ == 1) {
+            // One lane, nine rows: a row-by-row scan is a chain of ~20 dependent L2 round trips.  Instead issue
+            // ALL 18 range bounds, then the first GRID_PF points of ALL rows (36 float4 in flight; at 1-2 waves
+            // per SIMD the VGPRs are there), and only then compute: three round trips instead of twenty.
+            constexpr int PF = GRID_PF;
+            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, gp.gx - 1);
+            int lo[9], hi[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int z = cz + t / 3 - 1, y = cy + t % 3 - 1;
+                const bool ok = z >= 0 && z < gp.gz && y >= 0 && y < gp.gy;
+                const int row = ok ? (z * gp.gy + y) * gp.gx : 0;
+                lo[t] = cell_start[row + x0];
+                hi[t] = ok ? cell_start[row + x1 + 1] : lo[t];   // empty range for rows outside the grid
+            }
+            float4 pf[9][PF];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+#pragma unroll
+                for (int e = 0; e < PF; ++e) {
+                    // clamped into the row's range (a duplicate cannot change a minimum); an empty row re-reads a
+                    // valid element that the guard below ignores
+                    const int k = hi[t] > lo[t] ? min(lo[t] + e, hi[t] - 1) : 0;
+                    pf[t][e] = sorted[k];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                if (hi[t] > lo[t]) {
+#pragma unroll
+                    for (int e = 0; e < PF; ++e) {
+                        const unsigned long long kk = point_key<FMA>(pf[t][e], qx, qy, qz);
+                        if (kk < key) { key = kk; kpos = min(lo[t] + e, hi[t] - 1); }
+                    }
+                    if (hi[t] - lo[t] > PF) scan_range<FMA>(sorted, lo[t] + PF, hi[t], qx, qy, qz, key, kpos);
+                }
+            }
+        } else {
             const int x0 = max(cx - 1, 0), x1 = min(cx + 1, gp.gx - 1);
 #pragma unroll
             for (int t = sub; t < 9; t += LPQ) {
