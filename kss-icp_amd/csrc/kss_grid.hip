@@ -451,23 +451,22 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
         double r = 0.0;
 #pragma unroll
         for (int w = 0; w < BS / 64; ++w) r += sh[w][threadIdx.x];   // wave order: reproducible
-        partials[(int64_t)blockIdx.x * NSUMS + threadIdx.x] = r;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        // hand-off without an L2 write-back (MI355X_MICROARCH.md, "Valid forms", table row 1): EVERY store of the
+        // handed-off row is a write-through `sc1` store (relaxed agent-scope atomic store), the storing wave drains
+        // them (vmcnt(0)), the workgroup barrier orders that before ONE lane's agent-scope atomic add, and the
+        // workgroup whose add returns the last ticket reads every row with `sc1` loads after its own barrier.
+        // A release fence here would write back all the source / key lines this XCD just dirtied (several us).
+        __hip_atomic_store(&partials[(int64_t)blockIdx.x * NSUMS + threadIdx.x], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         const int tk = atomicAdd(ticket, 1);
-        const int last = tk == (int)gridDim.x - 1;
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        s_last = last;
+        s_last = tk == (int)gridDim.x - 1;
     }
     __syncthreads();
     if (!s_last) return;
-    double v = rows_column_sum(partials, (int)gridDim.x, shg);
+    double v = rows_column_sum_sc1(partials, (int)gridDim.x, shg);
     if (threadIdx.x < NSUMS) {
         if (threadIdx.x == NSUMS - 1) v = (double)__hip_atomic_load(list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sums_out[threadIdx.x] = v;
