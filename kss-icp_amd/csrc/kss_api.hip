@@ -41,7 +41,8 @@ struct kss_ctx {
     // grow-only device workspace
     DevBuf tgt4, src0, cur[2], keys, partials, sums, nn_work, red_work, pair_red, state, cs, scratch_a,
         scratch_b, scratch_c, stage_src, stage_tgt, stage_idx, stage_d2, stage_out, g_counts, g_start, g_cursor,
-        g_bsums, g_sorted, g_list, g_count, g_bbox, g_partials, g_start2, g_pairs;
+        g_bsums, g_sorted, g_list, g_count, g_bbox, g_partials, g_start2, g_pairs, g_stamps;
+    std::vector<unsigned long long> last_stamps;
     // pinned host staging
     void* h_sums = nullptr;  size_t h_sums_cap = 0;   // host-mapped: kernels write it through h_sums_dev
     void* h_sums_dev = nullptr;
@@ -194,7 +195,7 @@ int kss_ctx_destroy(kss_ctx* c) {
     DevBuf* bufs[] = {&c->tgt4, &c->src0, &c->cur[0], &c->cur[1], &c->keys, &c->partials, &c->sums, &c->nn_work,
                       &c->red_work, &c->pair_red, &c->state, &c->cs, &c->scratch_a, &c->scratch_b, &c->scratch_c,
                       &c->stage_src, &c->stage_tgt, &c->stage_idx, &c->stage_d2, &c->stage_out, &c->g_counts, &c->g_start,
-                      &c->g_cursor, &c->g_bsums, &c->g_sorted, &c->g_list, &c->g_count, &c->g_bbox, &c->g_partials, &c->g_start2, &c->g_pairs};
+                      &c->g_cursor, &c->g_bsums, &c->g_sorted, &c->g_list, &c->g_count, &c->g_bbox, &c->g_partials, &c->g_start2, &c->g_pairs, &c->g_stamps};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (c->h_sums) hipHostFree(c->h_sums);
@@ -237,6 +238,13 @@ int kss_grid_stats(kss_ctx* c, double out[8]) {
     if (!c || !out) return KSS_ERR_ARG;
     for (int k = 0; k < 8; ++k) out[k] = c->grid_stats[k];
     return KSS_OK;
+}
+// diagnostic: in-kernel timeline stamps of the last fused grid launch (KSS_GRID_STAMPS=1); not part of the ABI header
+int kss_debug_grid_stamps(kss_ctx* c, unsigned long long* out, int64_t cap) {
+    if (!c || !out) return KSS_ERR_ARG;
+    const int64_t n = std::min<int64_t>(cap, (int64_t)c->last_stamps.size());
+    for (int64_t i = 0; i < n; ++i) out[i] = c->last_stamps[(size_t)i];
+    return (int)n;
 }
 int kss_profile_reset(kss_ctx* c) {
     if (!c) return KSS_ERR_ARG;
@@ -604,16 +612,27 @@ int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, float4*
     if (pl.grid) {
         // single pair: the transform rides in the kernel arguments, the device-side state (active = 1) was
         // uploaded once by grid_setup
+        unsigned long long* stamps = nullptr;
+        const int nblk = grid_nn_blocks((int)pl.g[0].ns);
+        if (getenv("KSS_GRID_STAMPS")) {   // diagnostic build of the timeline (tools/grid_stamps.py)
+            KCHK(ensure(c, c->g_stamps, (size_t)nblk * 8 * sizeof(unsigned long long)));
+            HIPCHK(c, hipMemsetAsync(c->g_stamps.p, 0, (size_t)nblk * 8 * sizeof(unsigned long long), c->stream));
+            stamps = (unsigned long long*)c->g_stamps.p;
+        }
         {
             ProfScope ps(c, KSS_K_GRID_NN);
             // search + correspondence sums + final reduction in ONE launch; sums land in host-mapped memory
             launch_grid_nn(c->stream, fma, hs[0], d_in, d_out, (int)pl.g[0].ns, pl.gp, (const int32_t*)c->g_start.p,
                            (const float4*)c->g_sorted.p, (unsigned long long*)c->keys.p, (int32_t*)c->g_list.p, (int32_t*)c->g_count.p, max_d2,
                            (double*)c->g_partials.p, (int32_t*)c->g_count.p + 1, (double*)c->h_sums_dev, d_idx_out, d_d2_out,
-                           ++c->seq, c->h_seq_dev);
+                           ++c->seq, c->h_seq_dev, stamps);
         }
         HIPCHK(c, hipGetLastError());
         KCHK(wait_seq(c));
+        if (stamps) {
+            c->last_stamps.resize((size_t)nblk * 8);
+            HIPCHK(c, hipMemcpy(c->last_stamps.data(), stamps, c->last_stamps.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        }
         if (((const double*)c->h_sums)[NSUMS - 1] > 0.0) {
             // queries the cell search gave up on (far from the target): brute-force sweep over the list,
             // then the reduce again over every source

@@ -268,7 +268,12 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
                                                       double max_d2, double* __restrict__ partials, int32_t* __restrict__ ticket,
                                                       double* __restrict__ sums_out, int32_t* __restrict__ idx_out,
                                                       float* __restrict__ d2_out, unsigned long long seq,
-                                                      volatile unsigned long long* __restrict__ seq_out) {
+                                                      volatile unsigned long long* __restrict__ seq_out,
+                                                      unsigned long long* __restrict__ stamps) {
+    // diagnostic stamps (100 MHz s_memrealtime; null in production): [block*8 + {0 start, 1 searched, 2 reduced,
+    // 3 ticketed}], last workgroup also [4 summed, 5 published]
+#define KSS_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    KSS_STAMP(0);
     __shared__ double sh[BS / 64][NSUMS];
     __shared__ double shg[ROWSUM_GROUPS][NSUMS];
     __shared__ int s_last;
@@ -431,26 +436,51 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
         }
     }
 
+    KSS_STAMP(1);
     // ---- workgroup partial row, then the last workgroup finishes the job ----
-    // lanes of equal `sub` in the wave's 64/LPQ query groups hold the same components
+    double r = 0.0;
+    if constexpr (LPQ == 1) {
+        // 20 f64 per lane: a shuffle tree costs 240 ds_bpermute + dependent adds per wave (measured ~3 us of a
+        // 20 us kernel).  Transpose through LDS instead: lane t stores column-major (conflict free), 240 lanes each
+        // add one column's rows g, g+12, ... and the 12 group totals are added in group order.
+        __shared__ double shT[NSUMS][BS + 2];
 #pragma unroll
-    for (int j = 0; j < NACC; ++j) {
+        for (int c = 0; c < NSUMS; ++c) shT[c][threadIdx.x] = acc[c];
+        __syncthreads();
+        const int c = threadIdx.x / ROWSUM_GROUPS, g = threadIdx.x % ROWSUM_GROUPS;
+        if (c < NSUMS) {
+            double a0 = 0.0, a1 = 0.0;
+            int k = g;
+            for (; k + ROWSUM_GROUPS < BS; k += 2 * ROWSUM_GROUPS) { a0 += shT[c][k]; a1 += shT[c][k + ROWSUM_GROUPS]; }
+            if (k < BS) a0 += shT[c][k];
+            shg[g][c] = a0 + a1;
+        }
+        __syncthreads();
+        if (threadIdx.x < NSUMS)
+            for (int gg = 0; gg < ROWSUM_GROUPS; ++gg) r += shg[gg][threadIdx.x];
+        __syncthreads();   // shg is reused by the last workgroup below
+    } else {
+        // lanes of equal `sub` in the wave's 64/LPQ query groups hold the same components
 #pragma unroll
-        for (int m = LPQ; m < 64; m <<= 1) acc[j] += __shfl_xor(acc[j], m, 64);
-    }
-    {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        if (lane < LPQ) {
+        for (int j = 0; j < NACC; ++j) {
 #pragma unroll
-            for (int j = 0; j < NACC; ++j)
-                if (lane + j * LPQ < NSUMS) sh[wave][lane + j * LPQ] = acc[j];
+            for (int m = LPQ; m < 64; m <<= 1) acc[j] += __shfl_xor(acc[j], m, 64);
+        }
+        {
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            if (lane < LPQ) {
+#pragma unroll
+                for (int j = 0; j < NACC; ++j)
+                    if (lane + j * LPQ < NSUMS) sh[wave][lane + j * LPQ] = acc[j];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < NSUMS) {
+#pragma unroll
+            for (int w = 0; w < BS / 64; ++w) r += sh[w][threadIdx.x];   // wave order: reproducible
         }
     }
-    __syncthreads();
     if (threadIdx.x < NSUMS) {
-        double r = 0.0;
-#pragma unroll
-        for (int w = 0; w < BS / 64; ++w) r += sh[w][threadIdx.x];   // wave order: reproducible
         // hand-off without an L2 write-back (MI355X_MICROARCH.md, "Valid forms", table row 1): EVERY store of the
         // handed-off row is a write-through `sc1` store (relaxed agent-scope atomic store), the storing wave drains
         // them (vmcnt(0)), the workgroup barrier orders that before ONE lane's agent-scope atomic add, and the
@@ -460,24 +490,30 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+    KSS_STAMP(2);
     if (threadIdx.x == 0) {
         const int tk = atomicAdd(ticket, 1);
         s_last = tk == (int)gridDim.x - 1;
     }
     __syncthreads();
+    KSS_STAMP(3);
     if (!s_last) return;
     double v = rows_column_sum_sc1(partials, (int)gridDim.x, shg);
     if (threadIdx.x < NSUMS) {
         if (threadIdx.x == NSUMS - 1) v = (double)__hip_atomic_load(list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sums_out[threadIdx.x] = v;
-        __threadfence_system();   // the sums are in host memory before the sequence number below
+        // write-through system-scope stores into the host-mapped result: no L2 write-back fence needed
+        __hip_atomic_store(&sums_out[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the sums have left before the sequence number below
+        KSS_STAMP(4);
     }
     __syncthreads();
+    KSS_STAMP(5);
     if (threadIdx.x == 0) {
         *ticket = 0;   // re-arm for the next launch (stream order makes it visible)
         // host-mapped completion flag: the host spins on it instead of paying a stream-sync wake-up per iteration
-        if (seq_out) *seq_out = seq;
+        if (seq_out) __hip_atomic_store((unsigned long long*)seq_out, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+#undef KSS_STAMP
 }
 
 // =============================================================================================
@@ -734,11 +770,11 @@ static void grid_launch_bs(hipStream_t st, int bs, dim3 grid, const PairState& s
                            const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted, unsigned long long* d_keys,
                            int32_t* d_list, int32_t* d_list_count, double max_d2, double* d_partials, int32_t* d_ticket,
                            double* d_sums_out, int32_t* d_idx_out, float* d_d2_out, unsigned long long seq,
-                           unsigned long long* d_seq_out) {
+                           unsigned long long* d_seq_out, unsigned long long* d_stamps) {
 #define KSS_GRID_LAUNCH(BV)                                                                                                  \
     hipLaunchKernelGGL((grid_nn_kernel<FMA, LPQ, BV>), grid, dim3(BV), 0, st, state, d_src_in, d_src_out, ns, gp, d_cell_start, \
                        d_sorted, d_keys, d_list, d_list_count, max_d2, d_partials, d_ticket, d_sums_out, d_idx_out, d_d2_out, seq,  \
-                       d_seq_out)
+                       d_seq_out, d_stamps)
     if (bs == 1024) KSS_GRID_LAUNCH(1024); else if (bs == 512) KSS_GRID_LAUNCH(512); else KSS_GRID_LAUNCH(256);
 #undef KSS_GRID_LAUNCH
 }
@@ -747,11 +783,11 @@ void launch_grid_nn(hipStream_t st, bool fma, const PairState& state, const floa
                     const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted,
                     unsigned long long* d_keys, int32_t* d_list, int32_t* d_list_count, double max_d2, double* d_partials,
                     int32_t* d_ticket, double* d_sums_out, int32_t* d_idx_out, float* d_d2_out, unsigned long long seq,
-                    unsigned long long* d_seq_out) {
+                    unsigned long long* d_seq_out, unsigned long long* d_stamps) {
     const dim3 grid(grid_nn_blocks(ns));
     const int lpq = grid_lpq(), bs = grid_bs();
 #define KSS_GRID_ARGS st, bs, grid, state, d_src_in, d_src_out, ns, gp, d_cell_start, d_sorted, d_keys, d_list, d_list_count, max_d2, \
-                      d_partials, d_ticket, d_sums_out, d_idx_out, d_d2_out, seq, d_seq_out
+                      d_partials, d_ticket, d_sums_out, d_idx_out, d_d2_out, seq, d_seq_out, d_stamps
     if (fma) {
         switch (lpq) {
             case 1: grid_launch_bs<true, 1>(KSS_GRID_ARGS); break;

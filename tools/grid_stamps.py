@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Timeline of the fused grid kernel from in-kernel s_memrealtime stamps (KSS_GRID_STAMPS=1), in microseconds
+relative to the first workgroup's start.  Diagnostic only: the stamps perturb the kernel slightly."""
+import ctypes as C, os, sys
+import numpy as np
+os.environ["KSS_GRID_STAMPS"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as g
+import torch
+pkg = g.load_package(); S = pkg.synth
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+src, tgt = S.make_pair(0, n, R=S.rot_axis_angle([0, 0, 1], np.deg2rad(10.0)))
+ds = torch.from_numpy(src).cuda(); dt = torch.from_numpy(tgt).cuda()
+ctx = pkg.Context(0)
+p = ctx.icp_params(max_iterations=6, fixed_iterations=1, compute_fitness=0)
+ctx.icp_dev(ds.data_ptr(), n, dt.data_ptr(), n, p)
+ctx.icp_dev(ds.data_ptr(), n, dt.data_ptr(), n, p)
+L = pkg.load_library()
+buf = np.zeros(8 * 4096, np.uint64)
+L.kss_debug_grid_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+k = L.kss_debug_grid_stamps(ctx.h, buf.ctypes.data_as(C.c_void_p), buf.size)
+st = buf[:k].reshape(-1, 8).astype(np.int64)
+st = st[st[:, 0] > 0]
+t0 = st[:, 0].min()
+us = lambda a: (a - t0) / 100.0
+names = ["start", "searched", "reduced", "ticketed"]
+print("workgroups:", len(st))
+for i, nm in enumerate(names):
+    v = us(st[:, i])
+    print("%-9s min %7.2f  median %7.2f  max %7.2f us" % (nm, v.min(), np.median(v), v.max()))
+last = st[st[:, 5] > 0]
+if len(last):
+    print("last workgroup: summed %.2f us, published %.2f us" % (us(last[0, 4]), us(last[0, 5])))
+print("search duration per workgroup: median %.2f max %.2f us" % (np.median(us(st[:, 1]) - us(st[:, 0])), (us(st[:, 1]) - us(st[:, 0])).max()))
