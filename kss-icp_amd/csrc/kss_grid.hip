@@ -439,7 +439,7 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
     KSS_STAMP(1);
     // ---- workgroup partial row, then the last workgroup finishes the job ----
     double r = 0.0;
-    if constexpr (LPQ == 1) {
+    if constexpr (LPQ == 1 && BS <= 512) {
         // 20 f64 per lane: a shuffle tree costs 240 ds_bpermute + dependent adds per wave (measured ~3 us of a
         // 20 us kernel).  Transpose through LDS instead: lane t stores column-major (conflict free), 240 lanes each
         // add one column's rows g, g+12, ... and the 12 group totals are added in group order.
