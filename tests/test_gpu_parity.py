@@ -272,3 +272,64 @@ def test_register_matches_oracle_on_reference_pairs(ctx, O, ref_pairs, key):
     assert np.abs(got["R"] - ref["R"]).max() < 1e-5
     assert abs(got["E_d_init"] - ref["E_d_init"]) < 1e-8 and abs(got["final_fitness"] - ref["final_fitness"]) < 1e-8
     assert np.abs(got["pointAlign"] - ref["pointAlign"]).max() < 1e-4
+
+
+# ---- C-ABI argument checking and the RCCL record gather -----------------------------------------------------------
+def test_abi_rejects_bad_arguments(ctx, pkg):
+    import ctypes as C
+    L = pkg.load_library()
+    a = np.zeros((4, 3), np.float32)
+    out = np.zeros(8, np.float64)
+    vp = lambda x: x.ctypes.data_as(C.c_void_p)
+    assert L.kss_nn(ctx.h, None, 4, vp(a), 4, None, None) == -1                  # null cloud
+    assert L.kss_nn(ctx.h, vp(a), -1, vp(a), 4, None, None) == -1                # negative size
+    assert L.kss_preshape_stats(ctx.h, vp(a), 7, 4, vp(out), C.byref(C.c_double())) == -1      # bad dtype
+    assert L.kss_preshape_stats(ctx.h, vp(a), 0, 0, vp(out), C.byref(C.c_double())) == -1      # empty cloud
+    idx = np.array([0, 1, 2, 9], np.int32)
+    assert L.kss_cov(ctx.h, vp(a), vp(a), vp(idx), 4, 4, 1.0, vp(np.zeros(20))) == -1          # index out of range
+    g = C.c_int(0)
+    d = np.zeros((4, 3), np.float64)
+    assert L.kss_rotation_search(ctx.h, vp(d), 4, vp(d), 4, 8.0, vp(np.zeros(10)), 10, C.byref(g)) == -5   # err buffer too small
+    assert L.kss_ctx_set_nn_mode(ctx.h, 7) == -1
+    assert b"" != L.kss_last_error(ctx.h)
+    assert L.kss_ctx_create(99, C.byref(C.c_void_p())) == -1                      # no such device
+    assert L.kss_rigid_from_sums(vp(np.zeros(20)), vp(np.zeros(16, np.float32))) == -1         # zero correspondences
+
+
+def test_gather_results_over_rccl_single_rank(ctx, pkg):
+    """kss_gather_results with a real ncclComm_t (one rank: the collective degenerates to a copy, but the dlopen of
+    librccl, the symbol lookup, the staging and the stream handling are the ones N ranks use)."""
+    import ctypes as C
+    import torch  # noqa: F401  (loads torch's librccl so that dlopen("librccl.so") resolves to the same library)
+    rccl = None
+    for name in ("librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"):
+        try:
+            rccl = C.CDLL(name)
+            break
+        except OSError:
+            continue
+    if rccl is None:
+        import os, torch as _t
+        rccl = C.CDLL(os.path.join(os.path.dirname(_t.__file__), "lib", "librccl.so"))
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    n = 5
+    local = (pkg.IcpResult * n)()
+    for i in range(n):
+        local[i].pair_id = i; local[i].fitness = 0.25 * i; local[i].iterations = 10 + i
+        for k in range(16):
+            local[i].T[k] = float(i * 16 + k)
+    allr = (pkg.IcpResult * n)()
+    L = pkg.load_library()
+    rc = L.kss_gather_results(ctx.h, comm, 1, C.cast(local, C.c_void_p), n, C.cast(allr, C.c_void_p))
+    assert rc == 0, L.kss_last_error(ctx.h)
+    for i in range(n):
+        assert allr[i].pair_id == i and allr[i].fitness == 0.25 * i and allr[i].iterations == 10 + i and allr[i].T[7] == float(i * 16 + 7)
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)

@@ -43,6 +43,20 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
                 asm volatile("v_sub_f32 %0, %0, %8\n v_sub_f32 %1, %1, %8\n v_sub_f32 %2, %2, %8\n v_sub_f32 %3, %3, %8\n"
                              "v_sub_f32 %4, %4, %8\n v_sub_f32 %5, %5, %8\n v_sub_f32 %6, %6, %8\n v_sub_f32 %7, %7, %8\n"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
+            } else if (MODE == 8) {  // v_min_u32
+                asm volatile("v_min_u32 %0, %0, %8\n v_min_u32 %1, %1, %8\n v_min_u32 %2, %2, %8\n v_min_u32 %3, %3, %8\n"
+                             "v_min_u32 %4, %4, %8\n v_min_u32 %5, %5, %8\n v_min_u32 %6, %6, %8\n v_min_u32 %7, %7, %8\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+            } else if (MODE == 9) {  // v_min3_u32
+                asm volatile("v_min3_u32 %0, %0, %8, %9\n v_min3_u32 %1, %1, %8, %9\n v_min3_u32 %2, %2, %8, %9\n v_min3_u32 %3, %3, %8, %9\n"
+                             "v_min3_u32 %4, %4, %8, %9\n v_min3_u32 %5, %5, %8, %9\n v_min3_u32 %6, %6, %8, %9\n v_min3_u32 %7, %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            } else if (MODE == 10) {  // v_pk_add_f32 with neg + op_sel broadcast of the low half of src1 (the shape the NN sweep needs)
+                asm volatile("v_pk_add_f32 %0, %0, %4 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %1, %1, %4 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+                             "v_pk_add_f32 %2, %2, %4 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %3, %3, %4 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+                             "v_pk_add_f32 %0, %0, %4 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %1, %1, %4 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+                             "v_pk_add_f32 %2, %2, %4 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %3, %3, %4 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pc));
             } else if (MODE == 7) {  // v_min_f32
                 asm volatile("v_min_f32 %0, %0, %8\n v_min_f32 %1, %1, %8\n v_min_f32 %2, %2, %8\n v_min_f32 %3, %3, %8\n"
                              "v_min_f32 %4, %4, %8\n v_min_f32 %5, %5, %8\n v_min_f32 %6, %6, %8\n v_min_f32 %7, %7, %8\n"
@@ -75,12 +89,15 @@ double run(const char* name, int lanes_per_instr, int blocks, float* d_out) {
 int main() {
     float* d_out;
     hipMalloc(&d_out, sizeof(float) * 256 * 8192);
-    for (int blocks : {256 * 2, 256 * 4, 256 * 8}) {
+    for (int blocks : {256 * 4, 256 * 8}) {
         run<0>("v_fma_f32", 1, blocks, d_out);
         run<1>("v_mul_f32", 1, blocks, d_out);
         run<6>("v_sub_f32", 1, blocks, d_out);
         run<7>("v_min_f32", 1, blocks, d_out);
         run<5>("v_min3_f32", 1, blocks, d_out);
+        run<8>("v_min_u32", 1, blocks, d_out);
+        run<9>("v_min3_u32", 1, blocks, d_out);
+        run<10>("v_pk_add bcast", 2, blocks, d_out);
         run<2>("v_pk_mul_f32", 2, blocks, d_out);
         run<4>("v_pk_add_f32", 2, blocks, d_out);
         run<3>("v_pk_fma_f32", 2, blocks, d_out);
