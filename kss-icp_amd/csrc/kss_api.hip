@@ -457,7 +457,8 @@ static void choose_cells(const float mn[3], const float mx[3], int64_t nt, GridP
     gp.gz = std::max(1, std::min(256, (int)std::floor(ext[2] / h) + 1));
     const float mag = std::max(std::max(std::fabs(mn[0]), std::fabs(mx[0])), std::max(std::max(std::fabs(mn[1]), std::fabs(mx[1])), std::max(std::fabs(mn[2]), std::fabs(mx[2]))));
     gp.eps = 2e-6f * (mag + emax) + 1e-30f;
-    gp.rcap = 12;
+    gp.rcap = 4;   // shells before a query goes to the brute-force list (measured on badly initialised pairs: tools/hard_case.py)
+    if (const char* e = getenv("KSS_GRID_RCAP")) { const int v = atoi(e); if (v >= 1 && v <= 64) gp.rcap = v; }   // tuning hook
 }
 
 // Build the uniform cell list over the (single) target: bbox -> cell size -> counting sort.
