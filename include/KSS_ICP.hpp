@@ -6,9 +6,9 @@
 // (:155-162 and four copies) becomes one kss_icp call; KSSICP_Registration's pose search + candidate ICP
 // batch + final ICP (:86-131) is one kss_register call.  Written from scratch; no reference code.
 //
-// Down-sampling (:71-81): the reference uses AIVS (Method_AIVS_SimPro.hpp), the component immediately
-// upstream of the hot path (not yet built).  Until it is, kss_downsample_fps (exact
-// farthest-point sampling on the device) produces the pNumber-point S', T'.
+// Down-sampling (:71-81): AIVS on the device (kss_downsample_aivs: the reference's voxel grid, 8-colour per-voxel
+// farthest-point sampling and accurate cut).  Clouds the reference cannot voxelise (zero extent along an axis:
+// it divides by zero) fall back to kss_downsample_fps, exact farthest-point sampling.
 #pragma once
 #include <fstream>
 #include <iostream>
@@ -116,9 +116,18 @@ private:
     }
 
     static std::vector<std::vector<double>> downsample(const std::vector<std::vector<double>>& cloud, int m) {
-        if (m <= 0 || (size_t)m >= cloud.size()) return cloud;
-        std::vector<double> in = kss_host::pack(cloud), out((size_t)m * 3);
-        kss_host::Runtime::check(kss_downsample_fps(kss_host::Runtime::ctx(), in.data(), (int64_t)cloud.size(), m, out.data(), nullptr), "kss_downsample_fps");
+        if (m <= 0 || cloud.empty()) return cloud;
+        std::vector<double> in = kss_host::pack(cloud), out(in.size());
+        int64_t k = 0;
+        const int rc = kss_downsample_aivs(kss_host::Runtime::ctx(), in.data(), (int64_t)cloud.size(), m, out.data(), (int64_t)cloud.size(), &k, nullptr);
+        if (rc == KSS_ERR_ARG && (size_t)m < cloud.size()) {   // degenerate extent: the reference would divide by zero
+            std::cout << "AIVS: degenerate cloud, farthest-point sampling instead" << std::endl;
+            kss_host::Runtime::check(kss_downsample_fps(kss_host::Runtime::ctx(), in.data(), (int64_t)cloud.size(), m, out.data(), nullptr), "kss_downsample_fps");
+            k = m;
+        } else {
+            kss_host::Runtime::check(rc, "kss_downsample_aivs");
+        }
+        out.resize((size_t)k * 3);
         return kss_host::unpack(out);
     }
 

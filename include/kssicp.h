@@ -199,6 +199,18 @@ int kss_transform_apply_f32(kss_ctx *ctx, const float T[16], const float *in, in
  *  and is the next component to build; this keeps KSSICP_Registration drop-in. */
 int kss_downsample_fps(kss_ctx *ctx, const double *xyz, int64_t n, int64_t m, double *out, int32_t *out_idx);
 
+/* ---- AIVS down-sampler: pointPipeline_init_point_withoutUniform + BallRegion_init_withoutNormal +
+ *      AIVS_Pro_init + AIVS_simplification(point_num), KSS_ICP.hpp:71-81 (Method_AIVS_SimPro.hpp:94-154,
+ *      ballRegionCompute.hpp:114-147) ----
+ * Voxel grid, per-voxel farthest-point sampling in the reference's 8-colour order (one launch per colour, one
+ * wavefront per voxel) and the accurate cut, with the reference's arithmetic.  out must hold capacity points;
+ * *n_out receives the number selected, which can differ from point_num exactly as in the reference (fewer if the
+ * per-voxel budgets add up to less; more if the accurate cut runs out of live closest pairs).  out_idx (may be
+ * NULL) receives the indices into xyz.  KSS_ERR_ARG for degenerate (zero-extent / planar) clouds, which divide by
+ * zero in the reference; KSS_ERR_CAPACITY if capacity is too small. */
+int kss_downsample_aivs(kss_ctx *ctx, const double *xyz, int64_t n, int64_t point_num, double *out, int64_t capacity,
+                        int64_t *n_out, int32_t *out_idx);
+
 /* ---- PCR_QM: registrationMeasure.hpp:47-98 -> out = {MSE, RMSE, MAE} ---- */
 int kss_pcr_qm(kss_ctx *ctx, const double *aligned, int64_t na, const double *tmpl, int64_t nt,
                double out[3]);

@@ -24,7 +24,7 @@ SYMBOLS = [
     "kss_nn", "kss_nn_dev", "kss_cov", "kss_cov_dev", "kss_rigid_from_sums", "kss_rotation_search",
     "kss_rotation_search_dev", "kss_grid_angles", "kss_rotation_candidates", "kss_icp_default_params", "kss_icp",
     "kss_icp_dev", "kss_icp_batch", "kss_icp_batch_dev", "kss_transform_apply", "kss_transform_apply_dev",
-    "kss_pcr_qm", "kss_register", "kss_gather_results", "kss_transform_apply_f32", "kss_downsample_fps",
+    "kss_pcr_qm", "kss_register", "kss_gather_results", "kss_transform_apply_f32", "kss_downsample_fps", "kss_downsample_aivs",
 ]
 
 
@@ -129,6 +129,7 @@ def load_library():
     L.kss_pcr_qm.argtypes = [vp, vp, i64, vp, i64, vp]
     L.kss_transform_apply_f32.argtypes = [vp, vp, vp, i64, vp]
     L.kss_downsample_fps.argtypes = [vp, vp, i64, i64, vp, vp]
+    L.kss_downsample_aivs.argtypes = [vp, vp, i64, i64, vp, i64, C.POINTER(i64), vp]
     L.kss_register.argtypes = [vp, vp, i64, vp, i64, vp, i64, dbl, C.c_int, vp, C.POINTER(RegisterResult)]
     L.kss_gather_results.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
     _LIB = L
@@ -378,6 +379,14 @@ class Context:
         idx = np.empty(int(m), np.int32)
         self._chk(self.L.kss_downsample_fps(self.h, _p(a), len(a), int(m), _p(out), _p(idx)), "kss_downsample_fps")
         return out, idx
+
+    def downsample_aivs(self, pts, point_num):
+        a = _f64(pts)
+        out = np.empty_like(a)
+        idx = np.empty(len(a), np.int32)
+        k = C.c_int64(0)
+        self._chk(self.L.kss_downsample_aivs(self.h, _p(a), len(a), int(point_num), _p(out), len(a), C.byref(k), _p(idx)), "kss_downsample_aivs")
+        return out[:k.value].copy(), idx[:k.value].copy()
 
     # ---- PCR_QM
     def pcr_qm(self, aligned, tmpl):

@@ -1,0 +1,474 @@
+// kss_aivs.hip -- AIVS down-sampler on the GPU (the component immediately upstream of
+// the registration hot path).  Replaces, with the same arithmetic and the same selection order:
+//   pointPipeline_init_point_withoutUniform (pointPipeline.hpp:88-101, border :105-160),
+//   BallRegion_init_withoutNormal (ballRegionCompute.hpp:114-147): AchieveXYZ :690-758, BoxInput :632-688,
+//     box centres :1150-1172, neighbour boxes :975-1031 (quirks of the last x column included), scale :1194-1215,
+//   AIVS_simplification (Method_AIVS_SimPro.hpp:94-154): 8-colour schedule :587-643, per-box budget :776-794,
+//     per-voxel farthest-point sampling AIVS_Voroni_OpenMP_KNN :222-376, AIVS_AccurateCut_Optimization :848-957.
+// Not built: the K=13 self-kNN radius estimate (ballRegionCompute.hpp:477-530); nothing on this path reads it.
+//
+// Mapping: the reference runs the boxes of one colour in an OpenMP loop (8 sequential colours, because a box reads
+// the samples already placed in its 26 neighbours); here each colour is one launch with ONE WAVE PER BOX.  Boxes
+// hold tens of points, so a wave keeps a box's running min-distances in registers/global and picks the next
+// sample with a wave-wide arg-max (first maximum wins, as the serial scan does).  Distances are the reference's:
+// float PointXYZ, d2 = (dx*dx + dy*dy) + dz*dz without fma, then sqrt(float) (correctly rounded on gfx950).
+#pragma clang fp contract(off)
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "kss_internal.hpp"
+
+namespace kss {
+
+struct AivsGrid {
+    int nx, ny, nz, nboxes;   // boxes are 1-based: index = x + nx*(y-1) + nx*ny*(z-1); slot 0 unused
+    double minx, miny, minz, unit;
+    double rate, search_radius;
+};
+
+// ---- bounding box (f64) ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void aivs_bbox_kernel(const double* __restrict__ P, int n, double* __restrict__ partial) {
+    __shared__ double sh[4][6];
+    double mn[3] = {__builtin_inf(), __builtin_inf(), __builtin_inf()}, mx[3] = {-__builtin_inf(), -__builtin_inf(), -__builtin_inf()};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        for (int k = 0; k < 3; ++k) {
+            const double v = P[3 * (int64_t)i + k];
+            mn[k] = fmin(mn[k], v);
+            mx[k] = fmax(mx[k], v);
+        }
+    for (int off = 32; off > 0; off >>= 1)
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = fmin(mn[k], __shfl_down(mn[k], off, 64));
+            mx[k] = fmax(mx[k], __shfl_down(mx[k], off, 64));
+        }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+        for (int k = 0; k < 3; ++k) { sh[wave][k] = mn[k]; sh[wave][3 + k] = mx[k]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double v = sh[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fmin(v, sh[w][threadIdx.x]) : fmax(v, sh[w][threadIdx.x]);
+        partial[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+// ---- box of a point: BallRegion_BoxInput, ballRegionCompute.hpp:646-664 -------------------------------------------
+__device__ __forceinline__ int aivs_box_of(const double* __restrict__ P, int i, const AivsGrid& g) {
+    const double xNum = (P[3 * (int64_t)i] - g.minx) / g.unit, yNum = (P[3 * (int64_t)i + 1] - g.miny) / g.unit,
+                 zNum = (P[3 * (int64_t)i + 2] - g.minz) / g.unit;
+    int xi = (int)xNum, yi = (int)yNum, zi = (int)zNum;
+    if (xi < xNum || xi == 0) xi++;
+    if (yi < yNum || yi == 0) yi++;
+    if (zi < zNum || zi == 0) zi++;
+    return xi + g.nx * (yi - 1) + g.nx * g.ny * (zi - 1);
+}
+
+__global__ __launch_bounds__(256) void aivs_count_kernel(const double* __restrict__ P, int n, AivsGrid g, int32_t* __restrict__ box_of,
+                                                         int32_t* __restrict__ counts, int32_t* __restrict__ bad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = aivs_box_of(P, i, g);
+    if (b < 0 || b > g.nboxes) { atomicAdd(bad, 1); box_of[i] = 0; return; }   // the reference prints "Hello!" and indexes out of range
+    box_of[i] = b;
+    atomicAdd(&counts[b], 1);
+}
+
+__global__ __launch_bounds__(256) void aivs_scatter_kernel(const int32_t* __restrict__ box_of, int n, int32_t* __restrict__ cursor,
+                                                           int32_t* __restrict__ members_tmp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    members_tmp[atomicAdd(&cursor[box_of[i]], 1)] = i;
+}
+
+// squareBoxes[b] holds its points in push_back (= ascending index) order: rank every member inside its box
+__global__ __launch_bounds__(256) void aivs_rank_kernel(const int32_t* __restrict__ members_tmp, const int32_t* __restrict__ box_of, int n,
+                                                        const int32_t* __restrict__ start, int32_t* __restrict__ members) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int me = members_tmp[j];
+    const int b = box_of[me];
+    const int lo = start[b], hi = start[b + 1];
+    int rank = 0;
+    for (int k = lo; k < hi; ++k) rank += members_tmp[k] < me ? 1 : 0;
+    members[lo + rank] = me;
+}
+
+__device__ __forceinline__ void aivs_box_center(const AivsGrid& g, int boxIndex, double c[3]) {   // :1150-1172
+    int z_num = boxIndex / (g.nx * g.ny) + 1;
+    const int leveZ = boxIndex % (g.nx * g.ny);
+    int y_num = leveZ / g.nx + 1;
+    int x_num = leveZ % g.nx;
+    if (x_num == 0) { x_num = g.nx; y_num = y_num - 1; }
+    c[0] = (g.minx + (x_num - 1) * g.unit + g.minx + x_num * g.unit) / 2;
+    c[1] = (g.miny + (y_num - 1) * g.unit + g.miny + y_num * g.unit) / 2;
+    c[2] = (g.minz + (z_num - 1) * g.unit + g.minz + z_num * g.unit) / 2;
+}
+
+// per box: the member closest to the box centre (:634-686, strict '>' keeps the first minimum) and the sampling
+// budget (Method_AIVS_SimPro.hpp:776-794)
+__global__ __launch_bounds__(256) void aivs_box_info_kernel(const double* __restrict__ P, AivsGrid g, const int32_t* __restrict__ start,
+                                                            const int32_t* __restrict__ members, int32_t* __restrict__ center_pos,
+                                                            int32_t* __restrict__ sim_num) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > g.nboxes) return;
+    double c[3];
+    aivs_box_center(g, b, c);
+    double best = 9999;
+    int pos = -1;
+    const int lo = start[b], hi = start[b + 1];
+    for (int k = lo; k < hi; ++k) {
+        const int i = members[k];
+        const double dx = c[0] - P[3 * (int64_t)i], dy = c[1] - P[3 * (int64_t)i + 1], dz = c[2] - P[3 * (int64_t)i + 2];
+        const double d = sqrt(dx * dx + dy * dy + dz * dz);
+        if (best > d) { best = d; pos = k - lo; }
+    }
+    center_pos[b] = pos;
+    const double simBox = (double)(hi - lo) * g.rate;
+    const int t = (int)simBox;
+    sim_num[b] = (simBox - t > 0.2) ? t + 1 : t;
+}
+
+__device__ __forceinline__ float aivs_dist(const double* __restrict__ P, int a, int b) {
+    const float ax = (float)P[3 * (int64_t)a], ay = (float)P[3 * (int64_t)a + 1], az = (float)P[3 * (int64_t)a + 2];
+    const float bx = (float)P[3 * (int64_t)b], by = (float)P[3 * (int64_t)b + 1], bz = (float)P[3 * (int64_t)b + 2];
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return sqrtf((dx * dx + dy * dy) + dz * dz);
+}
+
+__device__ __forceinline__ int aivs_neighbor_boxes(const AivsGrid& g, int boxIndex, int out[26]) {   // :975-1031, quirks kept
+    const int z_num = boxIndex / (g.nx * g.ny) + 1;
+    const int leveZ = boxIndex % (g.nx * g.ny);
+    const int y_num = leveZ / g.nx + 1;
+    const int x_num = leveZ % g.nx;   // not wrapped for the last x column, exactly as the reference
+    int xs[3], ys[3], zs[3], nxs = 0, nys = 0, nzs = 0;
+    if (x_num > 1) xs[nxs++] = x_num - 1;
+    xs[nxs++] = x_num;
+    if (x_num < g.nx) xs[nxs++] = x_num + 1;
+    if (y_num > 1) ys[nys++] = y_num - 1;
+    ys[nys++] = y_num;
+    if (y_num < g.ny) ys[nys++] = y_num + 1;
+    if (z_num > 1) zs[nzs++] = z_num - 1;
+    zs[nzs++] = z_num;
+    if (z_num < g.nz) zs[nzs++] = z_num + 1;
+    int m = 0;
+    for (int i = 0; i < nxs; ++i)
+        for (int j = 0; j < nys; ++j)
+            for (int k = 0; k < nzs; ++k) {
+                if (xs[i] == x_num && ys[j] == y_num && zs[k] == z_num) continue;
+                const int idx = xs[i] + (ys[j] - 1) * g.nx + (zs[k] - 1) * g.nx * g.ny;
+                if (idx < g.nboxes + 1 && idx >= 0) out[m++] = idx;
+            }
+    return m;
+}
+
+// ---- one colour of AIVS_Voroni_OpenMP_KNN: one wave per box ------------------------------------------------------
+__global__ __launch_bounds__(64) void aivs_fps_kernel(const double* __restrict__ P, AivsGrid g, int ox, int oy, int oz,
+                                                      const int32_t* __restrict__ start, const int32_t* __restrict__ members,
+                                                      const int32_t* __restrict__ center_pos, const int32_t* __restrict__ sim_num,
+                                                      uint8_t* __restrict__ labelG, double* __restrict__ mind,
+                                                      int32_t* __restrict__ simiT, int32_t* __restrict__ n_samples) {
+    // blockIdx -> the box (i, j, k) of this colour class: i = 2*bx + ox (1-based, ox in {1, 2}) etc.
+    const int hx = (g.nx - ox) / 2 + 1, hy = (g.ny - oy) / 2 + 1;
+    const int bi = blockIdx.x % hx, bj = (blockIdx.x / hx) % hy, bk = blockIdx.x / (hx * hy);
+    const int i = 2 * bi + ox, j = 2 * bj + oy, k = 2 * bk + oz;
+    if (i > g.nx || j > g.ny || k > g.nz) return;
+    const int b = i + g.nx * (j - 1) + g.nx * g.ny * (k - 1);
+    const int lo = start[b], m = start[b + 1] - lo;
+    const int simNum = sim_num[b];
+    if (m == 0 || simNum == 0) return;
+    const int lane = threadIdx.x;
+    double pc[3];
+    aivs_box_center(g, b, pc);
+    const double R = g.search_radius;
+    int nbr[26];
+    const int nn = aivs_neighbor_boxes(g, b, nbr);
+
+    // already-sampled points of the neighbour boxes inside the search cube ("label 2"): is there any?
+    int found = 0;
+    for (int q = 0; q < nn; ++q) {
+        const int s0 = start[nbr[q]], s1 = start[nbr[q] + 1];
+        for (int l = s0 + lane; l < s1; l += 64) {
+            const int pi = members[l];
+            const double x = P[3 * (int64_t)pi], y = P[3 * (int64_t)pi + 1], z = P[3 * (int64_t)pi + 2];
+            if (x <= pc[0] + R && x >= pc[0] - R && y <= pc[1] + R && y >= pc[1] - R && z <= pc[2] + R && z >= pc[2] - R && labelG[pi] == 0) found = 1;
+        }
+    }
+    const bool any_l2 = __any(found);
+    const int cpos = center_pos[b];
+    const int seed_pos = (!any_l2 && cpos >= 0 && cpos < m) ? cpos : -1;   // addJ: seed the box centre only if no neighbour sample
+    const int seed_pt = seed_pos >= 0 ? members[lo + seed_pos] : -1;
+
+    // initial min-distance of every own point to the label-0/2 set
+    for (int k2 = lane; k2 < m; k2 += 64) {
+        const int me = members[lo + k2];
+        double mt;
+        if (k2 == seed_pos) {
+            mt = 0;
+        } else {
+            float best = __builtin_inff();
+            if (seed_pt >= 0) best = aivs_dist(P, me, seed_pt);
+            if (any_l2)
+                for (int q = 0; q < nn; ++q) {
+                    const int s0 = start[nbr[q]], s1 = start[nbr[q] + 1];
+                    for (int l = s0; l < s1; ++l) {
+                        const int pi = members[l];
+                        const double x = P[3 * (int64_t)pi], y = P[3 * (int64_t)pi + 1], z = P[3 * (int64_t)pi + 2];
+                        if (x <= pc[0] + R && x >= pc[0] - R && y <= pc[1] + R && y >= pc[1] - R && z <= pc[2] + R && z >= pc[2] - R &&
+                            labelG[pi] == 0) {
+                            const float d = aivs_dist(P, me, pi);
+                            if (d < best) best = d;
+                        }
+                    }
+                }
+            mt = best == __builtin_inff() ? 9999.0 : (double)best;
+        }
+        mind[lo + k2] = mt;
+    }
+    // Every own point k2 is read and written ONLY by its owner lane (k2 % 64): no lane ever depends on another
+    // lane's global stores; selections travel through shuffles.
+    int sample_index = 0;
+    if (seed_pos >= 0) {
+        if (lane == (seed_pos & 63)) { simiT[lo] = seed_pt; labelG[seed_pt] = 0; }
+        sample_index = 1;
+    }
+    // farthest-point loop: first maximum of mind over the still-unsampled own points (serial scan order)
+    while (sample_index < simNum) {
+        double bv = 0;
+        int bk2 = 0x7fffffff;
+        for (int k2 = lane; k2 < m; k2 += 64) {
+            const int me = members[lo + k2];
+            const double v = mind[lo + k2];
+            if (labelG[me] == 1 && v > bv) { bv = v; bk2 = k2; }   // ascending k2 per lane: first maximum kept
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(bv, off, 64);
+            const int ok = __shfl_xor(bk2, off, 64);
+            if (ov > bv || (ov == bv && ok < bk2)) { bv = ov; bk2 = ok; }
+        }
+        if (bk2 == 0x7fffffff) break;   // nothing left (indexSelect == -1)
+        const int sel = members[lo + bk2];
+        if (lane == (bk2 & 63)) { mind[lo + bk2] = 0; labelG[sel] = 0; simiT[lo + sample_index] = sel; }
+        ++sample_index;
+        for (int k2 = lane; k2 < m; k2 += 64) {
+            const int me = members[lo + k2];
+            if (k2 != bk2 && labelG[me] == 1) {
+                const double d = (double)aivs_dist(P, me, sel);
+                if (d < mind[lo + k2]) mind[lo + k2] = d;
+            }
+        }
+    }
+    if (lane == 0) n_samples[b] = sample_index;
+}
+
+// ---- accurate cut: K = 3 self-kNN among the samples (brute force; ties -> lower index) -----------------------------
+__global__ __launch_bounds__(256) void aivs_knn3_kernel(const double* __restrict__ P, const int32_t* __restrict__ samples, int ns,
+                                                        int32_t* __restrict__ nn1, float* __restrict__ d1, float* __restrict__ d2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    const int pi = samples[i];
+    const float ax = (float)P[3 * (int64_t)pi], ay = (float)P[3 * (int64_t)pi + 1], az = (float)P[3 * (int64_t)pi + 2];
+    float bd0 = __builtin_inff(), bd1 = __builtin_inff(), bd2 = __builtin_inff();
+    int bi0 = -1, bi1 = -1, bi2 = -1;
+    for (int j = 0; j < ns; ++j) {
+        const int pj = samples[j];
+        const float dx = ax - (float)P[3 * (int64_t)pj], dy = ay - (float)P[3 * (int64_t)pj + 1], dz = az - (float)P[3 * (int64_t)pj + 2];
+        const float d = (dx * dx + dy * dy) + dz * dz;
+        if (d < bd2) {   // stable insertion: equal distances keep the lower index first
+            if (d < bd1) {
+                bd2 = bd1; bi2 = bi1;
+                if (d < bd0) { bd1 = bd0; bi1 = bi0; bd0 = d; bi0 = j; }
+                else { bd1 = d; bi1 = j; }
+            } else { bd2 = d; bi2 = j; }
+        }
+    }
+    (void)bi0; (void)bi2;
+    nn1[i] = bi1;
+    d1[i] = sqrtf(bd1);
+    d2[i] = sqrtf(bd2);
+}
+
+// exclusive scan of small int arrays on one workgroup (boxes <= ~125k + 2): used for box starts and sample offsets
+__global__ __launch_bounds__(1024) void aivs_scan_kernel(const int32_t* __restrict__ in, int n, int32_t* __restrict__ out) {
+    __shared__ int sh[1024];
+    const int per = (n + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(n, lo + per);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += in[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = threadIdx.x > 0 ? sh[threadIdx.x - 1] : 0;
+    for (int i = lo; i < hi; ++i) { const int v = in[i]; out[i] = run; run += v; }
+    if (threadIdx.x == 1023) out[n] = sh[1023];
+}
+
+__global__ __launch_bounds__(256) void aivs_gather_samples_kernel(const int32_t* __restrict__ start, const int32_t* __restrict__ n_samples,
+                                                                  const int32_t* __restrict__ sample_off, const int32_t* __restrict__ simiT,
+                                                                  int nboxes1, int32_t* __restrict__ samples) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nboxes1) return;
+    const int k = n_samples[b], o = sample_off[b], lo = start[b];
+    for (int t = 0; t < k; ++t) samples[o + t] = simiT[lo + t];
+}
+
+#define AIVS_HIP(call)                                                                                   \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e_); rc = KSS_ERR_HIP; goto done; } \
+    } while (0)
+
+// Host driver.  d_xyz: n packed f64 points on the device.  out_idx: indices of the selected points in the
+// reference's output order.  Scratch is allocated per call (down-sampling runs once per cloud, not per iteration).
+int aivs_device(hipStream_t st, const double* d_xyz, int n, int point_num, std::vector<int32_t>& out_idx, std::string& err) {
+    int rc = KSS_OK;
+    out_idx.clear();
+    double* d_bbox = nullptr;
+    int32_t *d_box_of = nullptr, *d_counts = nullptr, *d_start = nullptr, *d_cursor = nullptr, *d_tmp = nullptr, *d_members = nullptr,
+            *d_center = nullptr, *d_sim = nullptr, *d_simiT = nullptr, *d_nsamp = nullptr, *d_soff = nullptr, *d_samples = nullptr,
+            *d_nn1 = nullptr, *d_bad = nullptr;
+    uint8_t* d_label = nullptr;
+    double* d_mind = nullptr;
+    float *d_d1 = nullptr, *d_d2 = nullptr;
+    std::vector<double> hb(64 * 6);
+    std::vector<int32_t> samples;
+    AivsGrid g;
+    int nb1 = 0, ns = 0;
+    {
+        AIVS_HIP(hipMalloc(&d_bbox, 64 * 6 * sizeof(double)));
+        hipLaunchKernelGGL(aivs_bbox_kernel, dim3(64), dim3(256), 0, st, d_xyz, n, d_bbox);
+        AIVS_HIP(hipMemcpyAsync(hb.data(), d_bbox, hb.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        AIVS_HIP(hipStreamSynchronize(st));
+        double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int b = 0; b < 64; ++b)
+            for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], hb[b * 6 + k]); mx[k] = std::max(mx[k], hb[b * 6 + 3 + k]); }
+        // BallRegion_EstimateBoxScale :1194-1215 and BallRegion_AchieveXYZ :690-758
+        int boxNum;
+        if (n < 10000) boxNum = 10;
+        else if (n < 50000) boxNum = 20;
+        else if (n < 100000) boxNum = 30;
+        else if (n < 500000) boxNum = 40;
+        else if (n < 1000000) boxNum = 50;
+        else boxNum = (int)std::pow((double)n / 8.0, 1.0 / 3.0);
+        g.minx = mn[0]; g.miny = mn[1]; g.minz = mn[2];
+        const double x_dis = std::fabs(mx[0] - mn[0]), y_dis = std::fabs(mx[1] - mn[1]), z_dis = std::fabs(mx[2] - mn[2]);
+        double large = x_dis;
+        if (large < y_dis) large = y_dis;
+        if (large < z_dis) large = z_dis;
+        g.unit = large / (double)boxNum;
+        if (!(g.unit > 0) || !std::isfinite(g.unit)) { err = "aivs: degenerate cloud (zero extent)"; rc = KSS_ERR_ARG; goto done; }
+        const double numX = x_dis / g.unit, numY = y_dis / g.unit, numZ = z_dis / g.unit;
+        g.nx = (int)numX; g.ny = (int)numY; g.nz = (int)numZ;
+        if (numX > (double)g.nx) g.nx++;
+        if (numY > (double)g.ny) g.ny++;
+        if (numZ > (double)g.nz) g.nz++;
+        if (g.nx < 1 || g.ny < 1 || g.nz < 1) { err = "aivs: planar cloud (the reference divides into zero boxes)"; rc = KSS_ERR_ARG; goto done; }
+        g.nboxes = g.nx * g.ny * g.nz;
+        g.rate = (double)point_num / (double)n;
+        g.search_radius = g.unit * 3.0 / 4.0;
+        nb1 = g.nboxes + 1;
+    }
+    AIVS_HIP(hipMalloc(&d_box_of, sizeof(int32_t) * (size_t)n));
+    AIVS_HIP(hipMalloc(&d_counts, sizeof(int32_t) * ((size_t)nb1 + 2)));
+    AIVS_HIP(hipMalloc(&d_start, sizeof(int32_t) * ((size_t)nb1 + 2)));
+    AIVS_HIP(hipMalloc(&d_cursor, sizeof(int32_t) * ((size_t)nb1 + 2)));
+    AIVS_HIP(hipMalloc(&d_tmp, sizeof(int32_t) * (size_t)n));
+    AIVS_HIP(hipMalloc(&d_members, sizeof(int32_t) * (size_t)n));
+    AIVS_HIP(hipMalloc(&d_center, sizeof(int32_t) * (size_t)nb1));
+    AIVS_HIP(hipMalloc(&d_sim, sizeof(int32_t) * (size_t)nb1));
+    AIVS_HIP(hipMalloc(&d_simiT, sizeof(int32_t) * (size_t)n));
+    AIVS_HIP(hipMalloc(&d_nsamp, sizeof(int32_t) * ((size_t)nb1 + 2)));
+    AIVS_HIP(hipMalloc(&d_soff, sizeof(int32_t) * ((size_t)nb1 + 2)));
+    AIVS_HIP(hipMalloc(&d_label, (size_t)n));
+    AIVS_HIP(hipMalloc(&d_mind, sizeof(double) * (size_t)n));
+    AIVS_HIP(hipMalloc(&d_bad, sizeof(int32_t)));
+    AIVS_HIP(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * ((size_t)nb1 + 2), st));
+    AIVS_HIP(hipMemsetAsync(d_nsamp, 0, sizeof(int32_t) * ((size_t)nb1 + 2), st));
+    AIVS_HIP(hipMemsetAsync(d_bad, 0, sizeof(int32_t), st));
+    AIVS_HIP(hipMemsetAsync(d_label, 1, (size_t)n, st));
+    {
+        const dim3 gp((n + 255) / 256), bp(256);
+        hipLaunchKernelGGL(aivs_count_kernel, gp, bp, 0, st, d_xyz, n, g, d_box_of, d_counts, d_bad);
+        hipLaunchKernelGGL(aivs_scan_kernel, dim3(1), dim3(1024), 0, st, d_counts, nb1, d_start);
+        AIVS_HIP(hipMemcpyAsync(d_cursor, d_start, sizeof(int32_t) * (size_t)nb1, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(aivs_scatter_kernel, gp, bp, 0, st, d_box_of, n, d_cursor, d_tmp);
+        hipLaunchKernelGGL(aivs_rank_kernel, gp, bp, 0, st, d_tmp, d_box_of, n, d_start, d_members);
+        hipLaunchKernelGGL(aivs_box_info_kernel, dim3((nb1 + 255) / 256), bp, 0, st, d_xyz, g, d_start, d_members, d_center, d_sim);
+        // the 8 colours in the reference's order (Method_AIVS_SimPro.hpp:609-632); parity 1 -> offset 1, parity 0 -> offset 2
+        const int order[8][3] = {{1, 1, 1}, {0, 1, 1}, {0, 0, 1}, {1, 0, 1}, {1, 1, 0}, {0, 1, 0}, {0, 0, 0}, {1, 0, 0}};
+        for (int c = 0; c < 8; ++c) {
+            const int ox = order[c][0] ? 1 : 2, oy = order[c][1] ? 1 : 2, oz = order[c][2] ? 1 : 2;
+            if (ox > g.nx || oy > g.ny || oz > g.nz) continue;
+            const int hx = (g.nx - ox) / 2 + 1, hy = (g.ny - oy) / 2 + 1, hz = (g.nz - oz) / 2 + 1;
+            hipLaunchKernelGGL(aivs_fps_kernel, dim3(hx * hy * hz), dim3(64), 0, st, d_xyz, g, ox, oy, oz, d_start, d_members, d_center,
+                               d_sim, d_label, d_mind, d_simiT, d_nsamp);
+        }
+        hipLaunchKernelGGL(aivs_scan_kernel, dim3(1), dim3(1024), 0, st, d_nsamp, nb1, d_soff);
+        AIVS_HIP(hipGetLastError());
+        int32_t h_total = 0, h_bad = 0;
+        AIVS_HIP(hipMemcpyAsync(&h_total, d_soff + nb1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        AIVS_HIP(hipMemcpyAsync(&h_bad, d_bad, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        AIVS_HIP(hipStreamSynchronize(st));
+        if (h_bad) { err = "aivs: a point fell outside the box grid"; rc = KSS_ERR_ARG; goto done; }
+        ns = h_total;
+        if (ns <= 0) goto done;
+        AIVS_HIP(hipMalloc(&d_samples, sizeof(int32_t) * (size_t)ns));
+        hipLaunchKernelGGL(aivs_gather_samples_kernel, dim3((nb1 + 255) / 256), bp, 0, st, d_start, d_nsamp, d_soff, d_simiT, nb1, d_samples);
+        samples.resize((size_t)ns);
+        AIVS_HIP(hipMemcpyAsync(samples.data(), d_samples, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost, st));
+    }
+    {
+        std::vector<uint8_t> alive((size_t)ns, 1);
+        int64_t dTiff = (int64_t)ns - point_num;
+        if (dTiff > 0 && ns >= 3) {
+            // AIVS_AccurateCut_Optimization :848-957: greedy removal of one end of the closest live pair (host: O(dTiff * ns))
+            AIVS_HIP(hipMalloc(&d_nn1, sizeof(int32_t) * (size_t)ns));
+            AIVS_HIP(hipMalloc(&d_d1, sizeof(float) * (size_t)ns));
+            AIVS_HIP(hipMalloc(&d_d2, sizeof(float) * (size_t)ns));
+            hipLaunchKernelGGL(aivs_knn3_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, d_xyz, d_samples, ns, d_nn1, d_d1, d_d2);
+            std::vector<int32_t> nn1((size_t)ns);
+            std::vector<float> d1((size_t)ns), d2((size_t)ns);
+            AIVS_HIP(hipMemcpyAsync(nn1.data(), d_nn1, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost, st));
+            AIVS_HIP(hipMemcpyAsync(d1.data(), d_d1, sizeof(float) * (size_t)ns, hipMemcpyDeviceToHost, st));
+            AIVS_HIP(hipMemcpyAsync(d2.data(), d_d2, sizeof(float) * (size_t)ns, hipMemcpyDeviceToHost, st));
+            AIVS_HIP(hipStreamSynchronize(st));
+            while (dTiff > 0) {
+                double mn = 9999;
+                int64_t b1 = -1, b2 = -1;
+                for (int64_t i = 0; i < ns; ++i) {
+                    const int64_t b2t = nn1[(size_t)i];
+                    const double dt = d1[(size_t)i];
+                    if (dt < mn && alive[(size_t)i] && alive[(size_t)b2t]) { mn = dt; b1 = i; b2 = b2t; }
+                }
+                if (mn == 9999 || b1 == -1 || b2 == -1) break;
+                int64_t del = b1;
+                if ((double)d2[(size_t)b1] > (double)d2[(size_t)b2]) del = b2;
+                alive[(size_t)del] = 0;
+                --dTiff;
+            }
+        } else {
+            AIVS_HIP(hipStreamSynchronize(st));
+        }
+        for (int i = 0; i < ns; ++i)
+            if (alive[(size_t)i]) out_idx.push_back(samples[(size_t)i]);
+    }
+done:
+    hipStreamSynchronize(st);
+    void* frees[] = {d_bbox, d_box_of, d_counts, d_start, d_cursor, d_tmp, d_members, d_center, d_sim, d_simiT, d_nsamp, d_soff,
+                     d_samples, d_nn1, d_bad, d_label, d_mind, d_d1, d_d2};
+    for (void* p : frees)
+        if (p) hipFree(p);
+    return rc;
+}
+
+}  // namespace kss

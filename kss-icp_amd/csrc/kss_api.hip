@@ -1045,6 +1045,26 @@ int kss_downsample_fps(kss_ctx* c, const double* xyz, int64_t n, int64_t m, doub
     return KSS_OK;
 }
 
+int kss_downsample_aivs(kss_ctx* c, const double* xyz, int64_t n, int64_t point_num, double* out, int64_t capacity,
+                        int64_t* n_out, int32_t* out_idx) {
+    if (!c || !xyz || !out || !n_out) return set_err(c, KSS_ERR_ARG, "downsample_aivs: null argument");
+    if (n <= 0 || point_num <= 0 || n > 0x7fff0000ll) return set_err(c, KSS_ERR_ARG, "downsample_aivs: bad sizes");
+    HIPCHK(c, hipSetDevice(c->device));
+    KCHK(upload(c, c->scratch_a, xyz, (size_t)n * 3 * sizeof(double)));
+    std::vector<int32_t> sel;
+    std::string err;
+    const int rc = aivs_device(c->stream, (const double*)c->scratch_a.p, (int)n, (int)std::min<int64_t>(point_num, 0x7fffffff), sel, err);
+    if (rc != KSS_OK) return set_err(c, rc, err.c_str());
+    *n_out = (int64_t)sel.size();
+    if ((int64_t)sel.size() > capacity) return set_err(c, KSS_ERR_CAPACITY, "downsample_aivs: output buffer too small");
+    for (size_t i = 0; i < sel.size(); ++i) {
+        const int32_t s = sel[i];
+        out[3 * i] = xyz[3 * (size_t)s]; out[3 * i + 1] = xyz[3 * (size_t)s + 1]; out[3 * i + 2] = xyz[3 * (size_t)s + 2];
+        if (out_idx) out_idx[i] = s;
+    }
+    return KSS_OK;
+}
+
 // ---- rotation search --------------------------------------------------------------------------------
 int kss_grid_angles(double step, double* angles, int capacity) {
     if (!angles || capacity <= 0 || !(step > 0)) return KSS_ERR_ARG;

@@ -772,6 +772,278 @@ void ko_fps(const double *xyz, int64_t n, int64_t m, int32_t *idx) {
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* AIVS down-sampler (see kss_oracle.h for the line map)                                   */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+    int nx, ny, nz, nboxes;       /* boxes are 1-based: index = x + nx*(y-1) + nx*ny*(z-1) */
+    double minx, miny, minz, unit;
+} aivs_grid;
+
+static int aivs_box_scale(int64_t n) {   /* ballRegionCompute.hpp:1194-1215 */
+    if (n < 10000) return 10;
+    if (n < 50000) return 20;
+    if (n < 100000) return 30;
+    if (n < 500000) return 40;
+    if (n < 1000000) return 50;
+    return (int)pow((double)n / 8.0, 1.0 / 3.0);
+}
+
+static void aivs_box_center(const aivs_grid *g, int boxIndex, double c[3]) {   /* :1150-1172 */
+    int z_num = boxIndex / (g->nx * g->ny) + 1;
+    int leveZ = boxIndex % (g->nx * g->ny);
+    int y_num = leveZ / g->nx + 1;
+    int x_num = leveZ % g->nx;
+    if (x_num == 0) { x_num = g->nx; y_num = y_num - 1; }
+    c[0] = (g->minx + (x_num - 1) * g->unit + g->minx + x_num * g->unit) / 2;
+    c[1] = (g->miny + (y_num - 1) * g->unit + g->miny + y_num * g->unit) / 2;
+    c[2] = (g->minz + (z_num - 1) * g->unit + g->minz + z_num * g->unit) / 2;
+}
+
+static int aivs_neighbor_boxes(const aivs_grid *g, int boxIndex, int out[26]) {   /* :975-1031, quirks kept */
+    int z_num = boxIndex / (g->nx * g->ny) + 1;
+    int leveZ = boxIndex % (g->nx * g->ny);
+    int y_num = leveZ / g->nx + 1;
+    int x_num = leveZ % g->nx;   /* NOT wrapped here (it is in aivs_box_center): last-column boxes get odd neighbours */
+    int xs[3], ys[3], zs[3], nxs = 0, nys = 0, nzs = 0;
+    if (x_num > 1) xs[nxs++] = x_num - 1;
+    xs[nxs++] = x_num;
+    if (x_num < g->nx) xs[nxs++] = x_num + 1;
+    if (y_num > 1) ys[nys++] = y_num - 1;
+    ys[nys++] = y_num;
+    if (y_num < g->ny) ys[nys++] = y_num + 1;
+    if (z_num > 1) zs[nzs++] = z_num - 1;
+    zs[nzs++] = z_num;
+    if (z_num < g->nz) zs[nzs++] = z_num + 1;
+    int m = 0;
+    for (int i = 0; i < nxs; i++)
+        for (int j = 0; j < nys; j++)
+            for (int k = 0; k < nzs; k++) {
+                if (xs[i] == x_num && ys[j] == y_num && zs[k] == z_num) continue;
+                int idx = xs[i] + (ys[j] - 1) * g->nx + (zs[k] - 1) * g->nx * g->ny;
+                if (idx < g->nboxes + 1 && idx >= 0) out[m++] = idx;   /* `index_Compute < squareBoxes.size()`; a negative index would be UB there */
+            }
+    return m;
+}
+
+static inline float aivs_dist(const double *pts, int a, int b) {
+    /* pcl::KdTreeFLANN on float PointXYZ, then sqrt(float) */
+    float ax = (float)pts[3 * (int64_t)a], ay = (float)pts[3 * (int64_t)a + 1], az = (float)pts[3 * (int64_t)a + 2];
+    float bx = (float)pts[3 * (int64_t)b], by = (float)pts[3 * (int64_t)b + 1], bz = (float)pts[3 * (int64_t)b + 2];
+    float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return sqrtf((dx * dx + dy * dy) + dz * dz);
+}
+
+int64_t ko_aivs(const double *P, int64_t n, int64_t point_num, int32_t *out_idx, int64_t cap) {
+    if (n <= 0 || point_num <= 0) return -1;
+    /* pointPipeline_Border, pointPipeline.hpp:105-160: strict comparisons, first extreme kept */
+    double maxx = P[0], minx = P[0], maxy = P[1], miny = P[1], maxz = P[2], minz = P[2];
+    for (int64_t i = 0; i < n; i++) {
+        double x = P[3 * i], y = P[3 * i + 1], z = P[3 * i + 2];
+        if (x < minx) minx = x;
+        if (x > maxx) maxx = x;
+        if (y < miny) miny = y;
+        if (y > maxy) maxy = y;
+        if (z < minz) minz = z;
+        if (z > maxz) maxz = z;
+    }
+    /* BallRegion_AchieveXYZ, ballRegionCompute.hpp:690-758 */
+    aivs_grid g;
+    int boxNum = aivs_box_scale(n);
+    g.minx = minx; g.miny = miny; g.minz = minz;
+    double x_dis = fabs(maxx - minx), y_dis = fabs(maxy - miny), z_dis = fabs(maxz - minz);
+    double large = x_dis;
+    if (large < y_dis) large = y_dis;
+    if (large < z_dis) large = z_dis;
+    g.unit = large / (double)boxNum;
+    double numX = x_dis / g.unit, numY = y_dis / g.unit, numZ = z_dis / g.unit;
+    g.nx = (int)numX; g.ny = (int)numY; g.nz = (int)numZ;
+    if (numX > (double)g.nx) g.nx++;
+    if (numY > (double)g.ny) g.ny++;
+    if (numZ > (double)g.nz) g.nz++;
+    if (g.nx < 1 || g.ny < 1 || g.nz < 1 || !(g.unit > 0)) return -2;   /* planar / degenerate clouds divide by zero in the reference */
+    g.nboxes = g.nx * g.ny * g.nz;
+    const int nb1 = g.nboxes + 1;
+    /* BallRegion_BoxInput, :632-688 */
+    int32_t *box_of = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+    int32_t *count = (int32_t *)calloc((size_t)nb1 + 1, sizeof(int32_t));
+    for (int64_t i = 0; i < n; i++) {
+        double xNum = (P[3 * i] - g.minx) / g.unit, yNum = (P[3 * i + 1] - g.miny) / g.unit, zNum = (P[3 * i + 2] - g.minz) / g.unit;
+        int xi = (int)xNum, yi = (int)yNum, zi = (int)zNum;
+        if (xi < xNum || xi == 0) xi++;
+        if (yi < yNum || yi == 0) yi++;
+        if (zi < zNum || zi == 0) zi++;
+        int idx = xi + g.nx * (yi - 1) + g.nx * g.ny * (zi - 1);
+        if (idx >= nb1 || idx < 0) { free(box_of); free(count); return -3; }   /* the reference prints "Hello!" and then indexes out of range */
+        box_of[i] = idx;
+        count[idx]++;
+    }
+    int32_t *start = (int32_t *)malloc(sizeof(int32_t) * ((size_t)nb1 + 1));
+    start[0] = 0;
+    for (int b = 0; b < nb1; b++) start[b + 1] = start[b] + count[b];
+    int32_t *members = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);   /* squareBoxes[b] in push_back (= index) order */
+    int32_t *fill = (int32_t *)calloc((size_t)nb1, sizeof(int32_t));
+    for (int64_t i = 0; i < n; i++) members[start[box_of[i]] + fill[box_of[i]]++] = (int32_t)i;
+    /* box centre and the member closest to it (:634-686): strict '>' keeps the first minimum */
+    int32_t *center_pos = (int32_t *)malloc(sizeof(int32_t) * (size_t)nb1);
+    for (int b = 0; b < nb1; b++) {
+        center_pos[b] = -1;
+        double c[3], best = 9999;
+        aivs_box_center(&g, b, c);
+        for (int k = start[b]; k < start[b + 1]; k++) {
+            int i = members[k];
+            double d = sqrt((c[0] - P[3 * (int64_t)i]) * (c[0] - P[3 * (int64_t)i]) + (c[1] - P[3 * (int64_t)i + 1]) * (c[1] - P[3 * (int64_t)i + 1]) +
+                            (c[2] - P[3 * (int64_t)i + 2]) * (c[2] - P[3 * (int64_t)i + 2]));
+            if (best > d) { best = d; center_pos[b] = k - start[b]; }
+        }
+    }
+    /* AIVS_BoxSimplification_Points, Method_AIVS_SimPro.hpp:776-794 */
+    const double rate = (double)point_num / (double)n;
+    int32_t *sim_num = (int32_t *)malloc(sizeof(int32_t) * (size_t)nb1);
+    for (int b = 0; b < nb1; b++) {
+        double simBox = (double)count[b] * rate;
+        int t = (int)simBox;
+        sim_num[b] = (simBox - t > 0.2) ? t + 1 : t;
+    }
+    /* AIVS_Voroni_OpenMP_KNN, :222-376.  labelG: 1 = not sampled, 0 = sampled */
+    uint8_t *labelG = (uint8_t *)malloc((size_t)n);
+    memset(labelG, 1, (size_t)n);
+    int32_t *simiT = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);   /* simiT[b] lives at start[b].. (size = box size), -1 = empty */
+    for (int64_t i = 0; i < n; i++) simiT[i] = -1;
+    const double searchBoxRadius = g.unit * 3.0 / 4.0;
+    double *mind = (double *)malloc(sizeof(double) * (size_t)n);
+    for (int colour = 0; colour < 8; colour++) {
+        /* AIVS_initBoxIndexNumber, :587-643: parity classes of (i, j, k); order inside a colour is irrelevant */
+        for (int i = 1; i <= g.nx; i++)
+            for (int j = 1; j <= g.ny; j++)
+                for (int k = 1; k <= g.nz; k++) {
+                    const int oi = i % 2, oj = j % 2, ok = k % 2;
+                    int cls;
+                    if (oi == 1 && oj == 1 && ok == 1) cls = 0;
+                    else if (oi == 0 && oj == 1 && ok == 1) cls = 1;
+                    else if (oi == 0 && oj == 0 && ok == 1) cls = 2;
+                    else if (oi == 1 && oj == 0 && ok == 1) cls = 3;
+                    else if (oi == 1 && oj == 1 && ok == 0) cls = 4;
+                    else if (oi == 0 && oj == 1 && ok == 0) cls = 5;
+                    else if (oi == 0 && oj == 0 && ok == 0) cls = 6;
+                    else cls = 7;
+                    if (cls != colour) continue;
+                    const int b = i + g.nx * (j - 1) + g.nx * g.ny * (k - 1);
+                    if (count[b] == 0) continue;
+                    const int simNum = sim_num[b];
+                    if (simNum == 0) continue;
+                    double pc[3];
+                    aivs_box_center(&g, b, pc);
+                    const int m = count[b];
+                    const int32_t *own = members + start[b];
+                    /* already-sampled points of the neighbour boxes inside the search cube (label 2) */
+                    int nbr[26];
+                    const int nn = aivs_neighbor_boxes(&g, b, nbr);
+                    int n_l2 = 0;
+                    static int32_t *l2 = NULL; static int l2cap = 0;
+                    for (int q = 0; q < nn; q++)
+                        for (int l = start[nbr[q]]; l < start[nbr[q] + 1]; l++) {
+                            const int pi = members[l];
+                            const double *pn = P + 3 * (int64_t)pi;
+                            if (pn[0] <= pc[0] + searchBoxRadius && pn[0] >= pc[0] - searchBoxRadius && pn[1] <= pc[1] + searchBoxRadius &&
+                                pn[1] >= pc[1] - searchBoxRadius && pn[2] <= pc[2] + searchBoxRadius && pn[2] >= pc[2] - searchBoxRadius &&
+                                labelG[pi] == 0) {
+                                if (n_l2 == l2cap) { l2cap = l2cap * 2 + 64; l2 = (int32_t *)realloc(l2, sizeof(int32_t) * (size_t)l2cap); }
+                                l2[n_l2++] = pi;
+                            }
+                        }
+                    int sample_index = 0;
+                    const int seed_pos = (n_l2 == 0 && center_pos[b] >= 0 && center_pos[b] < m) ? center_pos[b] : -1;   /* addJ */
+                    /* labelTemp: own points 1 (seed 0), neighbour samples 2 */
+                    for (int k2 = 0; k2 < m; k2++) {
+                        if (k2 == seed_pos) {
+                            mind[start[b] + k2] = 0;
+                            simiT[start[b] + sample_index++] = own[k2];
+                            labelG[own[k2]] = 0;
+                        } else {
+                            /* nearest label-0/2 point through the local kd-tree: min over them of sqrt(float d2) */
+                            double mt = 9999;
+                            float bestf = INFINITY;
+                            if (seed_pos >= 0) bestf = aivs_dist(P, own[k2], own[seed_pos]);
+                            for (int l = 0; l < n_l2; l++) { float d = aivs_dist(P, own[k2], l2[l]); if (d < bestf) bestf = d; }
+                            if (bestf != INFINITY) mt = (double)bestf;
+                            mind[start[b] + k2] = mt;
+                        }
+                    }
+                    uint8_t *lab = labelG;   /* own points: labelTemp 1 <=> labelG 1 inside this box (own points start unsampled) */
+                    while (sample_index < simNum) {
+                        int sel = -1; double mx = 0;
+                        for (int k2 = 0; k2 < m; k2++)
+                            if (lab[own[k2]] == 1 && mind[start[b] + k2] > mx) { sel = k2; mx = mind[start[b] + k2]; }
+                        if (sel == -1) break;
+                        mind[start[b] + sel] = 0;
+                        labelG[own[sel]] = 0;
+                        simiT[start[b] + sample_index++] = own[sel];
+                        for (int k2 = 0; k2 < m; k2++)
+                            if (lab[own[k2]] == 1) {
+                                double d = (double)aivs_dist(P, own[k2], own[sel]);
+                                if (d < mind[start[b] + k2]) mind[start[b] + k2] = d;
+                            }
+                    }
+                }
+    }
+    /* AIVS_AccurateCut_Optimization, :848-957 */
+    int32_t *samples = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+    int64_t ns = 0;
+    for (int b = 0; b < nb1; b++)
+        for (int k = start[b]; k < start[b + 1]; k++) {
+            if (simiT[k] == -1) break;
+            samples[ns++] = simiT[k];
+        }
+    int64_t dTiff = ns - point_num;
+    uint8_t *alive = (uint8_t *)malloc((size_t)(ns > 0 ? ns : 1));
+    memset(alive, 1, (size_t)(ns > 0 ? ns : 1));
+    if (dTiff > 0 && ns >= 3) {
+        /* K = 3 self-kNN among the samples: [0] self, [1] nearest, [2] second nearest (ties -> lower index) */
+        int32_t *nn1 = (int32_t *)malloc(sizeof(int32_t) * (size_t)ns);
+        float *d1 = (float *)malloc(sizeof(float) * (size_t)ns), *d2v = (float *)malloc(sizeof(float) * (size_t)ns);
+        for (int64_t i = 0; i < ns; i++) {
+            float bd[3] = {INFINITY, INFINITY, INFINITY}; int32_t bi[3] = {-1, -1, -1};
+            const double *a = P + 3 * (int64_t)samples[i];
+            float ax = (float)a[0], ay = (float)a[1], az = (float)a[2];
+            for (int64_t j = 0; j < ns; j++) {
+                const double *q = P + 3 * (int64_t)samples[j];
+                float dx = ax - (float)q[0], dy = ay - (float)q[1], dz = az - (float)q[2];
+                float d = (dx * dx + dy * dy) + dz * dz;
+                if (d < bd[2]) {   /* insert, stable: equal distances keep the lower index first */
+                    int pos = 2;
+                    while (pos > 0 && d < bd[pos - 1]) { bd[pos] = bd[pos - 1]; bi[pos] = bi[pos - 1]; pos--; }
+                    bd[pos] = d; bi[pos] = (int32_t)j;
+                }
+            }
+            nn1[i] = bi[1]; d1[i] = sqrtf(bd[1]); d2v[i] = sqrtf(bd[2]);
+        }
+        while (dTiff > 0) {
+            double mn = 9999; int64_t b1 = -1, b2 = -1;
+            for (int64_t i = 0; i < ns; i++) {
+                int64_t b2t = nn1[i];
+                double dt = d1[i];
+                if (dt < mn && alive[i] && alive[b2t]) { mn = dt; b1 = i; b2 = b2t; }
+            }
+            if (mn == 9999 || b1 == -1 || b2 == -1) break;
+            int64_t del = b1;
+            if ((double)d2v[b1] > (double)d2v[b2]) del = b2;
+            alive[del] = 0;
+            dTiff--;
+        }
+        free(nn1); free(d1); free(d2v);
+    }
+    int64_t nout = 0;
+    for (int64_t i = 0; i < ns; i++)
+        if (alive[i]) {
+            if (nout >= cap) { nout = -4; break; }
+            out_idx[nout++] = samples[i];
+        }
+    free(box_of); free(count); free(start); free(members); free(fill); free(center_pos); free(sim_num); free(labelG);
+    free(simiT); free(mind); free(samples); free(alive);
+    return nout;
+}
+
+/* ------------------------------------------------------------------------------------ */
 uint64_t ko_splitmix64(uint64_t seed, uint64_t counter) {
     uint64_t z = seed + (counter + 1) * 0x9E3779B97F4A7C15ULL;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;

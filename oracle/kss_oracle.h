@@ -164,6 +164,20 @@ void ko_free(void *p);
  * from the selected set. */
 void ko_fps(const double *xyz, int64_t n, int64_t m, int32_t *idx);
 
+/* ---- AIVS down-sampler: KSS_ICP.hpp:71-81 -> pointPipeline_init_point_withoutUniform (pointPipeline.hpp:88-101,
+ *      :105-160), BallRegion_init_withoutNormal (ballRegionCompute.hpp:114-147: AchieveXYZ :690-758, BoxInput
+ *      :632-688, box centres :1150-1172, neighbour boxes :975-1031, box scale :1194-1215), AIVS_Pro_init /
+ *      AIVS_simplification (Method_AIVS_SimPro.hpp:70-154: colouring :587-643, per-box budget :776-794,
+ *      per-voxel farthest-point sampling :222-376, accurate cut :848-957).
+ * The self-kNN radius estimate (ballRegionCompute.hpp:477-530) is NOT restated: its outputs (radius,
+ * pointNeibor) are never read on this path.  Distances inside AIVS come from pcl::KdTreeFLANN on float
+ * PointXYZ: d2 = (dx*dx+dy*dy)+dz*dz in float, then sqrt(float) (the float overload) -- restated as such;
+ * kNN ties are resolved to the lower index (FLANN: unspecified).  Parity unpinned: the reference holds no
+ * AIVS output fixture.
+ * out_idx receives the indices (into pts) of the selected points in output order; returns their number
+ * (may exceed point_num: the accurate cut stops when no live closest pair is left), or < 0 on error. */
+int64_t ko_aivs(const double *pts, int64_t n, int64_t point_num, int32_t *out_idx, int64_t cap);
+
 /* ---- synthetic clouds (portable counter-based RNG) ---- */
 uint64_t ko_splitmix64(uint64_t seed, uint64_t counter);
 

@@ -87,6 +87,8 @@ def lib():
         L.ko_ply_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_double))]
         L.ko_free.argtypes = [C.c_void_p]
         L.ko_fps.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.ko_aivs.restype = C.c_int64
+        L.ko_aivs.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64]
         L.ko_splitmix64.restype = C.c_uint64
         L.ko_splitmix64.argtypes = [C.c_uint64, C.c_uint64]
     return _LIB
@@ -291,6 +293,16 @@ def fps(xyz, m):
     idx = np.empty(int(m), np.int32)
     lib().ko_fps(_p(a), len(a), int(m), _p(idx))
     return idx
+
+
+def aivs(xyz, point_num):
+    """Indices of the AIVS-selected points, in output order."""
+    a = _f64(xyz)
+    idx = np.empty(len(a), np.int32)
+    k = lib().ko_aivs(_p(a), len(a), int(point_num), _p(idx), len(idx))
+    if k < 0:
+        raise RuntimeError("ko_aivs rc=%d" % k)
+    return idx[:k].copy()
 
 
 def splitmix64(seed, counter):

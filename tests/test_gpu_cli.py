@@ -65,9 +65,9 @@ def test_mirror_classes_against_oracle(O, ref_pairs):
     assert np.allclose(icp2[2:5], exp0, atol=1e-4)     # icp2[1] is the "0" of the ALIGN0 tag
     assert np.allclose(_vals(out, "QM"), O.pcr_qm(P, T), rtol=1e-10)
     reg = _vals(out, "REG")
-    # KSSICP_Registration = FPS down-sample (pNumber = min(n)/2, KSS_ICP.hpp:57-66) + kss_register: same pipeline on the oracle
+    # KSSICP_Registration = AIVS down-sample (pNumber = min(n)/2, KSS_ICP.hpp:57-81) + kss_register: same pipeline on the oracle
     m = min(len(S), len(T)) // 2
-    ko = O.kssicp_register(S[O.fps(S, m)], T[O.fps(T, m)], S, 6.0, 1000)
+    ko = O.kssicp_register(S[O.aivs(S, m)], T[O.aivs(T, m)], S, 6.0, 1000)
     assert abs(reg[0] - ko["scale"]) < 1e-12 and abs(reg[1] - ko["final_fitness"]) < 1e-8 and int(reg[2]) == len(S)
 
 
@@ -84,10 +84,35 @@ def test_cli_config_c1(pkg, O, tmp_path):
     mse = float(re.search(r"Registration Measure:MSE: (\S+)", r.stdout).group(1))
     # a sphere is rotation-degenerate: compare the fit quality with the same pipeline on the oracle
     s64, t64 = src.astype(np.float64), tgt.astype(np.float64)
-    ko = O.kssicp_register(s64[O.fps(s64, 1000)], t64[O.fps(t64, 1000)], s64, 8.0, 1000)
+    ko = O.kssicp_register(s64[O.aivs(s64, 1000)], t64[O.aivs(t64, 1000)], s64, 8.0, 1000)
     assert abs(mse - O.pcr_qm(ko["pointAlign"], t64)[0]) < 1e-6 * mse + 1e-9
     lines = open(po).read().split("\n")
     assert int(lines[0]) == 2000 and len(lines[1].split()) == 3
     # missing file: reference-style diagnostics, non-zero exit
     r = subprocess.run([os.path.join(CLI, "kss_icp"), str(tmp_path / "nope.ply"), pt], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "failed" in r.stdout
+
+
+def test_aivs_matches_oracle(ctx, O, pkg, ref_pairs):
+    """AIVS down-sampler (voxel grid + 8-colour per-voxel FPS + accurate cut): identical selection, in identical
+    order, as the oracle's line-by-line restatement of the reference."""
+    S = pkg.synth
+    cases = [(S.bumpy(5, 2000), 1000), (S.bumpy(6, 5000), 2000), (S.bumpy(7, 20000), 2000), (S.sphere(8, 12345), 700),
+             (S.bumpy(9, 100000), 2000), (S.bumpy(10, 64), 30), (S.bumpy(11, 3000) * np.array([1.0, 0.31, 2.7]) + 5.0, 999)]
+    for key in (("registration", "Bunny"), ("registration", "Horse"), ("registration_scale", "Bunny")):
+        s, t = ref_pairs[key]
+        m = min(len(s), len(t)) // 2
+        cases += [(s, m), (t, m)]
+    for P, m in cases:
+        out, idx = ctx.downsample_aivs(P, m)
+        ref = O.aivs(P, m)
+        assert np.array_equal(idx, ref), (len(P), m, len(idx), len(ref))
+        assert np.array_equal(out, np.asarray(P, dtype=np.float64)[ref])
+        assert len(set(idx.tolist())) == len(idx)
+    # clouds the reference cannot voxelise are rejected, not mis-sampled
+    flat = S.bumpy(12, 500).copy(); flat[:, 2] = 0.25
+    with pytest.raises(pkg.KssError) as e:
+        ctx.downsample_aivs(flat, 100)
+    assert e.value.status == -1
+    with pytest.raises(RuntimeError):
+        O.aivs(flat, 100)
