@@ -193,10 +193,9 @@ int kss_transform_apply_dev(kss_ctx *ctx, const float T[16], const double *d_in,
  * (KSS_ICP.hpp:162,170-180 read it back as pointAlign in the full-resolution overload) */
 int kss_transform_apply_f32(kss_ctx *ctx, const float T[16], const float *in, int64_t n, float *out);
 
-/* ---- down-sampling stand-in for AIVS (Method_AIVS_SimPro.hpp, KSS_ICP.hpp:71-81) ----
+/* ---- plain farthest-point sampling: fallback for clouds kss_downsample_aivs rejects (zero extent) ----
  * Exact farthest-point sampling in f64 starting from point 0 (ties -> lowest index); returns the m
- * selected points in selection order.  NOT AIVS parity: AIVS is the reference's own racy voxel-FPS
- *  and is the next component to build; this keeps KSSICP_Registration drop-in. */
+ * selected points in selection order.  Not an AIVS restatement. */
 int kss_downsample_fps(kss_ctx *ctx, const double *xyz, int64_t n, int64_t m, double *out, int32_t *out_idx);
 
 /* ---- AIVS down-sampler: pointPipeline_init_point_withoutUniform + BallRegion_init_withoutNormal +
