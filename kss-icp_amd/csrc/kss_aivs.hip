@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -329,8 +330,10 @@ __global__ __launch_bounds__(256) void aivs_gather_samples_kernel(const int32_t*
     } while (0)
 
 // Host driver.  d_xyz: n packed f64 points on the device.  out_idx: indices of the selected points in the
-// reference's output order.  Scratch is allocated per call (down-sampling runs once per cloud, not per iteration).
-int aivs_device(hipStream_t st, const double* d_xyz, int n, int point_num, std::vector<int32_t>& out_idx, std::string& err) {
+// reference's output order.  `scratch(bytes)` returns ONE device region (the context's grow-only workspace) that is
+// carved into the working arrays: no hipMalloc/hipFree on the call path.
+int aivs_device(hipStream_t st, const double* d_xyz, int n, int point_num, std::vector<int32_t>& out_idx, std::string& err,
+                const std::function<void*(size_t)>& scratch) {
     int rc = KSS_OK;
     out_idx.clear();
     double* d_bbox = nullptr;
@@ -344,8 +347,18 @@ int aivs_device(hipStream_t st, const double* d_xyz, int n, int point_num, std::
     std::vector<int32_t> samples;
     AivsGrid g;
     int nb1 = 0, ns = 0;
+    char* pool = nullptr;
+    size_t pool_off = 0;
+    auto carve = [&](size_t bytes) -> void* {
+        void* p = pool + pool_off;
+        pool_off += (bytes + 255) & ~(size_t)255;
+        return p;
+    };
     {
-        AIVS_HIP(hipMalloc(&d_bbox, 64 * 6 * sizeof(double)));
+        // the bounding box needs 3 KB before the grid size is known: it lives at the start of a first, small region
+        pool = (char*)scratch(64 * 6 * sizeof(double));
+        if (!pool) { err = "aivs: out of device memory"; rc = KSS_ERR_NOMEM; goto done; }
+        d_bbox = (double*)pool;
         hipLaunchKernelGGL(aivs_bbox_kernel, dim3(64), dim3(256), 0, st, d_xyz, n, d_bbox);
         AIVS_HIP(hipMemcpyAsync(hb.data(), d_bbox, hb.size() * sizeof(double), hipMemcpyDeviceToHost, st));
         AIVS_HIP(hipStreamSynchronize(st));
@@ -378,20 +391,19 @@ int aivs_device(hipStream_t st, const double* d_xyz, int n, int point_num, std::
         g.search_radius = g.unit * 3.0 / 4.0;
         nb1 = g.nboxes + 1;
     }
-    AIVS_HIP(hipMalloc(&d_box_of, sizeof(int32_t) * (size_t)n));
-    AIVS_HIP(hipMalloc(&d_counts, sizeof(int32_t) * ((size_t)nb1 + 2)));
-    AIVS_HIP(hipMalloc(&d_start, sizeof(int32_t) * ((size_t)nb1 + 2)));
-    AIVS_HIP(hipMalloc(&d_cursor, sizeof(int32_t) * ((size_t)nb1 + 2)));
-    AIVS_HIP(hipMalloc(&d_tmp, sizeof(int32_t) * (size_t)n));
-    AIVS_HIP(hipMalloc(&d_members, sizeof(int32_t) * (size_t)n));
-    AIVS_HIP(hipMalloc(&d_center, sizeof(int32_t) * (size_t)nb1));
-    AIVS_HIP(hipMalloc(&d_sim, sizeof(int32_t) * (size_t)nb1));
-    AIVS_HIP(hipMalloc(&d_simiT, sizeof(int32_t) * (size_t)n));
-    AIVS_HIP(hipMalloc(&d_nsamp, sizeof(int32_t) * ((size_t)nb1 + 2)));
-    AIVS_HIP(hipMalloc(&d_soff, sizeof(int32_t) * ((size_t)nb1 + 2)));
-    AIVS_HIP(hipMalloc(&d_label, (size_t)n));
-    AIVS_HIP(hipMalloc(&d_mind, sizeof(double) * (size_t)n));
-    AIVS_HIP(hipMalloc(&d_bad, sizeof(int32_t)));
+    {
+        const size_t N = (size_t)n, B = (size_t)nb1 + 2;
+        const size_t total = 8 * 256 + (N * 4) * 5 + (B * 4) * 7 + N + N * 8 + 256 /*bad*/ + (N * 4) * 2 /*samples, nn1*/ + (N * 4) * 2 /*d1, d2*/;
+        pool = (char*)scratch(total);   // the earlier small region is dead: its contents were copied to the host already
+        pool_off = 0;
+        if (!pool) { err = "aivs: out of device memory"; rc = KSS_ERR_NOMEM; goto done; }
+        d_box_of = (int32_t*)carve(N * 4); d_tmp = (int32_t*)carve(N * 4); d_members = (int32_t*)carve(N * 4);
+        d_simiT = (int32_t*)carve(N * 4); d_samples = (int32_t*)carve(N * 4);
+        d_counts = (int32_t*)carve(B * 4); d_start = (int32_t*)carve(B * 4); d_cursor = (int32_t*)carve(B * 4);
+        d_center = (int32_t*)carve(B * 4); d_sim = (int32_t*)carve(B * 4); d_nsamp = (int32_t*)carve(B * 4); d_soff = (int32_t*)carve(B * 4);
+        d_label = (uint8_t*)carve(N); d_mind = (double*)carve(N * 8); d_bad = (int32_t*)carve(256);
+        d_nn1 = (int32_t*)carve(N * 4); d_d1 = (float*)carve(N * 4); d_d2 = (float*)carve(N * 4);
+    }
     AIVS_HIP(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * ((size_t)nb1 + 2), st));
     AIVS_HIP(hipMemsetAsync(d_nsamp, 0, sizeof(int32_t) * ((size_t)nb1 + 2), st));
     AIVS_HIP(hipMemsetAsync(d_bad, 0, sizeof(int32_t), st));
@@ -422,7 +434,6 @@ int aivs_device(hipStream_t st, const double* d_xyz, int n, int point_num, std::
         if (h_bad) { err = "aivs: a point fell outside the box grid"; rc = KSS_ERR_ARG; goto done; }
         ns = h_total;
         if (ns <= 0) goto done;
-        AIVS_HIP(hipMalloc(&d_samples, sizeof(int32_t) * (size_t)ns));
         hipLaunchKernelGGL(aivs_gather_samples_kernel, dim3((nb1 + 255) / 256), bp, 0, st, d_start, d_nsamp, d_soff, d_simiT, nb1, d_samples);
         samples.resize((size_t)ns);
         AIVS_HIP(hipMemcpyAsync(samples.data(), d_samples, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost, st));
@@ -432,9 +443,6 @@ int aivs_device(hipStream_t st, const double* d_xyz, int n, int point_num, std::
         int64_t dTiff = (int64_t)ns - point_num;
         if (dTiff > 0 && ns >= 3) {
             // AIVS_AccurateCut_Optimization :848-957: greedy removal of one end of the closest live pair (host: O(dTiff * ns))
-            AIVS_HIP(hipMalloc(&d_nn1, sizeof(int32_t) * (size_t)ns));
-            AIVS_HIP(hipMalloc(&d_d1, sizeof(float) * (size_t)ns));
-            AIVS_HIP(hipMalloc(&d_d2, sizeof(float) * (size_t)ns));
             hipLaunchKernelGGL(aivs_knn3_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, d_xyz, d_samples, ns, d_nn1, d_d1, d_d2);
             std::vector<int32_t> nn1((size_t)ns);
             std::vector<float> d1((size_t)ns), d2((size_t)ns);
@@ -464,10 +472,6 @@ int aivs_device(hipStream_t st, const double* d_xyz, int n, int point_num, std::
     }
 done:
     hipStreamSynchronize(st);
-    void* frees[] = {d_bbox, d_box_of, d_counts, d_start, d_cursor, d_tmp, d_members, d_center, d_sim, d_simiT, d_nsamp, d_soff,
-                     d_samples, d_nn1, d_bad, d_label, d_mind, d_d1, d_d2};
-    for (void* p : frees)
-        if (p) hipFree(p);
     return rc;
 }
 

@@ -1053,7 +1053,8 @@ int kss_downsample_aivs(kss_ctx* c, const double* xyz, int64_t n, int64_t point_
     KCHK(upload(c, c->scratch_a, xyz, (size_t)n * 3 * sizeof(double)));
     std::vector<int32_t> sel;
     std::string err;
-    const int rc = aivs_device(c->stream, (const double*)c->scratch_a.p, (int)n, (int)std::min<int64_t>(point_num, 0x7fffffff), sel, err);
+    auto scratch = [c](size_t bytes) -> void* { return ensure(c, c->scratch_b, bytes) == KSS_OK ? c->scratch_b.p : nullptr; };
+    const int rc = aivs_device(c->stream, (const double*)c->scratch_a.p, (int)n, (int)std::min<int64_t>(point_num, 0x7fffffff), sel, err, scratch);
     if (rc != KSS_OK) return set_err(c, rc, err.c_str());
     *n_out = (int64_t)sel.size();
     if ((int64_t)sel.size() > capacity) return set_err(c, KSS_ERR_CAPACITY, "downsample_aivs: output buffer too small");

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -138,6 +139,7 @@ void launch_rot_search(hipStream_t st, const double* d_src, int64_t ns, const fl
 int preshape_blocks(int64_t n);
 
 // AIVS down-sampler (kss_aivs.hip): indices of the selected points in the reference's output order
-int aivs_device(hipStream_t st, const double* d_xyz, int n, int point_num, std::vector<int32_t>& out_idx, std::string& err);
+int aivs_device(hipStream_t st, const double* d_xyz, int n, int point_num, std::vector<int32_t>& out_idx, std::string& err,
+                const std::function<void*(size_t)>& scratch);
 
 }  // namespace kss
