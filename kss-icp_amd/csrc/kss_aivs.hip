@@ -190,17 +190,34 @@ __global__ __launch_bounds__(64) void aivs_fps_kernel(const double* __restrict__
     int nbr[26];
     const int nn = aivs_neighbor_boxes(g, b, nbr);
 
-    // already-sampled points of the neighbour boxes inside the search cube ("label 2"): is there any?
-    int found = 0;
+    // already-sampled points of the neighbour boxes inside the search cube ("label 2"): the wave scans the
+    // neighbours' members once, lane-strided, and compacts the hits into LDS (ballot + prefix popcount); their
+    // order is irrelevant (only a minimum over them is taken).  More than L2_CAP hits fall back to re-scanning.
+    constexpr int L2_CAP = 512;
+    __shared__ int32_t l2[L2_CAP];
+    int n_l2 = 0;
     for (int q = 0; q < nn; ++q) {
         const int s0 = start[nbr[q]], s1 = start[nbr[q] + 1];
-        for (int l = s0 + lane; l < s1; l += 64) {
-            const int pi = members[l];
-            const double x = P[3 * (int64_t)pi], y = P[3 * (int64_t)pi + 1], z = P[3 * (int64_t)pi + 2];
-            if (x <= pc[0] + R && x >= pc[0] - R && y <= pc[1] + R && y >= pc[1] - R && z <= pc[2] + R && z >= pc[2] - R && labelG[pi] == 0) found = 1;
+        for (int l0 = s0; l0 < s1; l0 += 64) {
+            const int l = l0 + lane;
+            int pi = -1;
+            bool hit = false;
+            if (l < s1) {
+                pi = members[l];
+                const double x = P[3 * (int64_t)pi], y = P[3 * (int64_t)pi + 1], z = P[3 * (int64_t)pi + 2];
+                hit = x <= pc[0] + R && x >= pc[0] - R && y <= pc[1] + R && y >= pc[1] - R && z <= pc[2] + R && z >= pc[2] - R && labelG[pi] == 0;
+            }
+            const unsigned long long mask = __ballot(hit);
+            if (hit) {
+                const int slot = n_l2 + __popcll(mask & ((1ull << lane) - 1ull));
+                if (slot < L2_CAP) l2[slot] = pi;
+            }
+            n_l2 += __popcll(mask);
         }
     }
-    const bool any_l2 = __any(found);
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    const bool any_l2 = n_l2 > 0;
     const int cpos = center_pos[b];
     const int seed_pos = (!any_l2 && cpos >= 0 && cpos < m) ? cpos : -1;   // addJ: seed the box centre only if no neighbour sample
     const int seed_pt = seed_pos >= 0 ? members[lo + seed_pos] : -1;
@@ -214,7 +231,12 @@ __global__ __launch_bounds__(64) void aivs_fps_kernel(const double* __restrict__
         } else {
             float best = __builtin_inff();
             if (seed_pt >= 0) best = aivs_dist(P, me, seed_pt);
-            if (any_l2)
+            if (any_l2 && n_l2 <= L2_CAP) {
+                for (int l = 0; l < n_l2; ++l) {
+                    const float d = aivs_dist(P, me, l2[l]);
+                    if (d < best) best = d;
+                }
+            } else if (any_l2)
                 for (int q = 0; q < nn; ++q) {
                     const int s0 = start[nbr[q]], s1 = start[nbr[q] + 1];
                     for (int l = s0; l < s1; ++l) {
@@ -268,30 +290,42 @@ __global__ __launch_bounds__(64) void aivs_fps_kernel(const double* __restrict__
 }
 
 // ---- accurate cut: K = 3 self-kNN among the samples (brute force; ties -> lower index) -----------------------------
-__global__ __launch_bounds__(256) void aivs_knn3_kernel(const double* __restrict__ P, const int32_t* __restrict__ samples, int ns,
-                                                        int32_t* __restrict__ nn1, float* __restrict__ d1, float* __restrict__ d2) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ns) return;
+__device__ __forceinline__ void top3_insert(float d, int j, float (&bd)[3], int (&bi)[3]) {
+    // ascending by (distance, index): equal distances keep the lower index first
+    if (d < bd[2] || (d == bd[2] && j < bi[2])) {
+        int pos = 2;
+        while (pos > 0 && (d < bd[pos - 1] || (d == bd[pos - 1] && j < bi[pos - 1]))) { bd[pos] = bd[pos - 1]; bi[pos] = bi[pos - 1]; --pos; }
+        bd[pos] = d; bi[pos] = j;
+    }
+}
+
+// one wave per sample: lanes stride over the samples keeping their own top-3, lane 0 merges the 64 x 3 candidates
+__global__ __launch_bounds__(64) void aivs_knn3_kernel(const double* __restrict__ P, const int32_t* __restrict__ samples, int ns,
+                                                       int32_t* __restrict__ nn1, float* __restrict__ d1, float* __restrict__ d2) {
+    __shared__ float sd[64][3];
+    __shared__ int si[64][3];
+    const int i = blockIdx.x, lane = threadIdx.x;
     const int pi = samples[i];
     const float ax = (float)P[3 * (int64_t)pi], ay = (float)P[3 * (int64_t)pi + 1], az = (float)P[3 * (int64_t)pi + 2];
-    float bd0 = __builtin_inff(), bd1 = __builtin_inff(), bd2 = __builtin_inff();
-    int bi0 = -1, bi1 = -1, bi2 = -1;
-    for (int j = 0; j < ns; ++j) {
+    float bd[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    int bi[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+    for (int j = lane; j < ns; j += 64) {
         const int pj = samples[j];
         const float dx = ax - (float)P[3 * (int64_t)pj], dy = ay - (float)P[3 * (int64_t)pj + 1], dz = az - (float)P[3 * (int64_t)pj + 2];
-        const float d = (dx * dx + dy * dy) + dz * dz;
-        if (d < bd2) {   // stable insertion: equal distances keep the lower index first
-            if (d < bd1) {
-                bd2 = bd1; bi2 = bi1;
-                if (d < bd0) { bd1 = bd0; bi1 = bi0; bd0 = d; bi0 = j; }
-                else { bd1 = d; bi1 = j; }
-            } else { bd2 = d; bi2 = j; }
-        }
+        top3_insert((dx * dx + dy * dy) + dz * dz, j, bd, bi);
     }
-    (void)bi0; (void)bi2;
-    nn1[i] = bi1;
-    d1[i] = sqrtf(bd1);
-    d2[i] = sqrtf(bd2);
+    for (int k = 0; k < 3; ++k) { sd[lane][k] = bd[k]; si[lane][k] = bi[k]; }
+    __syncthreads();
+    if (lane == 0) {
+        float md[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+        int mi[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+        for (int l = 0; l < 64; ++l)
+            for (int k = 0; k < 3; ++k)
+                if (si[l][k] != 0x7fffffff) top3_insert(sd[l][k], si[l][k], md, mi);
+        nn1[i] = mi[1];
+        d1[i] = sqrtf(md[1]);
+        d2[i] = sqrtf(md[2]);
+    }
 }
 
 // exclusive scan of small int arrays on one workgroup (boxes <= ~125k + 2): used for box starts and sample offsets
@@ -443,7 +477,7 @@ int aivs_device(hipStream_t st, const double* d_xyz, int n, int point_num, std::
         int64_t dTiff = (int64_t)ns - point_num;
         if (dTiff > 0 && ns >= 3) {
             // AIVS_AccurateCut_Optimization :848-957: greedy removal of one end of the closest live pair (host: O(dTiff * ns))
-            hipLaunchKernelGGL(aivs_knn3_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, d_xyz, d_samples, ns, d_nn1, d_d1, d_d2);
+            hipLaunchKernelGGL(aivs_knn3_kernel, dim3(ns), dim3(64), 0, st, d_xyz, d_samples, ns, d_nn1, d_d1, d_d2);
             std::vector<int32_t> nn1((size_t)ns);
             std::vector<float> d1((size_t)ns), d2((size_t)ns);
             AIVS_HIP(hipMemcpyAsync(nn1.data(), d_nn1, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost, st));
