@@ -37,6 +37,8 @@ struct kss_ctx {
     int nn_mode = KSS_NN_AUTO;
     double grid_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     double last_setup_ms = 0, last_loop_ms = 0;
+    bool tables_staged = false;
+    int64_t stats_ns = -1, stats_nt = -1;
 
     // grow-only device workspace
     DevBuf tgt4, src0, cur[2], keys, partials, sums, nn_work, red_work, pair_red, state, cs, scratch_a,
@@ -396,6 +398,17 @@ int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npairs, boo
     return KSS_OK;
 }
 
+// Work tables of the sweep / reduce kernels (uploaded lazily on the fused cell-list path).
+int stage_tables(kss_ctx* c, const IcpPlan& pl) {
+    if (c->tables_staged) return KSS_OK;
+    HIPCHK(c, hipMemcpyAsync(c->nn_work.p, pl.nn.data(), pl.nn.size() * sizeof(NNWork), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->red_work.p, pl.red.data(), pl.red.size() * sizeof(RedWork), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->pair_red.p, pl.pred.data(), pl.pred.size() * sizeof(PairRed), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // pageable sources: do not outlive this call unsynchronised
+    c->tables_staged = true;
+    return KSS_OK;
+}
+
 // Upload plan tables and size the workspace.
 int stage_plan(kss_ctx* c, const IcpPlan& pl) {
     KCHK(ensure(c, c->tgt4, (size_t)pl.total_tgt_pad * sizeof(float4)));
@@ -411,10 +424,8 @@ int stage_plan(kss_ctx* c, const IcpPlan& pl) {
     KCHK(ensure(c, c->state, (size_t)pl.npairs * sizeof(PairState)));
     KCHK(ensure_pinned(c, c->h_sums, c->h_sums_cap, (size_t)pl.npairs * NSUMS * sizeof(double)));
     KCHK(ensure_pinned(c, c->h_state, c->h_state_cap, (size_t)pl.npairs * sizeof(PairState)));
-    HIPCHK(c, hipMemcpyAsync(c->nn_work.p, pl.nn.data(), pl.nn.size() * sizeof(NNWork), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->red_work.p, pl.red.data(), pl.red.size() * sizeof(RedWork), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->pair_red.p, pl.pred.data(), pl.pred.size() * sizeof(PairRed), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));   // the std::vector sources may die after return
+    c->tables_staged = false;
+    if (!pl.grid) KCHK(stage_tables(c, pl));   // the fused cell-list path needs them only if a query falls back
     return KSS_OK;
 }
 
@@ -518,8 +529,10 @@ int grid_setup(kss_ctx* c, IcpPlan& pl) {
     HIPCHK(c, hipMemcpyAsync((float4*)c->src0.p + g.src_base, c->cur[1].p, (size_t)ns * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipGetLastError());
     c->grid_stats[0] = gp.h; c->grid_stats[1] = gp.gx; c->grid_stats[2] = gp.gy; c->grid_stats[3] = gp.gz;
-    c->grid_stats[4] = 0; c->grid_stats[5] = 0; c->grid_stats[6] = ns; c->grid_stats[7] = nt;
-    if (c->prof) {   // one extra small kernel, only while profiling
+    if (c->stats_ns != ns || c->stats_nt != nt) { c->grid_stats[4] = 0; c->grid_stats[5] = 0; }
+    c->grid_stats[6] = ns; c->grid_stats[7] = nt;
+    if (c->prof && (c->stats_ns != ns || c->stats_nt != nt)) {   // one extra small kernel, once per problem size while profiling
+        c->stats_ns = ns; c->stats_nt = nt;
         KCHK(ensure(c, c->scratch_c, 64));
         HIPCHK(c, hipMemsetAsync(c->scratch_c.p, 0, 16, c->stream));
         launch_grid_stats(c->stream, (const float4*)c->src0.p + g.src_base, ns, gp, (const int32_t*)c->g_start.p, (unsigned long long*)c->scratch_c.p);
@@ -637,6 +650,7 @@ int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, float4*
         if (((const double*)c->h_sums)[NSUMS - 1] > 0.0) {
             // queries the cell search gave up on (far from the target): brute-force sweep over the list,
             // then the reduce again over every source
+            KCHK(stage_tables(c, pl));
             {
                 ProfScope ps(c, KSS_K_NN_SWEEP);
                 launch_nn_sweep_list(c->stream, pl.S, fma, (const NNWork*)c->nn_work.p, (int)pl.nn.size(), (const PairState*)c->state.p,
