@@ -104,6 +104,18 @@ int kss_nn(kss_ctx *ctx, const float *src, int64_t ns, const float *tgt, int64_t
 int kss_nn_dev(kss_ctx *ctx, const float *d_src, int64_t ns, const float *d_tgt, int64_t nt,
                int32_t *d_idx, float *d_d2);
 
+/* ---- exact k-NN (k <= 32): pcl::KdTreeFLANN::nearestKSearch with K > 1 (ballRegionCompute.hpp:499 K = 13,
+ *      Method_AIVS_SimPro.hpp:904 K = 3, Method_Octree.hpp:137, pcl::NormalEstimation K = 20) ----
+ * idx / d2: nq * k entries, per query in ascending (d2, index) order; slots beyond nt hold -1 / +inf. */
+int kss_knn(kss_ctx *ctx, const float *query, int64_t nq, const float *tgt, int64_t nt, int k, int32_t *idx, float *d2);
+int kss_knn_dev(kss_ctx *ctx, const float *d_query, int64_t nq, const float *d_tgt, int64_t nt, int k, int32_t *d_idx, float *d_d2);
+
+/* ---- surface normals: estimateNormal_PCL_MP_return, normalCompute.hpp:308-355 ----
+ * pcl::NormalEstimationOMP semantics (k nearest neighbours incl. the point itself, float single-pass covariance,
+ * closed-form smallest eigenvector, flipped towards the view point (0,0,0)) and the reference's renormalisation in
+ * double.  normals: n * 3 doubles.  The reference uses k = 20. */
+int kss_normals(kss_ctx *ctx, const double *pts, int64_t n, int k, double *normals);
+
 /* ---- (a10) correspondence sums for TransformationEstimationSVD / umeyama (inside PCL ICP) ----
  * sums[0]=n kept (d2 <= max_d2), [1..3]=sum src, [4..6]=sum tgt[idx], [7..15]=sum src_i*tgt_j
  * (i major), [16]=sum d2 kept, [17]=sum d2 all, [18]=sum sqrt(d2) all, [19]=0.  f64, reduced

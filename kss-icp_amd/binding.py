@@ -24,7 +24,7 @@ SYMBOLS = [
     "kss_nn", "kss_nn_dev", "kss_cov", "kss_cov_dev", "kss_rigid_from_sums", "kss_rotation_search",
     "kss_rotation_search_dev", "kss_grid_angles", "kss_rotation_candidates", "kss_icp_default_params", "kss_icp",
     "kss_icp_dev", "kss_icp_batch", "kss_icp_batch_dev", "kss_transform_apply", "kss_transform_apply_dev",
-    "kss_pcr_qm", "kss_register", "kss_gather_results", "kss_transform_apply_f32", "kss_downsample_fps", "kss_downsample_aivs",
+    "kss_pcr_qm", "kss_register", "kss_gather_results", "kss_transform_apply_f32", "kss_downsample_fps", "kss_downsample_aivs", "kss_knn", "kss_knn_dev", "kss_normals",
 ]
 
 
@@ -130,6 +130,9 @@ def load_library():
     L.kss_transform_apply_f32.argtypes = [vp, vp, vp, i64, vp]
     L.kss_downsample_fps.argtypes = [vp, vp, i64, i64, vp, vp]
     L.kss_downsample_aivs.argtypes = [vp, vp, i64, i64, vp, i64, C.POINTER(i64), vp]
+    for n in ("kss_knn", "kss_knn_dev"):
+        getattr(L, n).argtypes = [vp, vp, i64, vp, i64, C.c_int, vp, vp]
+    L.kss_normals.argtypes = [vp, vp, i64, C.c_int, vp]
     L.kss_register.argtypes = [vp, vp, i64, vp, i64, vp, i64, dbl, C.c_int, vp, C.POINTER(RegisterResult)]
     L.kss_gather_results.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
     _LIB = L
@@ -387,6 +390,19 @@ class Context:
         k = C.c_int64(0)
         self._chk(self.L.kss_downsample_aivs(self.h, _p(a), len(a), int(point_num), _p(out), len(a), C.byref(k), _p(idx)), "kss_downsample_aivs")
         return out[:k.value].copy(), idx[:k.value].copy()
+
+    def knn(self, query, tgt, k):
+        q, t = _f32(query), _f32(tgt)
+        idx = np.empty((len(q), int(k)), np.int32)
+        d2 = np.empty((len(q), int(k)), np.float32)
+        self._chk(self.L.kss_knn(self.h, _p(q), len(q), _p(t), len(t), int(k), _p(idx), _p(d2)), "kss_knn")
+        return idx, d2
+
+    def normals(self, pts, k=20):
+        a = _f64(pts)
+        out = np.empty_like(a)
+        self._chk(self.L.kss_normals(self.h, _p(a), len(a), int(k), _p(out)), "kss_normals")
+        return out
 
     # ---- PCR_QM
     def pcr_qm(self, aligned, tmpl):

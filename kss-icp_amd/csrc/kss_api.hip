@@ -891,6 +891,69 @@ int kss_nn(kss_ctx* c, const float* src, int64_t ns, const float* tgt, int64_t n
     return KSS_OK;
 }
 
+// ---- k-NN and normals -------------------------------------------------------------------------------
+static int knn_generic_dev(kss_ctx* c, const void* d_q, int64_t nq, const void* d_t, int64_t nt, int dtype, int k, int32_t* d_idx, float* d_d2) {
+    if (!c || !d_q || !d_t || !d_idx || !d_d2) return set_err(c, KSS_ERR_ARG, "knn: null argument");
+    if (nq <= 0 || nt <= 0 || k < 1 || k > 32) return set_err(c, KSS_ERR_ARG, "knn: need nq, nt > 0 and 1 <= k <= 32");
+    if (nq > 0x7fff0000ll || nt > 0x7fff0000ll) return set_err(c, KSS_ERR_ARG, "knn: cloud too large");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t nt_pad = (nt + NN_TILE - 1) / NN_TILE * NN_TILE;
+    KCHK(ensure(c, c->tgt4, (size_t)nt_pad * sizeof(float4)));
+    KCHK(ensure(c, c->src0, (size_t)nq * sizeof(float4)));
+    if (dtype == KSS_F64) {
+        launch_pack_f64_to_f4(c->stream, (const double*)d_q, nq, (float4*)c->src0.p, nq, false);
+        launch_pack_f64_to_f4(c->stream, (const double*)d_t, nt, (float4*)c->tgt4.p, nt_pad, true);
+    } else {
+        launch_pack_f3_to_f4(c->stream, (const float*)d_q, nq, (float4*)c->src0.p, nq, false);
+        launch_pack_f3_to_f4(c->stream, (const float*)d_t, nt, (float4*)c->tgt4.p, nt_pad, true);
+    }
+    {
+        ProfScope ps(c, KSS_K_NN_SWEEP);
+        launch_knn_sweep(c->stream, (const float4*)c->src0.p, (int)nq, (const float4*)c->tgt4.p, (int)nt_pad, k, d_idx, d_d2);
+    }
+    HIPCHK(c, hipGetLastError());
+    return KSS_OK;
+}
+
+int kss_knn_dev(kss_ctx* c, const float* d_query, int64_t nq, const float* d_tgt, int64_t nt, int k, int32_t* d_idx, float* d_d2) {
+    KCHK(knn_generic_dev(c, d_query, nq, d_tgt, nt, KSS_F32, k, d_idx, d_d2));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KSS_OK;
+}
+
+int kss_knn(kss_ctx* c, const float* query, int64_t nq, const float* tgt, int64_t nt, int k, int32_t* idx, float* d2) {
+    if (!c || !query || !tgt || !idx || !d2) return set_err(c, KSS_ERR_ARG, "knn: null argument");
+    if (nq <= 0 || nt <= 0 || k < 1 || k > 32) return set_err(c, KSS_ERR_ARG, "knn: need nq, nt > 0 and 1 <= k <= 32");
+    HIPCHK(c, hipSetDevice(c->device));
+    KCHK(upload(c, c->stage_src, query, (size_t)nq * 3 * sizeof(float)));
+    KCHK(upload(c, c->stage_tgt, tgt, (size_t)nt * 3 * sizeof(float)));
+    KCHK(ensure(c, c->stage_idx, (size_t)nq * k * sizeof(int32_t)));
+    KCHK(ensure(c, c->stage_d2, (size_t)nq * k * sizeof(float)));
+    KCHK(knn_generic_dev(c, c->stage_src.p, nq, c->stage_tgt.p, nt, KSS_F32, k, (int32_t*)c->stage_idx.p, (float*)c->stage_d2.p));
+    HIPCHK(c, hipMemcpyAsync(idx, c->stage_idx.p, (size_t)nq * k * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d2, c->stage_d2.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KSS_OK;
+}
+
+int kss_normals(kss_ctx* c, const double* pts, int64_t n, int k, double* normals) {
+    if (!c || !pts || !normals) return set_err(c, KSS_ERR_ARG, "normals: null argument");
+    if (n <= 0 || k < 1 || k > 32) return set_err(c, KSS_ERR_ARG, "normals: need n > 0 and 1 <= k <= 32");
+    if (k > n) k = (int)n;
+    HIPCHK(c, hipSetDevice(c->device));
+    KCHK(upload(c, c->scratch_a, pts, (size_t)n * 3 * sizeof(double)));
+    KCHK(ensure(c, c->stage_idx, (size_t)n * k * sizeof(int32_t)));
+    KCHK(ensure(c, c->stage_d2, (size_t)n * k * sizeof(float)));
+    KCHK(ensure(c, c->stage_out, (size_t)n * 3 * sizeof(double)));
+    // self k-NN on the float-narrowed cloud (cloud_i.x = pointsVector[i][0]); src0 then holds the cloud as float4
+    KCHK(knn_generic_dev(c, c->scratch_a.p, n, c->scratch_a.p, n, KSS_F64, k, (int32_t*)c->stage_idx.p, (float*)c->stage_d2.p));
+    launch_normals(c->stream, (const float4*)c->src0.p, (int)n, (const int32_t*)c->stage_idx.p, k, (double*)c->stage_out.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(normals, c->stage_out.p, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KSS_OK;
+}
+
 // ---- covariance sums -----------------------------------------------------------------------------
 int kss_cov_dev(kss_ctx* c, const float* d_src, const float* d_tgt, const int32_t* d_idx, int64_t n, int64_t nt,
                 double max_d2, double sums[KSS_NSUMS]) {
@@ -1231,7 +1294,7 @@ int kss_register(kss_ctx* c, const double* src_sub, int64_t nss, const double* t
     res->E_d_init = r0.fitness;
     double chosen[3] = {best[0], best[1], best[2]};
     kss_icp_result rfinal = r0;
-    bool have_final = true;   // the judge ICP *is* the final ICP when the threshold branch is not taken
+    // the judge ICP *is* the final ICP when the threshold branch is not taken (same inputs, :93 vs :130)
     if (res->E_d_init > 0.0005 && nl > 0) {   // :99
         // (a14) all candidate ICPs as ONE batch sharing the target (:102-118)
         RCHK(ensure(c, dAll, (size_t)nl * nss * 3 * sizeof(double)));
@@ -1255,7 +1318,6 @@ int kss_register(kss_ctx* c, const double* src_sub, int64_t nss, const double* t
     } else if (res->E_d_init > 0.0005) {
         res->used_angle_list = 1;  // empty angle list: the reference would index out of range; keep the best grid pose
     }
-    (void)have_final;
     for (int k = 0; k < 3; ++k) res->angle[k] = chosen[k];
     res->final_fitness = rfinal.fitness;
     res->icp_iterations = rfinal.iterations;

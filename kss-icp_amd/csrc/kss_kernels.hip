@@ -378,7 +378,6 @@ __global__ __launch_bounds__(256) void sum_columns_kernel(const double* __restri
 __global__ __launch_bounds__(256) void preshape_sum_f32v_kernel(const float4* __restrict__ v, int64_t nf4, const float* __restrict__ xyz,
                                                                 int64_t nfloats, double* __restrict__ partials) {
     __shared__ double sh[4][3];
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0;   // sums of the elements whose (j + e) % 3 is 0 / 1 / 2, relative to j % 3 == 0
     double acc[3] = {0.0, 0.0, 0.0};
 #pragma unroll 4
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nf4; j += (int64_t)gridDim.x * blockDim.x) {
@@ -390,7 +389,6 @@ __global__ __launch_bounds__(256) void preshape_sum_f32v_kernel(const float4* __
         else if (m == 1) { acc[1] += e0; acc[2] += e1; acc[0] += e2; acc[1] += e3; }
         else { acc[2] += e0; acc[0] += e1; acc[1] += e2; acc[2] += e3; }
     }
-    (void)a0; (void)a1; (void)a2;
     if (blockIdx.x == 0 && threadIdx.x == 0)
         for (int64_t f = nf4 * 4; f < nfloats; ++f) acc[f % 3] += (double)xyz[f];   // < 4 trailing floats
     const double r = block_sum<3>(acc, sh);

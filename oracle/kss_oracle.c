@@ -1044,6 +1044,112 @@ int64_t ko_aivs(const double *P, int64_t n, int64_t point_num, int32_t *out_idx,
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* exact k-NN and PCL-style normals                                                         */
+/* ------------------------------------------------------------------------------------ */
+void ko_knn_brute(const float *q, int64_t nq, const float *t, int64_t nt, int k, int32_t *idx, float *d2) {
+#pragma omp parallel for schedule(static) if (nq >= 256)
+    for (int64_t i = 0; i < nq; i++) {
+        float *bd = d2 + i * k; int32_t *bi = idx + i * k;
+        for (int c = 0; c < k; c++) { bd[c] = INFINITY; bi[c] = -1; }
+        for (int64_t j = 0; j < nt; j++) {
+            float d = dist2(q + 3 * i, t + 3 * j, 0);
+            if (d < bd[k - 1]) {   /* ascending j: an equal distance never displaces an earlier (lower) index */
+                int pos = k - 1;
+                while (pos > 0 && d < bd[pos - 1]) { bd[pos] = bd[pos - 1]; bi[pos] = bi[pos - 1]; pos--; }
+                bd[pos] = d; bi[pos] = (int32_t)j;
+            }
+        }
+    }
+}
+
+static void pcl_roots2(float b, float c, float r[3]) {   /* computeRoots2 */
+    r[0] = 0.f;
+    float d = b * b - 4.0f * c;
+    if (d < 0.0f) d = 0.0f;
+    float sd = sqrtf(d);
+    r[2] = 0.5f * (b + sd);
+    r[1] = 0.5f * (b - sd);
+}
+
+static void pcl_roots(const float m[9], float r[3]) {   /* computeRoots, common/eigen.hpp */
+    float c0 = m[0] * m[4] * m[8] + 2.0f * m[1] * m[2] * m[5] - m[0] * m[5] * m[5] - m[4] * m[2] * m[2] - m[8] * m[1] * m[1];
+    float c1 = m[0] * m[4] - m[1] * m[1] + m[0] * m[8] - m[2] * m[2] + m[4] * m[8] - m[5] * m[5];
+    float c2 = m[0] + m[4] + m[8];
+    if (fabsf(c0) < FLT_EPSILON) { pcl_roots2(c2, c1, r); return; }
+    const float s_inv3 = (float)(1.0 / 3.0), s_sqrt3 = sqrtf(3.0f);
+    float c2_over_3 = c2 * s_inv3;
+    float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+    if (a_over_3 > 0.f) a_over_3 = 0.f;
+    float half_b = 0.5f * (c0 + c2_over_3 * (2.0f * c2_over_3 * c2_over_3 - c1));
+    float qq = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+    if (qq > 0.f) qq = 0.f;
+    float rho = sqrtf(-a_over_3);
+    float theta = atan2f(sqrtf(-qq), half_b) * s_inv3;
+    float ct = cosf(theta), st = sinf(theta);
+    r[0] = c2_over_3 + 2.0f * rho * ct;
+    r[1] = c2_over_3 - rho * (ct + s_sqrt3 * st);
+    r[2] = c2_over_3 - rho * (ct - s_sqrt3 * st);
+    float tmp;
+    if (r[0] >= r[1]) { tmp = r[0]; r[0] = r[1]; r[1] = tmp; }
+    if (r[1] >= r[2]) {
+        tmp = r[1]; r[1] = r[2]; r[2] = tmp;
+        if (r[0] >= r[1]) { tmp = r[0]; r[0] = r[1]; r[1] = tmp; }
+    }
+    if (r[0] <= 0) pcl_roots2(c2, c1, r);
+}
+
+void ko_normals_pcl(const double *P, int64_t n, int k, double *normals) {
+    float *pf = (float *)malloc(sizeof(float) * 3 * (size_t)n);
+    for (int64_t i = 0; i < 3 * n; i++) pf[i] = (float)P[i];   /* cloud_i.x = pointsVector[i][0] */
+    if (k > n) k = (int)n;
+    int32_t *idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)n * (size_t)k);
+    float *d2 = (float *)malloc(sizeof(float) * (size_t)n * (size_t)k);
+    ko_knn_brute(pf, n, pf, n, k, idx, d2);
+    for (int64_t i = 0; i < n; i++) {
+        /* computeMeanAndCovarianceMatrix (float, single pass) */
+        float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int c = 0; c < k; c++) {
+            const float *p = pf + 3 * (int64_t)idx[i * k + c];
+            a[0] += p[0] * p[0]; a[1] += p[0] * p[1]; a[2] += p[0] * p[2];
+            a[3] += p[1] * p[1]; a[4] += p[1] * p[2]; a[5] += p[2] * p[2];
+            a[6] += p[0]; a[7] += p[1]; a[8] += p[2];
+        }
+        for (int c = 0; c < 9; c++) a[c] /= (float)k;
+        float m[9];
+        m[0] = a[0] - a[6] * a[6]; m[1] = a[1] - a[6] * a[7]; m[2] = a[2] - a[6] * a[8];
+        m[4] = a[3] - a[7] * a[7]; m[5] = a[4] - a[7] * a[8]; m[8] = a[5] - a[8] * a[8];
+        m[3] = m[1]; m[6] = m[2]; m[7] = m[5];
+        /* solvePlaneParameters -> eigen33 (smallest eigenvalue + its eigenvector) */
+        float scale = 0.f;
+        for (int c = 0; c < 9; c++) if (fabsf(m[c]) > scale) scale = fabsf(m[c]);
+        if (scale <= FLT_MIN) scale = 1.0f;
+        float sm[9];
+        for (int c = 0; c < 9; c++) sm[c] = m[c] / scale;
+        float r[3];
+        pcl_roots(sm, r);
+        sm[0] -= r[0]; sm[4] -= r[0]; sm[8] -= r[0];
+        float v1[3] = {sm[1] * sm[5] - sm[2] * sm[4], sm[2] * sm[3] - sm[0] * sm[5], sm[0] * sm[4] - sm[1] * sm[3]};      /* row0 x row1 */
+        float v2[3] = {sm[1] * sm[8] - sm[2] * sm[7], sm[2] * sm[6] - sm[0] * sm[8], sm[0] * sm[7] - sm[1] * sm[6]};      /* row0 x row2 */
+        float v3[3] = {sm[4] * sm[8] - sm[5] * sm[7], sm[5] * sm[6] - sm[3] * sm[8], sm[3] * sm[7] - sm[4] * sm[6]};      /* row1 x row2 */
+        float l1 = v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2], l2 = v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2],
+              l3 = v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2];
+        float nx, ny, nz;
+        if (l1 >= l2 && l1 >= l3) { float s = sqrtf(l1); nx = v1[0] / s; ny = v1[1] / s; nz = v1[2] / s; }
+        else if (l2 >= l1 && l2 >= l3) { float s = sqrtf(l2); nx = v2[0] / s; ny = v2[1] / s; nz = v2[2] / s; }
+        else { float s = sqrtf(l3); nx = v3[0] / s; ny = v3[1] / s; nz = v3[2] / s; }
+        /* flipNormalTowardsViewpoint, view point (0, 0, 0) */
+        const float *p = pf + 3 * i;
+        float vx = 0.f - p[0], vy = 0.f - p[1], vz = 0.f - p[2];
+        float cos_theta = vx * nx + vy * ny + vz * nz;
+        if (cos_theta < 0) { nx *= -1; ny *= -1; nz *= -1; }
+        /* normalCompute.hpp:342-348: renormalise in double */
+        double dis = sqrt((double)nx * (double)nx + (double)ny * (double)ny + (double)nz * (double)nz);
+        normals[3 * i] = nx / dis; normals[3 * i + 1] = ny / dis; normals[3 * i + 2] = nz / dis;
+    }
+    free(pf); free(idx); free(d2);
+}
+
+/* ------------------------------------------------------------------------------------ */
 uint64_t ko_splitmix64(uint64_t seed, uint64_t counter) {
     uint64_t z = seed + (counter + 1) * 0x9E3779B97F4A7C15ULL;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;

@@ -178,6 +178,18 @@ void ko_fps(const double *xyz, int64_t n, int64_t m, int32_t *idx);
  * (may exceed point_num: the accurate cut stops when no live closest pair is left), or < 0 on error. */
 int64_t ko_aivs(const double *pts, int64_t n, int64_t point_num, int32_t *out_idx, int64_t cap);
 
+/* ---- exact k-NN in float (pcl::KdTreeFLANN::nearestKSearch with K > 1: ballRegionCompute.hpp:499 K=13,
+ *      Method_AIVS_SimPro.hpp:904 K=3, Method_Octree.hpp:137, inside pcl::NormalEstimation K=20) ----
+ * per query the k nearest targets in ascending (d2, index) order; d2 as in ko_nn_brute (no fma). */
+void ko_knn_brute(const float *q, int64_t nq, const float *t, int64_t nt, int k, int32_t *idx, float *d2);
+
+/* ---- normals: estimateNormal_PCL_MP_return, normalCompute.hpp:308-355 = pcl::NormalEstimationOMP (k = 20,
+ *      view point (0,0,0)) followed by a renormalisation in double.  PCL 1.8.1 restated from its published
+ *      source (features/normal_3d.h computePointNormal -> common/centroid.hpp computeMeanAndCovarianceMatrix
+ *      in float, single pass -> common/eigen.hpp eigen33 / computeRoots closed form -> flipNormalTowardsViewpoint).
+ *      PCL is absent from the reference tree: parity unpinned.  out: n*3 doubles. */
+void ko_normals_pcl(const double *pts, int64_t n, int k, double *normals);
+
 /* ---- synthetic clouds (portable counter-based RNG) ---- */
 uint64_t ko_splitmix64(uint64_t seed, uint64_t counter);
 

@@ -87,6 +87,8 @@ def lib():
         L.ko_ply_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_double))]
         L.ko_free.argtypes = [C.c_void_p]
         L.ko_fps.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.ko_knn_brute.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+        L.ko_normals_pcl.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         L.ko_aivs.restype = C.c_int64
         L.ko_aivs.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64]
         L.ko_splitmix64.restype = C.c_uint64
@@ -293,6 +295,21 @@ def fps(xyz, m):
     idx = np.empty(int(m), np.int32)
     lib().ko_fps(_p(a), len(a), int(m), _p(idx))
     return idx
+
+
+def knn_brute(q, t, k):
+    q, t = _f32(q), _f32(t)
+    idx = np.empty((len(q), k), np.int32)
+    d2 = np.empty((len(q), k), np.float32)
+    lib().ko_knn_brute(_p(q), len(q), _p(t), len(t), int(k), _p(idx), _p(d2))
+    return idx, d2
+
+
+def normals_pcl(pts, k=20):
+    a = _f64(pts)
+    out = np.empty_like(a)
+    lib().ko_normals_pcl(_p(a), len(a), int(k), _p(out))
+    return out
 
 
 def aivs(xyz, point_num):

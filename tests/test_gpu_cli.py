@@ -116,3 +116,28 @@ def test_aivs_matches_oracle(ctx, O, pkg, ref_pairs):
     assert e.value.status == -1
     with pytest.raises(RuntimeError):
         O.aivs(flat, 100)
+
+
+def test_knn_and_normals_match_oracle(ctx, O, pkg, ref_pairs):
+    """Exact k-NN (ascending (d2, index)) bit for bit; PCL-style normals within float round-off of the oracle's
+    restatement (device atan2f/cosf/sinf differ from glibc's in the last ulps)."""
+    rng = np.random.default_rng(2)
+    t = rng.normal(size=(3000, 3)).astype(np.float32)
+    t[100] = t[7]; t[2000] = t[7]                      # duplicates: ties keep the lower index first
+    q = np.concatenate([t[[7, 100]], rng.normal(size=(500, 3)).astype(np.float32)])
+    for k in (1, 3, 13, 20, 32):
+        idx, d2 = ctx.knn(q, t, k)
+        oi, od = O.knn_brute(q, t, k)
+        assert np.array_equal(idx, oi) and np.array_equal(d2.view(np.uint32), od.view(np.uint32))
+    idx, d2 = ctx.knn(q[:5], t[:4], 6)                 # fewer targets than k: -1 / +inf tail
+    oi, od = O.knn_brute(q[:5], t[:4], 6)
+    assert np.array_equal(idx, oi) and np.array_equal(d2, od) and (idx[:, 4:] == -1).all()
+    for P in (pkg.synth.bumpy(4, 6000), ref_pairs[("registration", "Horse")][0]):
+        n = ctx.normals(P, 20)
+        r = O.normals_pcl(P, 20)
+        assert np.abs(np.linalg.norm(n, axis=1) - 1).max() < 1e-12
+        dev = np.abs(n - r).max(axis=1)
+        assert np.mean(dev < 1e-4) > 0.995               # ill-conditioned (near-isotropic) neighbourhoods may differ more
+        assert np.median(dev) < 1e-6
+    with pytest.raises(pkg.KssError):
+        ctx.knn(q, t, 33)
