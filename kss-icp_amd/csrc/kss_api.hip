@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -18,6 +19,7 @@
 #include <vector>
 
 #include "kss_internal.hpp"
+#include "kss_host_pool.hpp"
 
 using namespace kss;
 
@@ -43,8 +45,10 @@ struct kss_ctx {
     // grow-only device workspace
     DevBuf tgt4, src0, cur[2], keys, partials, sums, nn_work, red_work, pair_red, state, cs, scratch_a,
         scratch_b, scratch_c, stage_src, stage_tgt, stage_idx, stage_d2, stage_out, g_counts, g_start, g_cursor,
-        g_bsums, g_sorted, g_list, g_count, g_bbox, g_partials, g_start2, g_pairs, g_stamps;
+        g_bsums, g_sorted, g_list, g_count, g_bbox, g_partials, g_start2, g_pairs, g_stamps, g_pos, pack_seg;
+    HostPool pool;   // per-pair host work of batched iterations
     std::vector<unsigned long long> last_stamps;
+    double evals_sum = 0.0, evals_launches = 0.0;   // diagnostic runs: distance evaluations of the fused grid launches
     // pinned host staging
     void* h_sums = nullptr;  size_t h_sums_cap = 0;   // host-mapped: kernels write it through h_sums_dev
     void* h_sums_dev = nullptr;
@@ -197,7 +201,7 @@ int kss_ctx_destroy(kss_ctx* c) {
     DevBuf* bufs[] = {&c->tgt4, &c->src0, &c->cur[0], &c->cur[1], &c->keys, &c->partials, &c->sums, &c->nn_work,
                       &c->red_work, &c->pair_red, &c->state, &c->cs, &c->scratch_a, &c->scratch_b, &c->scratch_c,
                       &c->stage_src, &c->stage_tgt, &c->stage_idx, &c->stage_d2, &c->stage_out, &c->g_counts, &c->g_start,
-                      &c->g_cursor, &c->g_bsums, &c->g_sorted, &c->g_list, &c->g_count, &c->g_bbox, &c->g_partials, &c->g_start2, &c->g_pairs, &c->g_stamps};
+                      &c->g_cursor, &c->g_bsums, &c->g_sorted, &c->g_list, &c->g_count, &c->g_bbox, &c->g_partials, &c->g_start2, &c->g_pairs, &c->g_stamps, &c->g_pos, &c->pack_seg};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (c->h_sums) hipHostFree(c->h_sums);
@@ -241,6 +245,14 @@ int kss_grid_stats(kss_ctx* c, double out[8]) {
     for (int k = 0; k < 8; ++k) out[k] = c->grid_stats[k];
     return KSS_OK;
 }
+// diagnostic: distance evaluations of the fused grid launches since the last call (KSS_GRID_STAMPS=1): {sum, launches}
+int kss_debug_grid_evals(kss_ctx* c, double out[2]) {
+    if (!c || !out) return KSS_ERR_ARG;
+    out[0] = c->evals_sum; out[1] = c->evals_launches;
+    c->evals_sum = 0.0; c->evals_launches = 0.0;
+    return KSS_OK;
+}
+
 // diagnostic: in-kernel timeline stamps of the last fused grid launch (KSS_GRID_STAMPS=1); not part of the ABI header
 int kss_debug_grid_stamps(kss_ctx* c, unsigned long long* out, int64_t cap) {
     if (!c || !out) return KSS_ERR_ARG;
@@ -441,6 +453,16 @@ int pack_clouds(kss_ctx* c, const IcpPlan& pl, const void* d_src, const int64_t*
         else launch_pack_f3_to_f4(c->stream, (const float*)base, pl.total_src, (float4*)c->src0.p, pl.total_src, false);
     }
     const int ntp = pl.shared_target ? 1 : pl.npairs;
+    if (ntp > 8) {   // many pairs: one launch over a per-pair segment table (segments are laid out back to back in tgt4)
+        std::vector<PackSeg> seg((size_t)ntp);
+        for (int p = 0; p < ntp; ++p) { seg[p].in_off = tgt_off[p]; seg[p].out_base = pl.g[p].tgt_base; seg[p].n = pl.g[p].nt; }
+        KCHK(ensure(c, c->pack_seg, seg.size() * sizeof(PackSeg)));
+        HIPCHK(c, hipMemcpyAsync(c->pack_seg.p, seg.data(), seg.size() * sizeof(PackSeg), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // `seg` is pageable and about to go out of scope
+        launch_pack_batch(c->stream, d_tgt, dtype, (const PackSeg*)c->pack_seg.p, ntp, pl.total_tgt_pad, (float4*)c->tgt4.p);
+        HIPCHK(c, hipGetLastError());
+        return KSS_OK;
+    }
     for (int p = 0; p < ntp; ++p) {
         const PairGeom& g = pl.g[p];
         const char* base = (const char*)d_tgt + (size_t)tgt_off[p] * 3 * esz;
@@ -500,6 +522,8 @@ int grid_setup(kss_ctx* c, IcpPlan& pl) {
     KCHK(ensure(c, c->g_bsums, ((ncells + 4095) / 4096 + 1) * sizeof(int32_t)));
     KCHK(ensure(c, c->g_sorted, (size_t)nt * sizeof(float4)));
     KCHK(ensure(c, c->g_list, (size_t)ns * sizeof(int32_t)));
+    KCHK(ensure(c, c->g_pos, (size_t)ns * sizeof(int32_t)));   // previous winner of every source: -1 = none yet
+    HIPCHK(c, hipMemsetAsync(c->g_pos.p, 0xff, (size_t)ns * sizeof(int32_t), c->stream));
     if (!c->h_seq) {
         void* p = nullptr;
         if (hipHostMalloc(&p, 64, hipHostMallocMapped) != hipSuccess) return set_err(c, KSS_ERR_NOMEM, "hipHostMalloc(seq)");
@@ -583,6 +607,8 @@ int grid_setup_batch(kss_ctx* c, IcpPlan& pl) {
     KCHK(ensure(c, c->g_cursor, (size_t)cells * sizeof(int32_t)));
     KCHK(ensure(c, c->g_bsums, (((size_t)cells + 4095) / 4096 + 1) * sizeof(int32_t)));
     KCHK(ensure(c, c->g_sorted, (size_t)sum_nt * sizeof(float4)));
+    KCHK(ensure(c, c->g_pos, (size_t)pl.total_src * sizeof(int32_t)));   // previous winners: -1 = none yet
+    HIPCHK(c, hipMemsetAsync(c->g_pos.p, 0xff, (size_t)pl.total_src * sizeof(int32_t), c->stream));
     if ((cells + 4095) / 4096 > 1024 * 16) return set_err(c, KSS_ERR_ARG, "batch cell lists too large for the scan");
     launch_gridb_build_targets(c->stream, (const float4*)c->tgt4.p, (int)pl.total_tgt_pad, (const GridPairDev*)c->g_pairs.p, np,
                                (int)cells, (int32_t*)c->g_counts.p, (int32_t*)c->g_start.p, (int32_t*)c->g_cursor.p,
@@ -629,8 +655,8 @@ int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, float4*
         unsigned long long* stamps = nullptr;
         const int nblk = grid_nn_blocks((int)pl.g[0].ns);
         if (getenv("KSS_GRID_STAMPS")) {   // diagnostic build of the timeline (tools/grid_stamps.py)
-            KCHK(ensure(c, c->g_stamps, (size_t)nblk * 8 * sizeof(unsigned long long)));
-            HIPCHK(c, hipMemsetAsync(c->g_stamps.p, 0, (size_t)nblk * 8 * sizeof(unsigned long long), c->stream));
+            KCHK(ensure(c, c->g_stamps, (size_t)nblk * 16 * sizeof(unsigned long long)));
+            HIPCHK(c, hipMemsetAsync(c->g_stamps.p, 0, (size_t)nblk * 16 * sizeof(unsigned long long), c->stream));
             stamps = (unsigned long long*)c->g_stamps.p;
         }
         {
@@ -639,13 +665,15 @@ int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, float4*
             launch_grid_nn(c->stream, fma, hs[0], d_in, d_out, (int)pl.g[0].ns, pl.gp, (const int32_t*)c->g_start.p,
                            (const float4*)c->g_sorted.p, (unsigned long long*)c->keys.p, (int32_t*)c->g_list.p, (int32_t*)c->g_count.p, max_d2,
                            (double*)c->g_partials.p, (int32_t*)c->g_count.p + 1, (double*)c->h_sums_dev, d_idx_out, d_d2_out,
-                           ++c->seq, c->h_seq_dev, stamps);
+                           ++c->seq, c->h_seq_dev, stamps, getenv("KSS_GRID_NOPREV") ? nullptr : (int32_t*)c->g_pos.p);
         }
         HIPCHK(c, hipGetLastError());
         KCHK(wait_seq(c));
         if (stamps) {
-            c->last_stamps.resize((size_t)nblk * 8);
+            c->last_stamps.resize((size_t)nblk * 16);
             HIPCHK(c, hipMemcpy(c->last_stamps.data(), stamps, c->last_stamps.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            for (int b = 0; b < nblk; ++b) c->evals_sum += (double)c->last_stamps[(size_t)b * 16 + 10];
+            c->evals_launches += 1.0;
         }
         if (((const double*)c->h_sums)[NSUMS - 1] > 0.0) {
             // queries the cell search gave up on (far from the target): brute-force sweep over the list,
@@ -666,10 +694,21 @@ int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, float4*
     }
     HIPCHK(c, hipMemcpyAsync(c->state.p, hs, (size_t)pl.npairs * sizeof(PairState), hipMemcpyHostToDevice, c->stream));
     if (pl.gridb) {
-        ProfScope ps(c, KSS_K_GRID_NN);
-        launch_gridb_nn(c->stream, fma, (const PairState*)c->state.p, (const GridPairDev*)c->g_pairs.p, pl.npairs, d_in, d_out,
-                        (int)pl.total_src, (const int32_t*)c->g_start.p, (const float4*)c->g_sorted.p, (unsigned long long*)c->keys.p);
-    } else {
+        // search + correspondence sums in one launch (one partial row per workgroup), then the per-pair row sums
+        {
+            ProfScope ps(c, KSS_K_GRID_NN);
+            launch_gridb_nn(c->stream, fma, (const RedWork*)c->red_work.p, (int)pl.red.size(), (const PairState*)c->state.p,
+                            (const GridPairDev*)c->g_pairs.p, d_in, d_out, (const int32_t*)c->g_start.p, (const float4*)c->g_sorted.p,
+                            getenv("KSS_GRID_NOPREV") ? nullptr : (int32_t*)c->g_pos.p, max_d2, (double*)c->partials.p, d_idx_out, d_d2_out);
+        }
+        ProfScope ps(c, KSS_K_CORR_REDUCE);
+        launch_finalize_sums(c->stream, (const PairRed*)c->pair_red.p, pl.npairs, (const double*)c->partials.p,
+                             (double*)c->h_sums_dev, nullptr, nullptr);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return KSS_OK;
+    }
+    {
         ProfScope ps(c, KSS_K_NN_SWEEP);
         launch_nn_sweep(c->stream, pl.S, fma, (const NNWork*)c->nn_work.p, (int)pl.nn.size(), (const PairState*)c->state.p,
                         d_in, d_out, (const float4*)c->tgt4.p, (unsigned long long*)c->keys.p);
@@ -717,34 +756,44 @@ int icp_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P, kss_icp_res
         const float4* d_in = it == 0 ? (const float4*)c->src0.p : (const float4*)c->cur[(it - 1) & 1].p;
         float4* d_out = (float4*)c->cur[it & 1].p;
         KCHK(nn_pass(c, pl, P.nn_fma != 0, d_in, d_out, max_d2, nullptr, nullptr));
-        for (int p = 0; p < np; ++p) {
-            if (!active[p]) continue;
-            const double* s = hsum + (size_t)p * NSUMS;
-            if ((int)s[0] < P.min_correspondences) {   // PCL: "Not enough correspondences found"
-                state[p] = KSS_STATE_NO_CORRESPONDENCES; converged[p] = 0; active[p] = 0; --n_active;
-                set_state(hs[p], I, 0, 0);
-                continue;
+        // per-pair solve + convergence test: pairs are independent (a large batch is split over a few host threads;
+        // each pair is handled by exactly one thread, so the results do not depend on the split)
+        std::atomic<int> finished{0};
+        auto solve = [&](int pb, int pe) {
+            int fin_here = 0;
+            for (int p = pb; p < pe; ++p) {
+                if (!active[p]) continue;
+                const double* s = hsum + (size_t)p * NSUMS;
+                if ((int)s[0] < P.min_correspondences) {   // PCL: "Not enough correspondences found"
+                    state[p] = KSS_STATE_NO_CORRESPONDENCES; converged[p] = 0; active[p] = 0; ++fin_here;
+                    set_state(hs[p], I, 0, 0);
+                    continue;
+                }
+                float* tk = &Tk[(size_t)p * 16];
+                rigid_from_sums(s, tk);
+                mat4_mul(tk, &fin[(size_t)p * 16], &fin[(size_t)p * 16]);   // final = transformation_ * final
+                ++iters[p];
+                const double mse = s[16] / s[0];
+                last_mse[p] = mse;
+                if (p == 0 && P.trace_n && *P.trace_n < P.trace_cap) {
+                    if (P.trace_sums) std::memcpy(P.trace_sums + (size_t)(*P.trace_n) * NSUMS, s, NSUMS * sizeof(double));
+                    if (P.trace_Tk) std::memcpy(P.trace_Tk + (size_t)(*P.trace_n) * 16, tk, 16 * sizeof(float));
+                    ++*P.trace_n;
+                }
+                const bool done = conv[p].has_converged(iters[p], tk, mse);
+                state[p] = conv[p].state;
+                if (done) {
+                    converged[p] = 1; active[p] = 0; ++fin_here;
+                    set_state(hs[p], tk, 0, 1);
+                } else {
+                    set_state(hs[p], tk, 1, 1);   // next sweep applies T_k on load (transformCloud)
+                }
             }
-            float* tk = &Tk[(size_t)p * 16];
-            rigid_from_sums(s, tk);
-            mat4_mul(tk, &fin[(size_t)p * 16], &fin[(size_t)p * 16]);   // final = transformation_ * final
-            ++iters[p];
-            const double mse = s[16] / s[0];
-            last_mse[p] = mse;
-            if (p == 0 && P.trace_n && *P.trace_n < P.trace_cap) {
-                if (P.trace_sums) std::memcpy(P.trace_sums + (size_t)(*P.trace_n) * NSUMS, s, NSUMS * sizeof(double));
-                if (P.trace_Tk) std::memcpy(P.trace_Tk + (size_t)(*P.trace_n) * 16, tk, 16 * sizeof(float));
-                ++*P.trace_n;
-            }
-            const bool done = conv[p].has_converged(iters[p], tk, mse);
-            state[p] = conv[p].state;
-            if (done) {
-                converged[p] = 1; active[p] = 0; --n_active;
-                set_state(hs[p], tk, 0, 1);
-            } else {
-                set_state(hs[p], tk, 1, 1);   // next sweep applies T_k on load (transformCloud)
-            }
-        }
+            finished.fetch_add(fin_here, std::memory_order_relaxed);
+        };
+        if (np >= 64) c->pool.parallel_for(np, solve);
+        else solve(0, np);
+        n_active -= finished.load(std::memory_order_relaxed);
         ++it;
     }
     for (int p = 0; p < np; ++p) {

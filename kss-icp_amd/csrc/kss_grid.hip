@@ -184,7 +184,7 @@ void launch_grid_build(hipStream_t st, const float4* d_tgt, int n, const GridPar
 // and fill the machine with 16x the waves.
 constexpr int GRID_LPQ_DEFAULT = 1;   // lanes per query; measured on C2 (100k x 100k): 1 / 2 / 4 / 8 / 16
 constexpr int GRID_BS_DEFAULT = 512;  // workgroup size
-constexpr int GRID_PF = 4;            // points of every row fetched up front by the one-lane-per-query path
+constexpr int GRID_WALK = 8;          // points in flight per step of the one-lane-per-query walk
 
 template <bool FMA>
 __device__ __forceinline__ unsigned long long point_key(const float4 p, float qx, float qy, float qz) {
@@ -196,20 +196,104 @@ __device__ __forceinline__ unsigned long long point_key(const float4 p, float qx
 }
 
 // Scan the cell-ordered points [lo, hi): four independent loads in flight per step (indices clamped to the
-// last point: a duplicate cannot change a minimum), tracking where the best point sits in `sorted`.
+// last point: a duplicate cannot change a minimum), tracking where the best point sits in `sorted` and its
+// coordinates (three selects per evaluation are cheaper than re-loading the winner afterwards).
 template <bool FMA>
 __device__ __forceinline__ void scan_range(const float4* __restrict__ sorted, int lo, int hi, float qx, float qy, float qz,
-                                           unsigned long long& key, int& kpos) {
+                                           unsigned long long& key, int& kpos, float4& win) {
     for (int k = lo; k < hi; k += 4) {
         const int k1 = min(k + 1, hi - 1), k2 = min(k + 2, hi - 1), k3 = min(k + 3, hi - 1);
         const float4 p0 = sorted[k], p1 = sorted[k1], p2 = sorted[k2], p3 = sorted[k3];
         const unsigned long long e0 = point_key<FMA>(p0, qx, qy, qz), e1 = point_key<FMA>(p1, qx, qy, qz),
                                  e2 = point_key<FMA>(p2, qx, qy, qz), e3 = point_key<FMA>(p3, qx, qy, qz);
-        if (e0 < key) { key = e0; kpos = k; }
-        if (e1 < key) { key = e1; kpos = k1; }
-        if (e2 < key) { key = e2; kpos = k2; }
-        if (e3 < key) { key = e3; kpos = k3; }
+        if (e0 < key) { key = e0; kpos = k; win = p0; }
+        if (e1 < key) { key = e1; kpos = k1; win = p1; }
+        if (e2 < key) { key = e2; kpos = k2; win = p2; }
+        if (e3 < key) { key = e3; kpos = k3; win = p3; }
     }
+}
+
+// The r = 1 step of a one-lane query: the 3x3x3 block around cell (cx, cy, cz) is 9 x-rows of <= 3 cells, every
+// row ONE contiguous range of `sorted`.  A row-by-row scan is a chain of ~20 dependent L2 round trips; instead ALL
+// range bounds are issued at once and the points of all rows are then walked as one list.
+//
+// Temporal coherence: the target this source matched in the PREVIOUS iteration (position `pp` in `sorted`, -1 = none)
+// is evaluated first.  Its distance d0 is an upper bound of the answer, so a row / end cell of the block whose
+// distance from the query exceeds d0 cannot hold the winner NOR a tie and is not read at all: with g = the f32 gap
+// to the cell's slab minus eps (eps covers the rounding of the cell assignment and of the gap), every point there
+// has computed d2 >= (1 - 3 ulp) * sum(g^2) > 0.999999 * sum(g^2) > d0.  Near convergence d0 is a fraction of a
+// cell edge and ~4 of the 27 cells remain.  Results do not depend on `pp` (any target is a valid bound).
+//
+// The surviving ranges go into a per-lane queue in LDS (column threadIdx.x: private to the lane, so no barrier)
+// and are walked as ONE flattened list, GRID_WALK points in flight per step: the loads issued are the loads
+// needed (the vector memory pipe bounds this kernel: 36 unconditional float4 gathers per lane used to cost more
+// than the whole remaining search).  Returns the number of distance evaluations.
+template <bool FMA, int BS>
+__device__ __forceinline__ int block_walk(const GridParams& gp, const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
+                                          float qx, float qy, float qz, int cx, int cy, int cz, int pp, int2 (*rowq)[BS],
+                                          unsigned long long& key, int& kpos, float4& win) {
+    const int xl = max(cx - 1, 0), xr = min(cx + 1, gp.gx - 1);
+    int s0[9], s1[9], s2[9], s3[9];
+    bool ok[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int z = cz + t / 3 - 1, y = cy + t % 3 - 1;
+        ok[t] = z >= 0 && z < gp.gz && y >= 0 && y < gp.gy;
+        const int row = ok[t] ? (z * gp.gy + y) * gp.gx : 0;
+        s0[t] = cell_start[row + xl];       // [s0, s1) = cell cx-1 (empty when it does not exist: xl == cx)
+        s1[t] = cell_start[row + cx];       // [s1, s2) = cell cx
+        s2[t] = cell_start[row + cx + 1];   // [s2, s3) = cell cx+1 (empty when it does not exist: xr == cx)
+        s3[t] = cell_start[row + xr + 1];
+    }
+    float d0 = __builtin_inff();
+    if (pp >= 0) {
+        win = sorted[pp];
+        key = point_key<FMA>(win, qx, qy, qz);
+        kpos = pp;
+        d0 = __uint_as_float((unsigned)(key >> 32));
+    }
+    // squared slack-reduced gaps from the query to the neighbouring slabs (same face expressions as the termination
+    // bound of the shell loop); index 1 = the query's own slab
+    const float exl = fmaxf((qx - (gp.ox + (float)cx * gp.h)) - gp.eps, 0.f), exr = fmaxf(((gp.ox + (float)(cx + 1) * gp.h) - qx) - gp.eps, 0.f);
+    const float eyl = fmaxf((qy - (gp.oy + (float)cy * gp.h)) - gp.eps, 0.f), eyr = fmaxf(((gp.oy + (float)(cy + 1) * gp.h) - qy) - gp.eps, 0.f);
+    const float ezl = fmaxf((qz - (gp.oz + (float)cz * gp.h)) - gp.eps, 0.f), ezr = fmaxf(((gp.oz + (float)(cz + 1) * gp.h) - qz) - gp.eps, 0.f);
+    const float exl2 = exl * exl, exr2 = exr * exr;
+    const float ey2[3] = {eyl * eyl, 0.f, eyr * eyr}, ez2[3] = {ezl * ezl, 0.f, ezr * ezr};
+    int nrow = 0, total = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float g2 = ey2[t % 3] + ez2[t / 3];
+        const bool need = ok[t] && !(d0 < g2 * 0.999999f);
+        const bool left = !(d0 < (g2 + exl2) * 0.999999f), right = !(d0 < (g2 + exr2) * 0.999999f);
+        const int lo = left ? s0[t] : s1[t];
+        const int hi = right ? s3[t] : s2[t];
+        if (need && hi > lo) {
+            rowq[nrow][threadIdx.x] = make_int2(lo, hi);
+            ++nrow;
+            total += hi - lo;
+        }
+    }
+    int cur = 0, end = 0, nxt = 0;
+    if (nrow > 0) { const int2 v = rowq[0][threadIdx.x]; cur = v.x; end = v.y; nxt = 1; }
+    constexpr int U = GRID_WALK;
+    for (int e = 0; e < total; e += U) {
+        int at[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            at[j] = min(cur, end - 1);   // an exhausted lane repeats its last point (cannot change a minimum)
+            ++cur;
+            if (cur >= end && nxt < nrow) { const int2 v = rowq[nxt][threadIdx.x]; cur = v.x; end = v.y; ++nxt; }
+        }
+        float4 pt[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) pt[j] = sorted[at[j]];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const unsigned long long kk = point_key<FMA>(pt[j], qx, qy, qz);
+            if (kk < key) { key = kk; kpos = at[j]; win = pt[j]; }
+        }
+    }
+    return total + (pp >= 0 ? 1 : 0);
 }
 
 template <int LPQ>
@@ -269,14 +353,18 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
                                                       double* __restrict__ sums_out, int32_t* __restrict__ idx_out,
                                                       float* __restrict__ d2_out, unsigned long long seq,
                                                       volatile unsigned long long* __restrict__ seq_out,
-                                                      unsigned long long* __restrict__ stamps) {
-    // diagnostic stamps (100 MHz s_memrealtime; null in production): [block*8 + {0 start, 1 searched, 2 reduced,
-    // 3 ticketed}], last workgroup also [4 summed, 5 published]
-#define KSS_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+                                                      unsigned long long* __restrict__ stamps, int32_t* __restrict__ pos_prev) {
+    // diagnostic stamps (100 MHz s_memrealtime; null in production): [block*16 + {0 start, 1 searched, 2 reduced,
+    // 3 ticketed}], last workgroup also [4 summed, 5 published]; search phase: 6 source loaded,
+    // 8 block scanned, 9 shells done; 10 = distance evaluations of the workgroup (a count)
+#define KSS_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    // search-phase stamps drain the wave's loads first, so they time the dependent round trips (diagnostic runs only)
+#define KSS_STAMPW(k) do { if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); KSS_STAMP(k); } } while (0)
     KSS_STAMP(0);
     __shared__ double sh[BS / 64][NSUMS];
     __shared__ double shg[ROWSUM_GROUPS][NSUMS];
     __shared__ int s_last;
+    __shared__ int2 rowq[LPQ == 1 ? 9 : 1][BS];   // per-lane queue of the point ranges still to be read (LPQ == 1)
     const int sub = threadIdx.x % LPQ;   // ps travels as a kernel argument: no per-iteration upload
     constexpr int QPB = BS / LPQ;
     // The 20 correspondence sums are spread over the LPQ lanes of a query group: lane `sub` owns sums[sub + j*LPQ]
@@ -307,50 +395,24 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
             p.y = ((ps.m[4] * x + ps.m[5] * y) + ps.m[6] * z) + ps.m[7];
             p.z = ((ps.m[8] * x + ps.m[9] * y) + ps.m[10] * z) + ps.m[11];
         }
+        KSS_STAMPW(6);
         if (sub == 0) src_out[i] = p;
         const float qx = p.x, qy = p.y, qz = p.z;
         const int cx = cell_coord(qx, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(qy, gp.oy, gp.inv_h, gp.gy),
                   cz = cell_coord(qz, gp.oz, gp.inv_h, gp.gz);
         unsigned long long key = ~0ull;
         int kpos = 0;
+        float4 win = make_float4(0.f, 0.f, 0.f, 0.f);   // the best point so far (LPQ == 1: tracked; else re-loaded)
         bool done = false;
         // ---- r = 1: the whole 3x3x3 block, 9 rows of <= 3 cells each, every row ONE contiguous range ----
         if constexpr (LPQ == 1) {
-            // One lane, nine rows: a row-by-row scan is a chain of ~20 dependent L2 round trips.  Instead issue
-            // ALL 18 range bounds, then the first GRID_PF points of ALL rows (36 float4 in flight; at 1-2 waves
-            // per SIMD the VGPRs are there), and only then compute: three round trips instead of twenty.
-            constexpr int PF = GRID_PF;
-            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, gp.gx - 1);
-            int lo[9], hi[9];
+            const int pp = pos_prev ? pos_prev[i] : -1;
+            const int ev = block_walk<FMA, BS>(gp, cell_start, sorted, qx, qy, qz, cx, cy, cz, pp, rowq, key, kpos, win);
+            if (stamps) {   // diagnostic runs: distance evaluations of the r = 1 block, summed per workgroup into slot 10
+                int evs = ev;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int z = cz + t / 3 - 1, y = cy + t % 3 - 1;
-                const bool ok = z >= 0 && z < gp.gz && y >= 0 && y < gp.gy;
-                const int row = ok ? (z * gp.gy + y) * gp.gx : 0;
-                lo[t] = cell_start[row + x0];
-                hi[t] = ok ? cell_start[row + x1 + 1] : lo[t];   // empty range for rows outside the grid
-            }
-            float4 pf[9][PF];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-#pragma unroll
-                for (int e = 0; e < PF; ++e) {
-                    // clamped into the row's range (a duplicate cannot change a minimum); an empty row re-reads a
-                    // valid element that the guard below ignores
-                    const int k = hi[t] > lo[t] ? min(lo[t] + e, hi[t] - 1) : 0;
-                    pf[t][e] = sorted[k];
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                if (hi[t] > lo[t]) {
-#pragma unroll
-                    for (int e = 0; e < PF; ++e) {
-                        const unsigned long long kk = point_key<FMA>(pf[t][e], qx, qy, qz);
-                        if (kk < key) { key = kk; kpos = min(lo[t] + e, hi[t] - 1); }
-                    }
-                    if (hi[t] - lo[t] > PF) scan_range<FMA>(sorted, lo[t] + PF, hi[t], qx, qy, qz, key, kpos);
-                }
+                for (int m = 32; m > 0; m >>= 1) evs += __shfl_xor(evs, m, 64);
+                if ((threadIdx.x & 63) == 0) atomicAdd(&stamps[(size_t)blockIdx.x * 16 + 10], (unsigned long long)evs);
             }
         } else {
             const int x0 = max(cx - 1, 0), x1 = min(cx + 1, gp.gx - 1);
@@ -359,10 +421,11 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
                 const int z = cz + t / 3 - 1, y = cy + t % 3 - 1;
                 if (z >= 0 && z < gp.gz && y >= 0 && y < gp.gy) {
                     const int row = (z * gp.gy + y) * gp.gx;
-                    scan_range<FMA>(sorted, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, key, kpos);
+                    scan_range<FMA>(sorted, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, key, kpos, win);
                 }
             }
         }
+        KSS_STAMPW(8);
         for (int r = 1; r <= gp.rcap; ++r) {
             if (r > 1) {   // shell r: its (2r+1)^2 rows are dealt round-robin to the lanes
                 const int w = 2 * r + 1;
@@ -374,11 +437,11 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
                     const int row = (z * gp.gy + y) * gp.gx;
                     if (dz == -r || dz == r || dy == -r || dy == r) {
                         // a row on the shell's y/z faces: the whole x extent is new
-                        scan_range<FMA>(sorted, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, key, kpos);
+                        scan_range<FMA>(sorted, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, key, kpos, win);
                     } else {
                         // interior row of shell r: only its two x end cells are new
-                        if (cx - r >= 0) scan_range<FMA>(sorted, cell_start[row + cx - r], cell_start[row + cx - r + 1], qx, qy, qz, key, kpos);
-                        if (cx + r < gp.gx) scan_range<FMA>(sorted, cell_start[row + cx + r], cell_start[row + cx + r + 1], qx, qy, qz, key, kpos);
+                        if (cx - r >= 0) scan_range<FMA>(sorted, cell_start[row + cx - r], cell_start[row + cx - r + 1], qx, qy, qz, key, kpos, win);
+                        if (cx + r < gp.gx) scan_range<FMA>(sorted, cell_start[row + cx + r], cell_start[row + cx + r + 1], qx, qy, qz, key, kpos, win);
                     }
                 }
             }
@@ -397,10 +460,12 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
             else if (bs > 0.f && best < bs * bs * 0.999999f) done = true;   // every unvisited point is strictly farther
             if (done) break;
         }
+        KSS_STAMPW(9);
         if (done) {
             const float d2 = __uint_as_float((unsigned)(key >> 32));
             const int idx = (int)(unsigned)(key & 0xffffffffull);
-            const float4 q = sorted[kpos];   // the winner's line was just read by a lane of this group: L1 hit
+            float4 q = win;
+            if constexpr (LPQ != 1) q = sorted[kpos];   // the winner's line was just read by a lane of this group: L1 hit
             const double dd = (double)d2;
             const bool keep = !(dd > max_d2);   // PCL: `if (distance[0] > max_dist_sqr) continue;`
             if constexpr (LPQ == 1) {
@@ -428,9 +493,11 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
                 const int oi = __float_as_int(p.w);   // original source index (sources are in cell order)
                 if (idx_out) idx_out[oi] = idx;
                 if (d2_out) d2_out[oi] = d2;
+                if (LPQ == 1 && pos_prev) pos_prev[i] = kpos;
             }
         } else if (sub == 0) {
             keys[i] = ~0ull;   // resolved by the brute-force list pass through atomicMin
+            if (LPQ == 1 && pos_prev) pos_prev[i] = -1;
             const int slot = atomicAdd(list_count, 1);
             list[slot] = i;
         }
@@ -498,7 +565,30 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
     __syncthreads();
     KSS_STAMP(3);
     if (!s_last) return;
-    double v = rows_column_sum_sc1(partials, (int)gridDim.x, shg);
+    // Column sums of the gridDim.x published rows, fixed order (bitwise reproducible): lane (g, c) adds rows g, g + FG,
+    // g + 2 FG, ... of column c -- eight sc1 loads in flight per batch, i.e. ONE cross-XCD round trip for <= 8 * FG rows
+    // (200 rows at C2) -- and the FG group totals are then added in group order.
+    constexpr int FG = BS / NSUMS;
+    __shared__ double shf[FG][NSUMS];
+    {
+        const int g = threadIdx.x / NSUMS, c = threadIdx.x % NSUMS, nrows = (int)gridDim.x;
+        if (g < FG) {
+            double a = 0.0;
+            for (int k = g; k < nrows; k += 8 * FG) {
+                double t[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    t[j] = k + j * FG < nrows ? __hip_atomic_load(&partials[(int64_t)(k + j * FG) * NSUMS + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a += t[j];
+            }
+            shf[g][c] = a;
+        }
+    }
+    __syncthreads();
+    double v = 0.0;
+    if (threadIdx.x < NSUMS)
+        for (int gg = 0; gg < FG; ++gg) v += shf[gg][threadIdx.x];
     if (threadIdx.x < NSUMS) {
         if (threadIdx.x == NSUMS - 1) v = (double)__hip_atomic_load(list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // write-through system-scope stores into the host-mapped result: no L2 write-back fence needed
@@ -513,6 +603,7 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
         // host-mapped completion flag: the host spins on it instead of paying a stream-sync wake-up per iteration
         if (seq_out) __hip_atomic_store((unsigned long long*)seq_out, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+#undef KSS_STAMPW
 #undef KSS_STAMP
 }
 
@@ -640,81 +731,102 @@ void launch_gridb_sort_sources(hipStream_t st, const float4* d_src, int total_sr
     hipLaunchKernelGGL(gridb_rank_fix_kernel, grid, block, 0, st, d_tmp, total_src, d_pairs, npairs, d_start, d_out);
 }
 
-// query: one lane per (sorted) source of the whole batch; writes keys[i] and the transformed source
+// query + correspondence sums: one workgroup per RedWork item (<= 256 consecutive sorted sources of ONE pair per
+// round), one lane per source.  Writes the transformed source, the previous-winner position and one partial row of
+// the 20 sums (the matched target's coordinates are still in registers: no gather pass); finalize_sums_kernel then
+// adds each pair's rows in row order.
 template <bool FMA>
-__global__ __launch_bounds__(256) void gridb_nn_kernel(const PairState* __restrict__ state, const GridPairDev* __restrict__ pairs,
-                                                       int npairs, const float4* __restrict__ src_in, float4* __restrict__ src_out,
-                                                       int total_src, const int32_t* __restrict__ cell_start,
-                                                       const float4* __restrict__ sorted, unsigned long long* __restrict__ keys) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total_src) return;
-    const int pi = pair_of(i, pairs, npairs, true);
-    const PairState ps = state[pi];
-    if (!ps.active) return;
-    const GridPairDev pr = pairs[pi];
-    const GridParams& gp = pr.gp;
-    float4 p = src_in[i];
-    if (ps.apply) {
-        const float x = p.x, y = p.y, z = p.z;
-        p.x = ((ps.m[0] * x + ps.m[1] * y) + ps.m[2] * z) + ps.m[3];
-        p.y = ((ps.m[4] * x + ps.m[5] * y) + ps.m[6] * z) + ps.m[7];
-        p.z = ((ps.m[8] * x + ps.m[9] * y) + ps.m[10] * z) + ps.m[11];
-    }
-    src_out[i] = p;
-    const float qx = p.x, qy = p.y, qz = p.z;
-    const int cx = cell_coord(qx, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(qy, gp.oy, gp.inv_h, gp.gy),
-              cz = cell_coord(qz, gp.oz, gp.inv_h, gp.gz);
-    const int32_t* __restrict__ cs = cell_start + pr.cell_base;
-    unsigned long long key = ~0ull;
-    int kpos = 0;
-    const int rmax = max(gp.gx, max(gp.gy, gp.gz));
-    for (int r = 1; r <= rmax; ++r) {
-        const int w = 2 * r + 1;
-        const int x0 = max(cx - r, 0), x1 = min(cx + r, gp.gx - 1);
-        if (r == 1) {
-            for (int t = 0; t < 9; ++t) {
-                const int z = cz + t / 3 - 1, y = cy + t % 3 - 1;
-                if (z < 0 || z >= gp.gz || y < 0 || y >= gp.gy) continue;
-                const int row = (z * gp.gy + y) * gp.gx;
-                scan_range<FMA>(sorted, cs[row + x0], cs[row + x1 + 1], qx, qy, qz, key, kpos);
+__global__ __launch_bounds__(256) void gridb_nn_kernel(const RedWork* __restrict__ work, const PairState* __restrict__ state,
+                                                       const GridPairDev* __restrict__ pairs, const float4* __restrict__ src_in,
+                                                       float4* __restrict__ src_out, const int32_t* __restrict__ cell_start,
+                                                       const float4* __restrict__ sorted, int32_t* __restrict__ pos_prev,
+                                                       double max_d2, double* __restrict__ partials,
+                                                       int32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
+    __shared__ int2 rowq[9][256];   // block_walk's per-lane range queue
+    __shared__ double sh[4][NSUMS];
+    const RedWork w = work[blockIdx.x];
+    const PairState ps = state[w.pair];
+    double acc[NSUMS];
+#pragma unroll
+    for (int c = 0; c < NSUMS; ++c) acc[c] = 0.0;
+    if (ps.active) {
+        const GridPairDev pr = pairs[w.pair];
+        const GridParams& gp = pr.gp;
+        const int32_t* __restrict__ cs = cell_start + pr.cell_base;
+        const int rmax = max(gp.gx, max(gp.gy, gp.gz));
+        for (int t = threadIdx.x; t < w.src_count; t += 256) {
+            const int i = w.src_begin + t;
+            float4 p = src_in[i];
+            if (ps.apply) {
+                const float x = p.x, y = p.y, z = p.z;
+                p.x = ((ps.m[0] * x + ps.m[1] * y) + ps.m[2] * z) + ps.m[3];
+                p.y = ((ps.m[4] * x + ps.m[5] * y) + ps.m[6] * z) + ps.m[7];
+                p.z = ((ps.m[8] * x + ps.m[9] * y) + ps.m[10] * z) + ps.m[11];
             }
-        } else {
-            for (int t = 0; t < w * w; ++t) {
-                const int dz = t / w - r, dy = t % w - r;
-                const int z = cz + dz, y = cy + dy;
-                if (z < 0 || z >= gp.gz || y < 0 || y >= gp.gy) continue;
-                const int row = (z * gp.gy + y) * gp.gx;
-                if (dz == -r || dz == r || dy == -r || dy == r) {
-                    scan_range<FMA>(sorted, cs[row + x0], cs[row + x1 + 1], qx, qy, qz, key, kpos);
+            src_out[i] = p;
+            const float qx = p.x, qy = p.y, qz = p.z;
+            const int cx = cell_coord(qx, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(qy, gp.oy, gp.inv_h, gp.gy),
+                      cz = cell_coord(qz, gp.oz, gp.inv_h, gp.gz);
+            unsigned long long key = ~0ull;
+            int kpos = 0;
+            float4 win = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int r = 1; r <= rmax; ++r) {
+                const int wd = 2 * r + 1;
+                const int x0 = max(cx - r, 0), x1 = min(cx + r, gp.gx - 1);
+                if (r == 1) {
+                    block_walk<FMA, 256>(gp, cs, sorted, qx, qy, qz, cx, cy, cz, pos_prev ? pos_prev[i] : -1, rowq, key, kpos, win);
                 } else {
-                    if (cx - r >= 0) scan_range<FMA>(sorted, cs[row + cx - r], cs[row + cx - r + 1], qx, qy, qz, key, kpos);
-                    if (cx + r < gp.gx) scan_range<FMA>(sorted, cs[row + cx + r], cs[row + cx + r + 1], qx, qy, qz, key, kpos);
+                    for (int u = 0; u < wd * wd; ++u) {
+                        const int dz = u / wd - r, dy = u % wd - r;
+                        const int z = cz + dz, y = cy + dy;
+                        if (z < 0 || z >= gp.gz || y < 0 || y >= gp.gy) continue;
+                        const int row = (z * gp.gy + y) * gp.gx;
+                        if (dz == -r || dz == r || dy == -r || dy == r) {
+                            scan_range<FMA>(sorted, cs[row + x0], cs[row + x1 + 1], qx, qy, qz, key, kpos, win);
+                        } else {
+                            if (cx - r >= 0) scan_range<FMA>(sorted, cs[row + cx - r], cs[row + cx - r + 1], qx, qy, qz, key, kpos, win);
+                            if (cx + r < gp.gx) scan_range<FMA>(sorted, cs[row + cx + r], cs[row + cx + r + 1], qx, qy, qz, key, kpos, win);
+                        }
+                    }
                 }
+                const float best = __uint_as_float((unsigned)(key >> 32));
+                float b = __builtin_inff();
+                if (cx - r > 0) b = fminf(b, qx - (gp.ox + (float)(cx - r) * gp.h));
+                if (cx + r < gp.gx - 1) b = fminf(b, (gp.ox + (float)(cx + r + 1) * gp.h) - qx);
+                if (cy - r > 0) b = fminf(b, qy - (gp.oy + (float)(cy - r) * gp.h));
+                if (cy + r < gp.gy - 1) b = fminf(b, (gp.oy + (float)(cy + r + 1) * gp.h) - qy);
+                if (cz - r > 0) b = fminf(b, qz - (gp.oz + (float)(cz - r) * gp.h));
+                if (cz + r < gp.gz - 1) b = fminf(b, (gp.oz + (float)(cz + r + 1) * gp.h) - qz);
+                const float bs = b - gp.eps;
+                if (b == __builtin_inff()) break;                              // the pair's whole grid has been visited
+                if (bs > 0.f && best < bs * bs * 0.999999f) break;             // every unvisited point is strictly farther
+            }
+            if (key != ~0ull) {   // (an empty target cannot happen: the plan rejects it)
+                const float d2 = __uint_as_float((unsigned)(key >> 32));
+                accumulate_corr(acc, qx, qy, qz, win.x, win.y, win.z, d2, max_d2);
+                if (pos_prev) pos_prev[i] = kpos;   // positions are global in the pair-by-pair `sorted`
+                const int oi = __float_as_int(p.w);
+                if (idx_out) idx_out[oi] = (int)(unsigned)(key & 0xffffffffull);
+                if (d2_out) d2_out[oi] = d2;
             }
         }
-        const float best = __uint_as_float((unsigned)(key >> 32));
-        float b = __builtin_inff();
-        if (cx - r > 0) b = fminf(b, qx - (gp.ox + (float)(cx - r) * gp.h));
-        if (cx + r < gp.gx - 1) b = fminf(b, (gp.ox + (float)(cx + r + 1) * gp.h) - qx);
-        if (cy - r > 0) b = fminf(b, qy - (gp.oy + (float)(cy - r) * gp.h));
-        if (cy + r < gp.gy - 1) b = fminf(b, (gp.oy + (float)(cy + r + 1) * gp.h) - qy);
-        if (cz - r > 0) b = fminf(b, qz - (gp.oz + (float)(cz - r) * gp.h));
-        if (cz + r < gp.gz - 1) b = fminf(b, (gp.oz + (float)(cz + r + 1) * gp.h) - qz);
-        const float bs = b - gp.eps;
-        if (b == __builtin_inff()) break;                              // the pair's whole grid has been visited
-        if (bs > 0.f && best < bs * bs * 0.999999f) break;             // every unvisited point is strictly farther
     }
-    keys[i] = key;
+    const double r = block_sum<NSUMS>(acc, sh);
+    if (threadIdx.x < NSUMS) partials[(int64_t)w.partial_index * NSUMS + threadIdx.x] = r;
 }
 
-void launch_gridb_nn(hipStream_t st, bool fma, const PairState* d_state, const GridPairDev* d_pairs, int npairs,
-                     const float4* d_src_in, float4* d_src_out, int total_src, const int32_t* d_cell_start,
-                     const float4* d_sorted, unsigned long long* d_keys) {
-    const dim3 grid((total_src + 255) / 256), block(256);
+void launch_gridb_nn(hipStream_t st, bool fma, const RedWork* d_work, int n_work, const PairState* d_state,
+                     const GridPairDev* d_pairs, const float4* d_src_in, float4* d_src_out, const int32_t* d_cell_start,
+                     const float4* d_sorted, int32_t* d_pos, double max_d2, double* d_partials, int32_t* d_idx_out,
+                     float* d_d2_out) {
+    if (n_work <= 0) return;
+    const dim3 grid(n_work), block(256);
     if (fma)
-        hipLaunchKernelGGL(gridb_nn_kernel<true>, grid, block, 0, st, d_state, d_pairs, npairs, d_src_in, d_src_out, total_src, d_cell_start, d_sorted, d_keys);
+        hipLaunchKernelGGL(gridb_nn_kernel<true>, grid, block, 0, st, d_work, d_state, d_pairs, d_src_in, d_src_out, d_cell_start,
+                           d_sorted, d_pos, max_d2, d_partials, d_idx_out, d_d2_out);
     else
-        hipLaunchKernelGGL(gridb_nn_kernel<false>, grid, block, 0, st, d_state, d_pairs, npairs, d_src_in, d_src_out, total_src, d_cell_start, d_sorted, d_keys);
+        hipLaunchKernelGGL(gridb_nn_kernel<false>, grid, block, 0, st, d_work, d_state, d_pairs, d_src_in, d_src_out, d_cell_start,
+                           d_sorted, d_pos, max_d2, d_partials, d_idx_out, d_d2_out);
 }
 
 // statistics for the roofline statement: evaluations of one r = 1 pass and occupied cells (profiling only)
@@ -770,11 +882,11 @@ static void grid_launch_bs(hipStream_t st, int bs, dim3 grid, const PairState& s
                            const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted, unsigned long long* d_keys,
                            int32_t* d_list, int32_t* d_list_count, double max_d2, double* d_partials, int32_t* d_ticket,
                            double* d_sums_out, int32_t* d_idx_out, float* d_d2_out, unsigned long long seq,
-                           unsigned long long* d_seq_out, unsigned long long* d_stamps) {
+                           unsigned long long* d_seq_out, unsigned long long* d_stamps, int32_t* d_pos) {
 #define KSS_GRID_LAUNCH(BV)                                                                                                  \
     hipLaunchKernelGGL((grid_nn_kernel<FMA, LPQ, BV>), grid, dim3(BV), 0, st, state, d_src_in, d_src_out, ns, gp, d_cell_start, \
                        d_sorted, d_keys, d_list, d_list_count, max_d2, d_partials, d_ticket, d_sums_out, d_idx_out, d_d2_out, seq,  \
-                       d_seq_out, d_stamps)
+                       d_seq_out, d_stamps, d_pos)
     if (bs == 1024) KSS_GRID_LAUNCH(1024); else if (bs == 512) KSS_GRID_LAUNCH(512); else KSS_GRID_LAUNCH(256);
 #undef KSS_GRID_LAUNCH
 }
@@ -783,11 +895,11 @@ void launch_grid_nn(hipStream_t st, bool fma, const PairState& state, const floa
                     const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted,
                     unsigned long long* d_keys, int32_t* d_list, int32_t* d_list_count, double max_d2, double* d_partials,
                     int32_t* d_ticket, double* d_sums_out, int32_t* d_idx_out, float* d_d2_out, unsigned long long seq,
-                    unsigned long long* d_seq_out, unsigned long long* d_stamps) {
+                    unsigned long long* d_seq_out, unsigned long long* d_stamps, int32_t* d_pos) {
     const dim3 grid(grid_nn_blocks(ns));
     const int lpq = grid_lpq(), bs = grid_bs();
 #define KSS_GRID_ARGS st, bs, grid, state, d_src_in, d_src_out, ns, gp, d_cell_start, d_sorted, d_keys, d_list, d_list_count, max_d2, \
-                      d_partials, d_ticket, d_sums_out, d_idx_out, d_d2_out, seq, d_seq_out, d_stamps
+                      d_partials, d_ticket, d_sums_out, d_idx_out, d_d2_out, seq, d_seq_out, d_stamps, d_pos
     if (fma) {
         switch (lpq) {
             case 1: grid_launch_bs<true, 1>(KSS_GRID_ARGS); break;

@@ -70,6 +70,13 @@ struct alignas(16) GridPairDev {
     int32_t pad;
 };
 
+// one pair's target segment for the batched pack kernel
+struct PackSeg {
+    int64_t in_off;     // first point in the caller's packed array
+    int64_t out_base;   // first slot in tgt4
+    int64_t n;          // real points; slots [n, next segment) are sentinel padding
+};
+
 constexpr int NN_TILE = 256;      // targets staged per LDS tile (one float4 per thread)
 constexpr int NN_SUB = 32;        // targets per sub-tile (arg-min bookkeeping granularity)
 constexpr int NN_THREADS = 256;
@@ -77,6 +84,7 @@ constexpr int NN_THREADS = 256;
 // ---- kernel launchers (kss_kernels.hip) ---------------------------------------------------------
 void launch_pack_f3_to_f4(hipStream_t st, const float* d_in, int64_t n, float4* d_out, int64_t n_pad, bool sentinel);
 void launch_pack_f64_to_f4(hipStream_t st, const double* d_in, int64_t n, float4* d_out, int64_t n_pad, bool sentinel);
+void launch_pack_batch(hipStream_t st, const void* d_in, int dtype, const PackSeg* d_seg, int nseg, int64_t total_out, float4* d_out);
 
 void launch_nn_sweep(hipStream_t st, int S, bool fma, const NNWork* d_work, int n_work,
                      const PairState* d_state, const float4* d_src_in, float4* d_src_out,
@@ -92,7 +100,7 @@ void launch_grid_nn(hipStream_t st, bool fma, const PairState& state, const floa
                     const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted,
                     unsigned long long* d_keys, int32_t* d_list, int32_t* d_list_count, double max_d2, double* d_partials,
                     int32_t* d_ticket, double* d_sums_out, int32_t* d_idx_out, float* d_d2_out, unsigned long long seq,
-                    unsigned long long* d_seq_out, unsigned long long* d_stamps);
+                    unsigned long long* d_seq_out, unsigned long long* d_stamps, int32_t* d_pos);
 int grid_nn_blocks(int ns);
 void launch_gridb_bbox(hipStream_t st, const float4* d_tgt, const GridPairDev* d_pairs, int npairs, float* d_bbox);
 void launch_gridb_build_targets(hipStream_t st, const float4* d_tgt, int total_tgt_pad, const GridPairDev* d_pairs, int npairs,
@@ -101,9 +109,10 @@ void launch_gridb_build_targets(hipStream_t st, const float4* d_tgt, int total_t
 void launch_gridb_sort_sources(hipStream_t st, const float4* d_src, int total_src, const GridPairDev* d_pairs, int npairs,
                                int total_cells, int32_t* d_counts, int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums,
                                float4* d_tmp, float4* d_out);
-void launch_gridb_nn(hipStream_t st, bool fma, const PairState* d_state, const GridPairDev* d_pairs, int npairs,
-                     const float4* d_src_in, float4* d_src_out, int total_src, const int32_t* d_cell_start,
-                     const float4* d_sorted, unsigned long long* d_keys);
+void launch_gridb_nn(hipStream_t st, bool fma, const RedWork* d_work, int n_work, const PairState* d_state,
+                     const GridPairDev* d_pairs, const float4* d_src_in, float4* d_src_out, const int32_t* d_cell_start,
+                     const float4* d_sorted, int32_t* d_pos, double max_d2, double* d_partials, int32_t* d_idx_out,
+                     float* d_d2_out);
 void launch_grid_stats(hipStream_t st, const float4* d_src, int ns, const GridParams& gp, const int32_t* d_cell_start,
                        unsigned long long* d_out /* [0] evaluations of the 3x3x3 block, [1] occupied cells */);
 void launch_grid_sort_sources(hipStream_t st, const float4* d_src, int n, const GridParams& gp, int32_t* d_counts,

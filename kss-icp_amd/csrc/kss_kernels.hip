@@ -50,6 +50,41 @@ void launch_pack_f64_to_f4(hipStream_t st, const double* d_in, int64_t n, float4
     hipLaunchKernelGGL(pack_to_f4_kernel<double>, dim3(blocks), dim3(256), 0, st, d_in, n, d_out, n_pad, sentinel ? 1 : 0);
 }
 
+// Batched form for the targets of many pairs: ONE launch instead of one per pair (a 1024-pair batch used to spend
+// more time launching pack kernels than searching).  Output slot i belongs to the pair whose padded segment
+// [out_base, out_base + out_pad) contains it (binary search in the per-pair table).
+template <typename T>
+__global__ __launch_bounds__(256) void pack_batch_kernel(const T* __restrict__ in, const PackSeg* __restrict__ seg, int nseg,
+                                                         int64_t total_out, float4* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total_out) return;
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (seg[mid].out_base <= i) lo = mid; else hi = mid - 1;
+    }
+    const PackSeg sg = seg[lo];
+    const int64_t k = i - sg.out_base;
+    float4 v;
+    if (k < sg.n) {
+        const T* __restrict__ q = in + 3 * (sg.in_off + k);
+        v = make_float4((float)q[0], (float)q[1], (float)q[2], 0.f);
+    } else {
+        const float f = __builtin_inff();   // sentinel padding: can never win an arg-min
+        v = make_float4(f, f, f, 0.f);
+    }
+    out[i] = v;
+}
+
+void launch_pack_batch(hipStream_t st, const void* d_in, int dtype, const PackSeg* d_seg, int nseg, int64_t total_out, float4* d_out) {
+    if (total_out <= 0 || nseg <= 0) return;
+    const int blocks = (int)((total_out + 255) / 256);
+    if (dtype == KSS_F64)
+        hipLaunchKernelGGL(pack_batch_kernel<double>, dim3(blocks), dim3(256), 0, st, (const double*)d_in, d_seg, nseg, total_out, d_out);
+    else
+        hipLaunchKernelGGL(pack_batch_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)d_in, d_seg, nseg, total_out, d_out);
+}
+
 // ---------------------------------------------------------------------------------------------
 // (b) NN sweep.  One workgroup = 256*S sources of one pair x one split of that pair's targets.
 //   - sources live in registers (S per lane), optionally transformed on load by the previous

@@ -16,16 +16,16 @@ p = ctx.icp_params(max_iterations=6, fixed_iterations=1, compute_fitness=0)
 ctx.icp_dev(ds.data_ptr(), n, dt.data_ptr(), n, p)
 ctx.icp_dev(ds.data_ptr(), n, dt.data_ptr(), n, p)
 L = pkg.load_library()
-buf = np.zeros(8 * 4096, np.uint64)
+buf = np.zeros(16 * 4096, np.uint64)
 L.kss_debug_grid_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 k = L.kss_debug_grid_stamps(ctx.h, buf.ctypes.data_as(C.c_void_p), buf.size)
-st = buf[:k].reshape(-1, 8).astype(np.int64)
+st = buf[:k].reshape(-1, 16).astype(np.int64)
 st = st[st[:, 0] > 0]
 t0 = st[:, 0].min()
 us = lambda a: (a - t0) / 100.0
-names = ["start", "searched", "reduced", "ticketed"]
+names = [(0, "start"), (6, "src"), (8, "block"), (9, "shells"), (1, "searched"), (2, "reduced"), (3, "ticketed")]
 print("workgroups:", len(st))
-for i, nm in enumerate(names):
+for i, nm in names:
     v = us(st[:, i])
     print("%-9s min %7.2f  median %7.2f  max %7.2f us" % (nm, v.min(), np.median(v), v.max()))
 last = st[st[:, 5] > 0]
