@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--mode", default="auto", choices=["auto", "brute", "grid"], help="NN engine of the timed path")
     ap.add_argument("--brute-steps", type=int, default=3, help="steps of the secondary brute-force measurement (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prof-stride", type=int, default=8,
+                    help="HIP-event timing of every n-th kernel launch inside the timed region (1 = every launch)")
     return ap.parse_args()
 
 
@@ -146,7 +148,7 @@ def main():
     step = make_step(a.mode)
     for _ in range(a.warmup):
         step()
-    ctx.profile_enable(True)
+    ctx.profile_enable(a.prof_stride)   # HIP events around every n-th launch of the timed region
     ctx.profile_reset()
     dt, last = run_steps(step, a.steps, dist, world, torch)
     prof = {k: ctx.profile_get(getattr(pkg, k)) for k in ("K_NN_SWEEP", "K_CORR_REDUCE", "K_GRID_NN", "K_GRID_BUILD")}

@@ -61,8 +61,10 @@ void *kss_ctx_stream(kss_ctx *ctx);
  * entry point has no nn_mode of its own or it is KSS_NN_AUTO.  Results never depend on it. */
 int   kss_ctx_set_nn_mode(kss_ctx *ctx, int nn_mode);
 
-/* per-kernel timing with HIP events recorded on the context's stream around every launch of
- * the named kernel class (used by bench.py for the roofline object). */
+/* per-kernel timing with HIP events recorded on the context's stream around launches of the named kernel
+ * class (used by bench.py for the roofline object).  kss_profile_enable(ctx, n): 0 = off, 1 = every launch,
+ * n > 1 = every n-th launch of each class (an event pair costs a few microseconds, comparable to the fused
+ * cell-list launch it brackets); kss_profile_get reports the sampled launches only. */
 enum { KSS_K_NN_SWEEP = 0, KSS_K_CORR_REDUCE = 1, KSS_K_PRESHAPE = 2, KSS_K_ROT_SEARCH = 3,
        KSS_K_POSE_APPLY = 4, KSS_K_GRID_NN = 5, KSS_K_GRID_BUILD = 6, KSS_K_COUNT = 7 };
 int kss_profile_enable(kss_ctx *ctx, int on);

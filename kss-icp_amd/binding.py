@@ -227,7 +227,8 @@ class Context:
 
     # ---- profiling
     def profile_enable(self, on=True):
-        self._chk(self.L.kss_profile_enable(self.h, 1 if on else 0), "kss_profile_enable")
+        """False/0 = off, True/1 = time every launch, n > 1 = time every n-th launch of each kernel class."""
+        self._chk(self.L.kss_profile_enable(self.h, int(on)), "kss_profile_enable")
 
     def profile_reset(self):
         self._chk(self.L.kss_profile_reset(self.h), "kss_profile_reset")

@@ -39,6 +39,8 @@ struct kss_ctx {
     int nn_mode = KSS_NN_AUTO;
     double grid_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     double last_setup_ms = 0, last_loop_ms = 0;
+    double t_launch_us = 0, t_wait_us = 0, t_host_us = 0;   // KSS_TIMING breakdown of the fused single-pair loop
+    bool timing = false;
     bool tables_staged = false;
     int64_t stats_ns = -1, stats_nt = -1;
 
@@ -52,13 +54,14 @@ struct kss_ctx {
     // pinned host staging
     void* h_sums = nullptr;  size_t h_sums_cap = 0;   // host-mapped: kernels write it through h_sums_dev
     void* h_sums_dev = nullptr;
-    unsigned long long* h_seq = nullptr;       // host-mapped completion flag of the fused grid kernel
+    unsigned long long* h_seq = nullptr;       // host-mapped result of the fused grid kernel: NSUMS x {bits(sum), sequence number}
     unsigned long long* h_seq_dev = nullptr;
     unsigned long long seq = 0;
     void* h_state = nullptr; size_t h_state_cap = 0;
 
     // profiling
-    bool prof = false;
+    int prof = 0;                       // 0 = off, n = event-time every n-th launch of each kernel class
+    unsigned prof_tick[KSS_K_COUNT] = {};
     struct EvPair { hipEvent_t a, b; };
     std::vector<EvPair> ev[KSS_K_COUNT];
     std::vector<EvPair> ev_pool;   // recycled event pairs: no hipEventCreate/Destroy inside timed loops
@@ -117,7 +120,8 @@ static int ensure_pinned(kss_ctx* c, void*& p, size_t& cap, size_t bytes) {
 
 struct ProfScope {   // records a start/stop event pair around a launch when profiling is on
     kss_ctx* c; int k; kss_ctx::EvPair ep; bool on;
-    ProfScope(kss_ctx* c_, int k_) : c(c_), k(k_), on(c_->prof) {
+    ProfScope(kss_ctx* c_, int k_) : c(c_), k(k_), on(c_->prof > 0) {
+        if (on && c->prof > 1) on = (c->prof_tick[k]++ % (unsigned)c->prof) == 0;   // sampled: the events themselves cost ~3 us
         if (!on) return;
         if (!c->ev_pool.empty()) {
             ep = c->ev_pool.back();
@@ -228,7 +232,8 @@ int kss_ctx_set_nn_mode(kss_ctx* c, int nn_mode) {
 
 int kss_profile_enable(kss_ctx* c, int on) {
     if (!c) return KSS_ERR_ARG;
-    c->prof = on != 0;
+    c->prof = on > 0 ? on : 0;
+    for (int k = 0; k < KSS_K_COUNT; ++k) c->prof_tick[k] = 0;
     if (c->prof) {   // pre-create the event pairs a timed region will use
         HIPCHK(c, hipSetDevice(c->device));
         while (c->ev_pool.size() < 4096) {
@@ -526,9 +531,9 @@ int grid_setup(kss_ctx* c, IcpPlan& pl) {
     HIPCHK(c, hipMemsetAsync(c->g_pos.p, 0xff, (size_t)ns * sizeof(int32_t), c->stream));
     if (!c->h_seq) {
         void* p = nullptr;
-        if (hipHostMalloc(&p, 64, hipHostMallocMapped) != hipSuccess) return set_err(c, KSS_ERR_NOMEM, "hipHostMalloc(seq)");
+        if (hipHostMalloc(&p, NSUMS * 16, hipHostMallocMapped) != hipSuccess) return set_err(c, KSS_ERR_NOMEM, "hipHostMalloc(seq)");
         c->h_seq = (unsigned long long*)p;
-        *c->h_seq = 0;
+        std::memset(p, 0, NSUMS * 16);
         void* d = nullptr;
         HIPCHK(c, hipHostGetDevicePointer(&d, p, 0));
         c->h_seq_dev = (unsigned long long*)d;
@@ -622,17 +627,29 @@ int grid_setup_batch(kss_ctx* c, IcpPlan& pl) {
     return KSS_OK;
 }
 
-// Wait for the fused grid kernel: spin on its host-mapped sequence number (a stream sync costs a 5-10 us
-// wake-up per ICP iteration); after ~2 ms without progress fall back to the stream sync, which also
-// surfaces a faulted kernel instead of spinning forever.
+// Wait for the fused grid kernel.  Its last workgroup stores every sum TOGETHER with the launch's sequence number as
+// one aligned 16-byte write into host-mapped memory ({bits(sum), seq} pairs): a slot whose sequence number matches
+// holds this launch's value, so there is no separate completion flag and no write-acknowledge round trip between
+// "sums stored" and "flag stored" on the device.  The host spins on the pairs (a stream sync costs a 5-10 us wake-up
+// per ICP iteration); after ~2 ms without progress it falls back to the stream sync, which also surfaces a faulted
+// kernel instead of spinning forever.  The sums are copied to h_sums, where the rest of the loop expects them.
 int wait_seq(kss_ctx* c) {
     const unsigned long long want = c->seq;
+    double* out = (double*)c->h_sums;
+    auto collect = [&]() -> bool {
+        for (int k = NSUMS - 1; k >= 0; --k) {   // slot 19 is written by the highest lane: usually the last to land
+            if (__atomic_load_n(&c->h_seq[2 * k + 1], __ATOMIC_ACQUIRE) != want) return false;
+            const unsigned long long bits = __atomic_load_n(&c->h_seq[2 * k], __ATOMIC_RELAXED);
+            std::memcpy(&out[k], &bits, sizeof(double));
+        }
+        return true;
+    };
     for (long spin = 0; spin < 2000000; ++spin) {
-        if (__atomic_load_n(c->h_seq, __ATOMIC_ACQUIRE) == want) return KSS_OK;
+        if (collect()) return KSS_OK;
         __builtin_ia32_pause();
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (__atomic_load_n(c->h_seq, __ATOMIC_ACQUIRE) != want) return set_err(c, KSS_ERR_HIP, "grid kernel finished without publishing its result");
+    if (!collect()) return set_err(c, KSS_ERR_HIP, "grid kernel finished without publishing its result");
     return KSS_OK;
 }
 
@@ -659,16 +676,23 @@ int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, float4*
             HIPCHK(c, hipMemsetAsync(c->g_stamps.p, 0, (size_t)nblk * 16 * sizeof(unsigned long long), c->stream));
             stamps = (unsigned long long*)c->g_stamps.p;
         }
+        const auto tl0 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
         {
             ProfScope ps(c, KSS_K_GRID_NN);
             // search + correspondence sums + final reduction in ONE launch; sums land in host-mapped memory
             launch_grid_nn(c->stream, fma, hs[0], d_in, d_out, (int)pl.g[0].ns, pl.gp, (const int32_t*)c->g_start.p,
                            (const float4*)c->g_sorted.p, (unsigned long long*)c->keys.p, (int32_t*)c->g_list.p, (int32_t*)c->g_count.p, max_d2,
-                           (double*)c->g_partials.p, (int32_t*)c->g_count.p + 1, (double*)c->h_sums_dev, d_idx_out, d_d2_out,
+                           (double*)c->g_partials.p, (int32_t*)c->g_count.p + 1, d_idx_out, d_d2_out,
                            ++c->seq, c->h_seq_dev, stamps, getenv("KSS_GRID_NOPREV") ? nullptr : (int32_t*)c->g_pos.p);
         }
         HIPCHK(c, hipGetLastError());
+        const auto tl1 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
         KCHK(wait_seq(c));
+        if (c->timing) {
+            const auto tl2 = std::chrono::steady_clock::now();
+            c->t_launch_us += std::chrono::duration<double, std::micro>(tl1 - tl0).count();
+            c->t_wait_us += std::chrono::duration<double, std::micro>(tl2 - tl1).count();
+        }
         if (stamps) {
             c->last_stamps.resize((size_t)nblk * 16);
             HIPCHK(c, hipMemcpy(c->last_stamps.data(), stamps, c->last_stamps.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -829,11 +853,15 @@ int icp_run_dev(kss_ctx* c, const void* d_src, const int64_t* src_off, const voi
     KCHK(grid_setup_batch(c, pl));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const auto t1 = std::chrono::steady_clock::now();
+    c->timing = getenv("KSS_TIMING") != nullptr;
+    c->t_launch_us = c->t_wait_us = 0;
     const int rc = icp_loop(c, pl, *p, results);
     const auto t2 = std::chrono::steady_clock::now();
     c->last_setup_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
     c->last_loop_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
-    if (getenv("KSS_TIMING")) std::fprintf(stderr, "[kss] setup %.3f ms, loop+fitness %.3f ms\n", c->last_setup_ms, c->last_loop_ms);
+    if (c->timing)
+        std::fprintf(stderr, "[kss] setup %.3f ms, loop+fitness %.3f ms (fused launches: enqueue %.1f us, wait %.1f us, rest = host math)\n",
+                     c->last_setup_ms, c->last_loop_ms, c->t_launch_us, c->t_wait_us);
     return rc;
 }
 

@@ -76,30 +76,6 @@ __device__ __forceinline__ double rows_column_sum(const double* __restrict__ row
     return v;
 }
 
-// Same, for rows published by OTHER workgroups of the running kernel with write-through (sc1) stores: every
-// load is an agent-scope relaxed atomic load (global_load ... sc1: served by L2, never by this CU's L1).
-__device__ __forceinline__ double rows_column_sum_sc1(const double* rows, int nrows, double (*shg)[NSUMS]) {
-    const int g = threadIdx.x / NSUMS, c = threadIdx.x % NSUMS;
-    if (g < ROWSUM_GROUPS) {
-        constexpr int G = ROWSUM_GROUPS;
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        int k = g;
-        for (; k + 3 * G < nrows; k += 4 * G) {
-            a0 += __hip_atomic_load(&rows[(int64_t)(k) * NSUMS + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a1 += __hip_atomic_load(&rows[(int64_t)(k + G) * NSUMS + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a2 += __hip_atomic_load(&rows[(int64_t)(k + 2 * G) * NSUMS + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a3 += __hip_atomic_load(&rows[(int64_t)(k + 3 * G) * NSUMS + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        for (; k < nrows; k += G) a0 += __hip_atomic_load(&rows[(int64_t)k * NSUMS + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        shg[g][c] = (a0 + a1) + (a2 + a3);
-    }
-    __syncthreads();
-    double v = 0.0;
-    if (threadIdx.x < NSUMS)
-        for (int gg = 0; gg < ROWSUM_GROUPS; ++gg) v += shg[gg][threadIdx.x];
-    return v;
-}
-
 // correspondence sums of one (source, matched target) pair; see KSS_NSUMS in include/kssicp.h
 __device__ __forceinline__ void accumulate_corr(double (&acc)[NSUMS], float px, float py, float pz,
                                                 float qx, float qy, float qz, float d2f, double max_d2) {

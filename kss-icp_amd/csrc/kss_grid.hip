@@ -176,15 +176,15 @@ void launch_grid_build(hipStream_t st, const float4* d_tgt, int n, const GridPar
 }
 
 // ---- query -----------------------------------------------------------------------------------------------
-// GRID_LPQ lanes cooperate on one query: the rows of a shell are dealt round-robin to the lanes, each
-// lane keeps its own best (d2, idx) packed as ONE unsigned 64-bit key (bits(d2) << 32 | idx: unsigned
-// order == smaller distance first, then lower index; d2 >= +0 so its bit pattern is monotone), and a
-// 4-step xor-shuffle min merges them.  A single lane per query is latency bound (a chain of ~60
-// dependent L2 loads over only 1.5 waves per SIMD at 100k queries); 16 lanes cut the chain to ~4 loads
-// and fill the machine with 16x the waves.
-constexpr int GRID_LPQ_DEFAULT = 1;   // lanes per query; measured on C2 (100k x 100k): 1 / 2 / 4 / 8 / 16
+// One lane per query.  A lane keeps its best (d2, idx) packed as ONE unsigned 64-bit key (bits(d2) << 32 | idx:
+// unsigned order == smaller distance first, then lower index; d2 >= +0 so its bit pattern is monotone).
+// (2-16 cooperating lanes per query were measured as well: once sources are cell-sorted and the block's ranges
+// are fetched up front, one lane wins at every size tried.)
 constexpr int GRID_BS_DEFAULT = 512;  // workgroup size
-constexpr int GRID_WALK = 8;          // points in flight per step of the one-lane-per-query walk
+#ifndef KSS_GRID_WALK
+#define KSS_GRID_WALK 8
+#endif
+constexpr int GRID_WALK = KSS_GRID_WALK;   // points in flight per step of the walk (4 / 8 / 16 measured equal)
 
 template <bool FMA>
 __device__ __forceinline__ unsigned long long point_key(const float4 p, float qx, float qy, float qz) {
@@ -296,16 +296,6 @@ __device__ __forceinline__ int block_walk(const GridParams& gp, const int32_t* _
     return total + (pp >= 0 ? 1 : 0);
 }
 
-template <int LPQ>
-__device__ __forceinline__ void group_min(unsigned long long& k, int& kpos) {
-#pragma unroll
-    for (int m = LPQ / 2; m > 0; m >>= 1) {
-        const unsigned long long o = __shfl_xor(k, m, LPQ);
-        const int op = __shfl_xor(kpos, m, LPQ);
-        if (o < k) { k = o; kpos = op; }
-    }
-}
-
 // ---- spatial order for the SOURCES: same cell order as the target, original index in .w ------------------
 // Sources are scattered into cell order with atomics (arbitrary order inside a cell) and then every element
 // computes its rank among the elements of its cell by original index, which makes the final order -- and
@@ -343,52 +333,48 @@ void launch_grid_sort_sources(hipStream_t st, const float4* d_src, int n, const 
 //     at agent scope, and the workgroup barrier publishes that to the other lanes before they load.
 //   Sources the search gives up on are excluded from the sums and counted in slot 19: the host then runs the
 //   brute-force list pass + the stand-alone reduce (rare: only for sources far from the target).
-template <bool FMA, int LPQ, int BS>
+template <bool FMA, int BS>
 __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const float4* __restrict__ src_in,
                                                       float4* __restrict__ src_out, int ns, GridParams gp,
                                                       const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
                                                       unsigned long long* __restrict__ keys,
                                                       int32_t* __restrict__ list, int32_t* __restrict__ list_count,
                                                       double max_d2, double* __restrict__ partials, int32_t* __restrict__ ticket,
-                                                      double* __restrict__ sums_out, int32_t* __restrict__ idx_out,
+                                                      int32_t* __restrict__ idx_out,
                                                       float* __restrict__ d2_out, unsigned long long seq,
-                                                      volatile unsigned long long* __restrict__ seq_out,
+                                                      unsigned long long* __restrict__ pub,
                                                       unsigned long long* __restrict__ stamps, int32_t* __restrict__ pos_prev) {
     // diagnostic stamps (100 MHz s_memrealtime; null in production): [block*16 + {0 start, 1 searched, 2 reduced,
-    // 3 ticketed}], last workgroup also [4 summed, 5 published]; search phase: 6 source loaded,
+    // 3 ticketed}], last workgroup also [4 result stored]; search phase: 6 source loaded,
     // 8 block scanned, 9 shells done; 10 = distance evaluations of the workgroup (a count)
 #define KSS_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     // search-phase stamps drain the wave's loads first, so they time the dependent round trips (diagnostic runs only)
 #define KSS_STAMPW(k) do { if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); KSS_STAMP(k); } } while (0)
     KSS_STAMP(0);
-    __shared__ double sh[BS / 64][NSUMS];
-    __shared__ double shg[ROWSUM_GROUPS][NSUMS];
+    constexpr int FG = BS / NSUMS;           // lane groups of the two column-sum stages below
+    __shared__ double shf[FG][NSUMS];
     __shared__ int s_last;
-    __shared__ int2 rowq[LPQ == 1 ? 9 : 1][BS];   // per-lane queue of the point ranges still to be read (LPQ == 1)
-    const int sub = threadIdx.x % LPQ;   // ps travels as a kernel argument: no per-iteration upload
-    constexpr int QPB = BS / LPQ;
-    // The 20 correspondence sums are spread over the LPQ lanes of a query group: lane `sub` owns sums[sub + j*LPQ]
-    // (NACC accumulators per lane instead of twenty: register pressure decides how many waves hide the
-    // latency of the search).  sums[c] = keep * pv * qv with pv in {1, px, py, pz}, qv in {1, qx, qy, qz}
-    // for c < 16 (0 count, 1..3 src, 4..6 tgt, 7..15 src_i * tgt_j); 16 = d2 kept, 17 = d2, 18 = sqrt(d2).
-    constexpr int NACC = (NSUMS + LPQ - 1) / LPQ;
-    double acc[NACC];
+    __shared__ int2 rowq[9][BS];   // block_walk's per-lane queue of point ranges
+    // the 20 correspondence sums of this lane's queries (KSS_NSUMS in include/kssicp.h); ps travels as a kernel
+    // argument: no per-iteration upload
+    double acc[NSUMS];
 #pragma unroll
-    for (int j = 0; j < NACC; ++j) acc[j] = 0.0;
+    for (int j = 0; j < NSUMS; ++j) acc[j] = 0.0;
 
     // XCD-aware, contiguous chunks: workgroups b and b+8 share an XCD (round-robin dispatch), so the virtual
     // index below hands every XCD one contiguous eighth of the (spatially sorted) sources and its L2 then
     // holds one eighth of the cell list; a different placement only changes speed, never results.
     const int per_xcd = (int)gridDim.x / 8;                     // the launcher makes gridDim.x a multiple of 8
     const int vb = ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8;   // bijection on [0, gridDim.x)
-    const int nrounds_total = (ns + QPB - 1) / QPB;             // one "round" = QPB queries of one workgroup
+    const int nrounds_total = (ns + BS - 1) / BS;               // one "round" = BS queries of one workgroup
     const int base = nrounds_total / (int)gridDim.x, rem = nrounds_total % (int)gridDim.x;
     const int rounds = base + (vb < rem ? 1 : 0);               // balanced: the first `rem` chunks are one longer
     const int first = vb * base + min(vb, rem);
     for (int rr = 0; rr < rounds; ++rr) {
-        const int i = (first + rr) * QPB + (int)threadIdx.x / LPQ;   // uniform per lane group
+        const int i = (first + rr) * BS + (int)threadIdx.x;
         if (i >= ns) break;
         float4 p = src_in[i];
+        const int pp = pos_prev ? pos_prev[i] : -1;
         if (ps.apply) {   // pcl transformCloud with the previous iteration's Matrix4f, as nn_sweep_kernel does
             const float x = p.x, y = p.y, z = p.z;
             p.x = ((ps.m[0] * x + ps.m[1] * y) + ps.m[2] * z) + ps.m[3];
@@ -396,41 +382,28 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
             p.z = ((ps.m[8] * x + ps.m[9] * y) + ps.m[10] * z) + ps.m[11];
         }
         KSS_STAMPW(6);
-        if (sub == 0) src_out[i] = p;
+        src_out[i] = p;
         const float qx = p.x, qy = p.y, qz = p.z;
         const int cx = cell_coord(qx, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(qy, gp.oy, gp.inv_h, gp.gy),
                   cz = cell_coord(qz, gp.oz, gp.inv_h, gp.gz);
         unsigned long long key = ~0ull;
         int kpos = 0;
-        float4 win = make_float4(0.f, 0.f, 0.f, 0.f);   // the best point so far (LPQ == 1: tracked; else re-loaded)
+        float4 win = make_float4(0.f, 0.f, 0.f, 0.f);   // the best point so far
         bool done = false;
-        // ---- r = 1: the whole 3x3x3 block, 9 rows of <= 3 cells each, every row ONE contiguous range ----
-        if constexpr (LPQ == 1) {
-            const int pp = pos_prev ? pos_prev[i] : -1;
-            const int ev = block_walk<FMA, BS>(gp, cell_start, sorted, qx, qy, qz, cx, cy, cz, pp, rowq, key, kpos, win);
-            if (stamps) {   // diagnostic runs: distance evaluations of the r = 1 block, summed per workgroup into slot 10
-                int evs = ev;
+        // ---- r = 1: the 3x3x3 block, pruned by the previous winner's distance ----
+        const int ev = block_walk<FMA, BS>(gp, cell_start, sorted, qx, qy, qz, cx, cy, cz, pp, rowq, key, kpos, win);
+        if (stamps) {   // diagnostic runs: distance evaluations of the r = 1 block, summed per workgroup into slot 10
+            int evs = ev;
 #pragma unroll
-                for (int m = 32; m > 0; m >>= 1) evs += __shfl_xor(evs, m, 64);
-                if ((threadIdx.x & 63) == 0) atomicAdd(&stamps[(size_t)blockIdx.x * 16 + 10], (unsigned long long)evs);
-            }
-        } else {
-            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, gp.gx - 1);
-#pragma unroll
-            for (int t = sub; t < 9; t += LPQ) {
-                const int z = cz + t / 3 - 1, y = cy + t % 3 - 1;
-                if (z >= 0 && z < gp.gz && y >= 0 && y < gp.gy) {
-                    const int row = (z * gp.gy + y) * gp.gx;
-                    scan_range<FMA>(sorted, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, key, kpos, win);
-                }
-            }
+            for (int m = 32; m > 0; m >>= 1) evs += __shfl_xor(evs, m, 64);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&stamps[(size_t)blockIdx.x * 16 + 10], (unsigned long long)evs);
         }
         KSS_STAMPW(8);
         for (int r = 1; r <= gp.rcap; ++r) {
-            if (r > 1) {   // shell r: its (2r+1)^2 rows are dealt round-robin to the lanes
+            if (r > 1) {   // shell r: (2r+1)^2 rows
                 const int w = 2 * r + 1;
                 const int x0 = max(cx - r, 0), x1 = min(cx + r, gp.gx - 1);
-                for (int t = sub; t < w * w; t += LPQ) {
+                for (int t = 0; t < w * w; ++t) {
                     const int dz = t / w - r, dy = t % w - r;
                     const int z = cz + dz, y = cy + dy;
                     if (z < 0 || z >= gp.gz || y < 0 || y >= gp.gy) continue;
@@ -445,7 +418,6 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
                     }
                 }
             }
-            group_min<LPQ>(key, kpos);
             const float best = __uint_as_float((unsigned)(key >> 32));
             // distance from the query to the faces of the visited block; faces on the grid border are open
             float b = __builtin_inff();
@@ -463,41 +435,15 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
         KSS_STAMPW(9);
         if (done) {
             const float d2 = __uint_as_float((unsigned)(key >> 32));
-            const int idx = (int)(unsigned)(key & 0xffffffffull);
-            float4 q = win;
-            if constexpr (LPQ != 1) q = sorted[kpos];   // the winner's line was just read by a lane of this group: L1 hit
-            const double dd = (double)d2;
-            const bool keep = !(dd > max_d2);   // PCL: `if (distance[0] > max_dist_sqr) continue;`
-            if constexpr (LPQ == 1) {
-                accumulate_corr(acc, qx, qy, qz, q.x, q.y, q.z, d2, max_d2);   // one lane owns all 20 sums: no selects
-            } else {
-#pragma unroll
-            for (int j = 0; j < NACC; ++j) {
-                const int c = sub + j * LPQ;   // the component this lane owns in slot j
-                const int pa = (c >= 1 && c <= 3) ? c - 1 : ((c >= 7 && c <= 15) ? (c - 7) / 3 : -1);
-                const int qb = (c >= 4 && c <= 6) ? c - 4 : ((c >= 7 && c <= 15) ? (c - 7) % 3 : -1);
-                const double pv = pa == 0 ? (double)qx : pa == 1 ? (double)qy : pa == 2 ? (double)qz : 1.0;
-                const double qv = qb == 0 ? (double)q.x : qb == 1 ? (double)q.y : qb == 2 ? (double)q.z : 1.0;
-                double v;
-                if (c < 16) v = keep ? pv * qv : 0.0;
-                else if (c == 16) v = keep ? dd : 0.0;
-                else if (c == 17) v = dd;
-                else if (c == 18) v = sqrt(dd);
-                else v = 0.0;
-                acc[j] += v;
-            }
-            }
-            (void)keep;
-            if (sub == 0) {
-                keys[i] = key;
-                const int oi = __float_as_int(p.w);   // original source index (sources are in cell order)
-                if (idx_out) idx_out[oi] = idx;
-                if (d2_out) d2_out[oi] = d2;
-                if (LPQ == 1 && pos_prev) pos_prev[i] = kpos;
-            }
-        } else if (sub == 0) {
+            accumulate_corr(acc, qx, qy, qz, win.x, win.y, win.z, d2, max_d2);
+            keys[i] = key;
+            if (pos_prev) pos_prev[i] = kpos;
+            const int oi = __float_as_int(p.w);   // original source index (sources are in cell order)
+            if (idx_out) idx_out[oi] = (int)(unsigned)(key & 0xffffffffull);
+            if (d2_out) d2_out[oi] = d2;
+        } else {
             keys[i] = ~0ull;   // resolved by the brute-force list pass through atomicMin
-            if (LPQ == 1 && pos_prev) pos_prev[i] = -1;
+            if (pos_prev) pos_prev[i] = -1;
             const int slot = atomicAdd(list_count, 1);
             list[slot] = i;
         }
@@ -505,47 +451,27 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
 
     KSS_STAMP(1);
     // ---- workgroup partial row, then the last workgroup finishes the job ----
+    // 20 f64 per lane: a shuffle tree costs 240 ds_bpermute + dependent adds per wave (measured ~3 us of a 20 us
+    // kernel).  Transpose through LDS instead: lane t stores column-major (conflict free), FG * 20 lanes each add one
+    // column's rows g, g + FG, ... and the FG group totals are added in group order.
     double r = 0.0;
-    if constexpr (LPQ == 1 && BS <= 512) {
-        // 20 f64 per lane: a shuffle tree costs 240 ds_bpermute + dependent adds per wave (measured ~3 us of a
-        // 20 us kernel).  Transpose through LDS instead: lane t stores column-major (conflict free), 240 lanes each
-        // add one column's rows g, g+12, ... and the 12 group totals are added in group order.
+    {
         __shared__ double shT[NSUMS][BS + 2];
 #pragma unroll
         for (int c = 0; c < NSUMS; ++c) shT[c][threadIdx.x] = acc[c];
         __syncthreads();
-        const int c = threadIdx.x / ROWSUM_GROUPS, g = threadIdx.x % ROWSUM_GROUPS;
+        const int c = threadIdx.x / FG, g = threadIdx.x % FG;
         if (c < NSUMS) {
             double a0 = 0.0, a1 = 0.0;
             int k = g;
-            for (; k + ROWSUM_GROUPS < BS; k += 2 * ROWSUM_GROUPS) { a0 += shT[c][k]; a1 += shT[c][k + ROWSUM_GROUPS]; }
+            for (; k + FG < BS; k += 2 * FG) { a0 += shT[c][k]; a1 += shT[c][k + FG]; }
             if (k < BS) a0 += shT[c][k];
-            shg[g][c] = a0 + a1;
+            shf[g][c] = a0 + a1;
         }
         __syncthreads();
         if (threadIdx.x < NSUMS)
-            for (int gg = 0; gg < ROWSUM_GROUPS; ++gg) r += shg[gg][threadIdx.x];
-        __syncthreads();   // shg is reused by the last workgroup below
-    } else {
-        // lanes of equal `sub` in the wave's 64/LPQ query groups hold the same components
-#pragma unroll
-        for (int j = 0; j < NACC; ++j) {
-#pragma unroll
-            for (int m = LPQ; m < 64; m <<= 1) acc[j] += __shfl_xor(acc[j], m, 64);
-        }
-        {
-            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-            if (lane < LPQ) {
-#pragma unroll
-                for (int j = 0; j < NACC; ++j)
-                    if (lane + j * LPQ < NSUMS) sh[wave][lane + j * LPQ] = acc[j];
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < NSUMS) {
-#pragma unroll
-            for (int w = 0; w < BS / 64; ++w) r += sh[w][threadIdx.x];   // wave order: reproducible
-        }
+            for (int gg = 0; gg < FG; ++gg) r += shf[gg][threadIdx.x];
+        __syncthreads();   // shf is reused by the last workgroup below
     }
     if (threadIdx.x < NSUMS) {
         // hand-off without an L2 write-back (MI355X_MICROARCH.md, "Valid forms", table row 1): EVERY store of the
@@ -568,8 +494,6 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
     // Column sums of the gridDim.x published rows, fixed order (bitwise reproducible): lane (g, c) adds rows g, g + FG,
     // g + 2 FG, ... of column c -- eight sc1 loads in flight per batch, i.e. ONE cross-XCD round trip for <= 8 * FG rows
     // (200 rows at C2) -- and the FG group totals are then added in group order.
-    constexpr int FG = BS / NSUMS;
-    __shared__ double shf[FG][NSUMS];
     {
         const int g = threadIdx.x / NSUMS, c = threadIdx.x % NSUMS, nrows = (int)gridDim.x;
         if (g < FG) {
@@ -591,18 +515,18 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
         for (int gg = 0; gg < FG; ++gg) v += shf[gg][threadIdx.x];
     if (threadIdx.x < NSUMS) {
         if (threadIdx.x == NSUMS - 1) v = (double)__hip_atomic_load(list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // write-through system-scope stores into the host-mapped result: no L2 write-back fence needed
-        __hip_atomic_store(&sums_out[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the sums have left before the sequence number below
+        // publish {bits(sum), seq} as ONE aligned 16-byte system-scope store per sum into host-mapped memory: the host
+        // accepts a slot when its sequence number matches, so no flag has to be ordered after the data (that ordering
+        // would cost a write-acknowledge round trip over PCIe) and no L2 write-back fence is needed
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const unsigned long long vb = (unsigned long long)__double_as_longlong(v);
+        u32x4 w;
+        w.x = (unsigned)vb; w.y = (unsigned)(vb >> 32); w.z = (unsigned)seq; w.w = (unsigned)(seq >> 32);
+        unsigned long long* dst = pub + 2 * threadIdx.x;
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(w) : "memory");
         KSS_STAMP(4);
     }
-    __syncthreads();
-    KSS_STAMP(5);
-    if (threadIdx.x == 0) {
-        *ticket = 0;   // re-arm for the next launch (stream order makes it visible)
-        // host-mapped completion flag: the host spins on it instead of paying a stream-sync wake-up per iteration
-        if (seq_out) __hip_atomic_store((unsigned long long*)seq_out, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (threadIdx.x == 0) *ticket = 0;   // re-arm for the next launch (stream order makes it visible)
 #undef KSS_STAMPW
 #undef KSS_STAMP
 }
@@ -865,58 +789,39 @@ static int env_int(const char* name, int dflt) {
     }
     return dflt;
 }
-// tuning hooks (defaults measured on C2, 100k x 100k; profiles/): lanes per query, workgroup size, workgroup cap
-static int grid_lpq() { const int v = env_int("KSS_GRID_LPQ", GRID_LPQ_DEFAULT); return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? v : GRID_LPQ_DEFAULT; }
-static int grid_bs() { const int v = env_int("KSS_GRID_BS", GRID_BS_DEFAULT); return (v == 256 || v == 512 || v == 1024) ? v : GRID_BS_DEFAULT; }
+// tuning hooks (defaults measured on C2, 100k x 100k; profiles/): workgroup size, workgroup cap
+static int grid_bs() { const int v = env_int("KSS_GRID_BS", GRID_BS_DEFAULT); return (v == 256 || v == 512) ? v : GRID_BS_DEFAULT; }
 
 int grid_nn_blocks(int ns) {
-    const int qpb = grid_bs() / grid_lpq();
-    const int need = (ns + qpb - 1) / qpb;
-    const int cap = env_int("KSS_GRID_BLOCKS", 131072 / grid_bs());   // one 512-lane workgroup per CU
+    const int bs = grid_bs();
+    const int need = (ns + bs - 1) / bs;
+    const int cap = env_int("KSS_GRID_BLOCKS", 131072 / bs);   // one 512-lane workgroup per CU
     const int nb = need < cap ? need : cap;
     return (nb + 7) / 8 * 8;   // multiple of 8: the XCD-aware block remap in the kernel is then a bijection
 }
 
-template <bool FMA, int LPQ>
-static void grid_launch_bs(hipStream_t st, int bs, dim3 grid, const PairState& state, const float4* d_src_in, float4* d_src_out, int ns,
-                           const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted, unsigned long long* d_keys,
-                           int32_t* d_list, int32_t* d_list_count, double max_d2, double* d_partials, int32_t* d_ticket,
-                           double* d_sums_out, int32_t* d_idx_out, float* d_d2_out, unsigned long long seq,
-                           unsigned long long* d_seq_out, unsigned long long* d_stamps, int32_t* d_pos) {
-#define KSS_GRID_LAUNCH(BV)                                                                                                  \
-    hipLaunchKernelGGL((grid_nn_kernel<FMA, LPQ, BV>), grid, dim3(BV), 0, st, state, d_src_in, d_src_out, ns, gp, d_cell_start, \
-                       d_sorted, d_keys, d_list, d_list_count, max_d2, d_partials, d_ticket, d_sums_out, d_idx_out, d_d2_out, seq,  \
-                       d_seq_out, d_stamps, d_pos)
-    if (bs == 1024) KSS_GRID_LAUNCH(1024); else if (bs == 512) KSS_GRID_LAUNCH(512); else KSS_GRID_LAUNCH(256);
-#undef KSS_GRID_LAUNCH
+template <bool FMA, int BS>
+static void grid_launch(hipStream_t st, dim3 grid, const PairState& state, const float4* d_src_in, float4* d_src_out, int ns,
+                        const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted, unsigned long long* d_keys,
+                        int32_t* d_list, int32_t* d_list_count, double max_d2, double* d_partials, int32_t* d_ticket,
+                        int32_t* d_idx_out, float* d_d2_out, unsigned long long seq,
+                        unsigned long long* d_pub, unsigned long long* d_stamps, int32_t* d_pos) {
+    hipLaunchKernelGGL((grid_nn_kernel<FMA, BS>), grid, dim3(BS), 0, st, state, d_src_in, d_src_out, ns, gp, d_cell_start,
+                       d_sorted, d_keys, d_list, d_list_count, max_d2, d_partials, d_ticket, d_idx_out, d_d2_out, seq,
+                       d_pub, d_stamps, d_pos);
 }
 
 void launch_grid_nn(hipStream_t st, bool fma, const PairState& state, const float4* d_src_in, float4* d_src_out, int ns,
                     const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted,
                     unsigned long long* d_keys, int32_t* d_list, int32_t* d_list_count, double max_d2, double* d_partials,
-                    int32_t* d_ticket, double* d_sums_out, int32_t* d_idx_out, float* d_d2_out, unsigned long long seq,
-                    unsigned long long* d_seq_out, unsigned long long* d_stamps, int32_t* d_pos) {
+                    int32_t* d_ticket, int32_t* d_idx_out, float* d_d2_out, unsigned long long seq,
+                    unsigned long long* d_pub, unsigned long long* d_stamps, int32_t* d_pos) {
     const dim3 grid(grid_nn_blocks(ns));
-    const int lpq = grid_lpq(), bs = grid_bs();
-#define KSS_GRID_ARGS st, bs, grid, state, d_src_in, d_src_out, ns, gp, d_cell_start, d_sorted, d_keys, d_list, d_list_count, max_d2, \
-                      d_partials, d_ticket, d_sums_out, d_idx_out, d_d2_out, seq, d_seq_out, d_stamps, d_pos
-    if (fma) {
-        switch (lpq) {
-            case 1: grid_launch_bs<true, 1>(KSS_GRID_ARGS); break;
-            case 2: grid_launch_bs<true, 2>(KSS_GRID_ARGS); break;
-            case 4: grid_launch_bs<true, 4>(KSS_GRID_ARGS); break;
-            case 16: grid_launch_bs<true, 16>(KSS_GRID_ARGS); break;
-            default: grid_launch_bs<true, 8>(KSS_GRID_ARGS); break;
-        }
-    } else {
-        switch (lpq) {
-            case 1: grid_launch_bs<false, 1>(KSS_GRID_ARGS); break;
-            case 2: grid_launch_bs<false, 2>(KSS_GRID_ARGS); break;
-            case 4: grid_launch_bs<false, 4>(KSS_GRID_ARGS); break;
-            case 16: grid_launch_bs<false, 16>(KSS_GRID_ARGS); break;
-            default: grid_launch_bs<false, 8>(KSS_GRID_ARGS); break;
-        }
-    }
+    const int bs = grid_bs();
+#define KSS_GRID_ARGS st, grid, state, d_src_in, d_src_out, ns, gp, d_cell_start, d_sorted, d_keys, d_list, d_list_count, max_d2, \
+                      d_partials, d_ticket, d_idx_out, d_d2_out, seq, d_pub, d_stamps, d_pos
+    if (fma) { if (bs == 256) grid_launch<true, 256>(KSS_GRID_ARGS); else grid_launch<true, 512>(KSS_GRID_ARGS); }
+    else     { if (bs == 256) grid_launch<false, 256>(KSS_GRID_ARGS); else grid_launch<false, 512>(KSS_GRID_ARGS); }
 #undef KSS_GRID_ARGS
 }
 

@@ -34,7 +34,7 @@ inline void svd3(const double A[9], double U[9], double s[3], double V[9]) {
                     beta += B[3 * k + q] * B[3 * k + q];
                     gamma += B[3 * k + p] * B[3 * k + q];
                 }
-                if (gamma == 0.0 || std::fabs(gamma) <= 1e-17 * std::sqrt(alpha * beta)) continue;
+                if (gamma == 0.0 || std::fabs(gamma) <= 1e-15 * std::sqrt(alpha * beta)) continue;
                 rotated = true;
                 const double zeta = (beta - alpha) / (2.0 * gamma);
                 const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
