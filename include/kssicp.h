@@ -76,6 +76,10 @@ int kss_grid_stats(kss_ctx *ctx, double out[8]);
 int kss_profile_reset(kss_ctx *ctx);
 /* synchronises the stream; total_ms = sum of event-timed durations, launches = count */
 int kss_profile_get(kss_ctx *ctx, int kernel_class, double *total_ms, int64_t *launches);
+/* what a HIP event pair reads around an EMPTY kernel launched into the idle stream (ms, mean of 200): an upper
+ * bound of what event timing adds to a short kernel's own duration.  bench.py reports it beside its per-launch
+ * durations (context for comparing them with rocprofv3's kernel trace); it is not subtracted. */
+int kss_profile_event_overhead(kss_ctx *ctx, double *ms);
 
 /* ---- (a2) KSS pre-shape: initRegistration_MiddleAlign, initRegistrationKSS.hpp:144-207 ----
  * centroid (mean of points) and mean distance to the centroid, accumulated in f64 with a

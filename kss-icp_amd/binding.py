@@ -20,7 +20,7 @@ F32, F64 = 0, 1
 SYMBOLS = [
     "kss_version", "kss_status_string", "kss_last_error", "kss_ctx_create", "kss_ctx_create_on_stream",
     "kss_ctx_destroy", "kss_ctx_synchronize", "kss_ctx_stream", "kss_ctx_set_nn_mode", "kss_profile_enable", "kss_profile_reset",
-    "kss_profile_get", "kss_grid_stats", "kss_preshape_stats", "kss_preshape_stats_dev", "kss_pose_apply", "kss_pose_apply_dev",
+    "kss_profile_get", "kss_profile_event_overhead", "kss_grid_stats", "kss_preshape_stats", "kss_preshape_stats_dev", "kss_pose_apply", "kss_pose_apply_dev",
     "kss_nn", "kss_nn_dev", "kss_cov", "kss_cov_dev", "kss_rigid_from_sums", "kss_rotation_search",
     "kss_rotation_search_dev", "kss_grid_angles", "kss_rotation_candidates", "kss_icp_default_params", "kss_icp",
     "kss_icp_dev", "kss_icp_batch", "kss_icp_batch_dev", "kss_transform_apply", "kss_transform_apply_dev",
@@ -106,6 +106,7 @@ def load_library():
     L.kss_profile_reset.argtypes = [vp]
     L.kss_grid_stats.argtypes = [vp, vp]
     L.kss_profile_get.argtypes = [vp, C.c_int, C.POINTER(dbl), C.POINTER(i64)]
+    L.kss_profile_event_overhead.argtypes = [vp, C.POINTER(dbl)]
     for n in ("kss_preshape_stats", "kss_preshape_stats_dev"):
         getattr(L, n).argtypes = [vp, vp, C.c_int, i64, vp, C.POINTER(dbl)]
     for n in ("kss_pose_apply", "kss_pose_apply_dev"):
@@ -232,6 +233,11 @@ class Context:
 
     def profile_reset(self):
         self._chk(self.L.kss_profile_reset(self.h), "kss_profile_reset")
+
+    def profile_event_overhead(self):
+        ms = C.c_double(0)
+        self._chk(self.L.kss_profile_event_overhead(self.h, C.byref(ms)), "kss_profile_event_overhead")
+        return ms.value
 
     def profile_get(self, k):
         ms, n = C.c_double(0), C.c_int64(0)

@@ -272,6 +272,30 @@ int kss_profile_reset(kss_ctx* c) {
     for (int k = 0; k < KSS_K_COUNT; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
     return KSS_OK;
 }
+int kss_profile_event_overhead(kss_ctx* c, double* ms) {
+    if (!c || !ms) return KSS_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipEvent_t a = nullptr, b = nullptr;
+    HIPCHK(c, hipEventCreate(&a));
+    HIPCHK(c, hipEventCreate(&b));
+    for (int i = 0; i < 16; ++i) launch_empty(c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double tot = 0.0;
+    const int reps = 200;
+    for (int i = 0; i < reps; ++i) {   // idle queue -> event, launch, event: the pattern of one fused ICP iteration
+        hipEventRecord(a, c->stream);
+        launch_empty(c->stream);
+        hipEventRecord(b, c->stream);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        float e = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&e, a, b));
+        tot += e;
+    }
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    *ms = tot / reps;
+    return KSS_OK;
+}
 int kss_profile_get(kss_ctx* c, int k, double* total_ms, int64_t* launches) {
     if (!c || k < 0 || k >= KSS_K_COUNT) return KSS_ERR_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -84,6 +84,7 @@ constexpr int NN_THREADS = 256;
 // ---- kernel launchers (kss_kernels.hip) ---------------------------------------------------------
 void launch_pack_f3_to_f4(hipStream_t st, const float* d_in, int64_t n, float4* d_out, int64_t n_pad, bool sentinel);
 void launch_pack_f64_to_f4(hipStream_t st, const double* d_in, int64_t n, float4* d_out, int64_t n_pad, bool sentinel);
+void launch_empty(hipStream_t st);
 void launch_pack_batch(hipStream_t st, const void* d_in, int dtype, const PackSeg* d_seg, int nseg, int64_t total_out, float4* d_out);
 
 void launch_nn_sweep(hipStream_t st, int S, bool fma, const NNWork* d_work, int n_work,

@@ -50,6 +50,10 @@ void launch_pack_f64_to_f4(hipStream_t st, const double* d_in, int64_t n, float4
     hipLaunchKernelGGL(pack_to_f4_kernel<double>, dim3(blocks), dim3(256), 0, st, d_in, n, d_out, n_pad, sentinel ? 1 : 0);
 }
 
+// empty launch: calibrates what a HIP event pair adds around a short kernel (kss_profile_event_overhead)
+__global__ void empty_kernel() {}
+void launch_empty(hipStream_t st) { hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, st); }
+
 // Batched form for the targets of many pairs: ONE launch instead of one per pair (a 1024-pair batch used to spend
 // more time launching pack kernels than searching).  Output slot i belongs to the pair whose padded segment
 // [out_base, out_base + out_pad) contains it (binary search in the per-pair table).
