@@ -169,6 +169,11 @@ typedef struct {
     float  *trace_Tk;                  /* trace_cap * 16 */
     int     trace_cap;
     int    *trace_n;
+    /* optional: the correspondences getFitnessScore() sums over -- nearest target index and squared distance of every
+     * source point of pair 0 under the final transform (host pointers, n_src entries each, may be NULL; filled only
+     * when compute_fitness is set) */
+    int32_t *fitness_idx;
+    float   *fitness_d2;
 } kss_icp_params;
 
 /* NN search structure.  BRUTE: the LDS-tiled source x target sweep (north star).  GRID: exact search

@@ -44,7 +44,8 @@ class IcpParams(C.Structure):
                 ("fixed_iterations", C.c_int), ("nn_fma", C.c_int), ("compute_fitness", C.c_int),
                 ("nn_sources_per_thread", C.c_int), ("nn_target_splits", C.c_int), ("nn_mode", C.c_int),
                 ("trace_sums", C.POINTER(C.c_double)), ("trace_Tk", C.POINTER(C.c_float)),
-                ("trace_cap", C.c_int), ("trace_n", C.POINTER(C.c_int))]
+                ("trace_cap", C.c_int), ("trace_n", C.POINTER(C.c_int)),
+                ("fitness_idx", C.POINTER(C.c_int32)), ("fitness_d2", C.POINTER(C.c_float))]
 
 
 class IcpResult(C.Structure):
@@ -328,11 +329,16 @@ class Context:
             setattr(p, k, v)
         return p
 
-    def icp(self, src, tgt, params=None, trace_cap=0):
+    def icp(self, src, tgt, params=None, trace_cap=0, fitness_corr=False):
         s, t = _f32(src), _f32(tgt)
         p = params if params is not None else self.icp_params()
         res = IcpResult()
         tr = None
+        fc = None
+        if fitness_corr:
+            fc = (np.full(len(s), -1, np.int32), np.full(len(s), np.nan, np.float32))
+            p.fitness_idx = fc[0].ctypes.data_as(C.POINTER(C.c_int32))
+            p.fitness_d2 = fc[1].ctypes.data_as(C.POINTER(C.c_float))
         if trace_cap > 0:
             sums = np.zeros((trace_cap, NSUMS), np.float64)
             tk = np.zeros((trace_cap, 16), np.float32)
@@ -349,6 +355,9 @@ class Context:
             out["trace_sums"] = tr[0][:tr[2].value].copy()
             out["trace_Tk"] = tr[1][:tr[2].value].reshape(-1, 4, 4).copy()
             p.trace_sums = None; p.trace_Tk = None; p.trace_cap = 0; p.trace_n = None
+        if fc:
+            out["fitness_idx"], out["fitness_d2"] = fc
+            p.fitness_idx = None; p.fitness_d2 = None
         return out
 
     def icp_dev(self, d_src, ns, d_tgt, nt, params):

@@ -853,8 +853,21 @@ int icp_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P, kss_icp_res
     if (P.compute_fitness) {
         // getFitnessScore(): NN of final * ORIGINAL input, mean d2 over all source points
         for (int p = 0; p < np; ++p) set_state(hs[p], &fin[(size_t)p * 16], 1, 1);
-        KCHK(nn_pass(c, pl, P.nn_fma != 0, (const float4*)c->src0.p, (float4*)c->cur[0].p, max_d2, nullptr, nullptr));
+        int32_t* d_idx = nullptr;
+        float* d_d2 = nullptr;
+        if (P.fitness_idx || P.fitness_d2) {   // per-source correspondences of this pass (indexed by original source index)
+            KCHK(ensure(c, c->stage_idx, (size_t)pl.total_src * sizeof(int32_t)));
+            KCHK(ensure(c, c->stage_d2, (size_t)pl.total_src * sizeof(float)));
+            d_idx = (int32_t*)c->stage_idx.p; d_d2 = (float*)c->stage_d2.p;
+        }
+        KCHK(nn_pass(c, pl, P.nn_fma != 0, (const float4*)c->src0.p, (float4*)c->cur[0].p, max_d2, d_idx, d_d2));
         for (int p = 0; p < np; ++p) results[p].fitness = hsum[(size_t)p * NSUMS + 17] / (double)pl.g[p].ns;
+        if (d_idx) {
+            const size_t n0 = (size_t)pl.g[0].ns;
+            if (P.fitness_idx) HIPCHK(c, hipMemcpyAsync(P.fitness_idx, d_idx, n0 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+            if (P.fitness_d2) HIPCHK(c, hipMemcpyAsync(P.fitness_d2, d_d2, n0 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
     }
     return KSS_OK;
 }

@@ -83,6 +83,45 @@ def test_grid_icp_bitwise_equals_brute(ctx, pkg):
     assert np.array_equal(c2["trace_sums"], c3["trace_sums"]) and np.array_equal(c2["T"], c3["T"])
 
 
+def _tie_lattice_pair(n_side=24):
+    """Targets on an integer lattice, sources on cell faces / edges / centres of that lattice (2, 4 and 8 targets at
+    exactly the same distance) and slightly off them: exact ties across cells, the case the previous-winner bound must
+    not prune (equal distance must still resolve to the lowest index)."""
+    g = np.arange(n_side, dtype=np.float32)
+    tgt = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3) * np.float32(0.125)
+    rng = np.random.default_rng(5)
+    tgt = tgt[rng.permutation(len(tgt))]                     # index order unrelated to position
+    base = tgt[rng.integers(0, len(tgt), 6000)]
+    off = rng.integers(0, 2, size=(6000, 3)).astype(np.float32) * np.float32(0.0625)   # 0 or half a lattice step per axis
+    src = base + off
+    src[::3] += rng.normal(scale=1e-3, size=(2000, 3)).astype(np.float32)
+    return src.astype(np.float32), tgt.astype(np.float32)
+
+
+@pytest.mark.parametrize("case", ["bumpy", "ties", "duplicates", "c2"])
+def test_grid_warm_started_search_is_bit_exact(ctx, O, pkg, case):
+    """After the first iteration the cell search starts from each source's previous winner and skips the cells that
+    bound excludes.  The per-source (index, d2) of the last pass must still equal a brute-force search bit for bit."""
+    S = pkg.synth
+    if case == "bumpy":
+        src, tgt = S.make_pair(41, 30000, R=S.rot_axis_angle([0.2, 1.0, 0.1], np.deg2rad(9.0)), t=(0.01, -0.02, 0.0), shape="bumpy")
+    elif case == "ties":
+        src, tgt = _tie_lattice_pair()
+    elif case == "duplicates":
+        src, tgt = S.make_pair(42, 12000, R=S.rot_axis_angle([0, 0, 1], np.deg2rad(4.0)), shape="bumpy")
+        tgt = np.concatenate([tgt, tgt[::2], tgt[::5]]).astype(np.float32)      # repeated points: equal distances, lower index wins
+    else:
+        src, tgt = S.config_c2(100000)
+    tree = O.KdTree(tgt) if len(src) * len(tgt) > 4e8 else None
+    for iters in (1, 2, 7):
+        for mode in (pkg.NN_GRID, pkg.NN_BRUTE):
+            r = ctx.icp(src, tgt, ctx.icp_params(max_iterations=iters, fixed_iterations=1, nn_mode=mode), fitness_corr=True)
+            moved = O.transform_points_f32(r["T"], src)      # the final Matrix4f applied in float, as the kernels do
+            oi, od = tree.nn(moved, nthreads=8) if tree else O.nn_brute(moved, tgt)
+            assert np.array_equal(r["fitness_idx"], oi), (case, iters, mode, int((r["fitness_idx"] != oi).sum()))
+            assert np.array_equal(r["fitness_d2"].view(np.uint32), od.view(np.uint32)), (case, iters, mode)
+
+
 def test_grid_icp_with_unresolved_sources(ctx, O, pkg):
     """A source far from the target: the cell search gives up on most points in the first iterations, the
     brute-force list pass resolves them, later iterations stay inside the grid."""
