@@ -47,7 +47,7 @@ struct kss_ctx {
     // grow-only device workspace
     DevBuf tgt4, src0, cur[2], keys, partials, sums, nn_work, red_work, pair_red, state, cs, scratch_a,
         scratch_b, scratch_c, stage_src, stage_tgt, stage_idx, stage_d2, stage_out, g_counts, g_start, g_cursor,
-        g_bsums, g_sorted, g_list, g_count, g_bbox, g_partials, g_start2, g_pairs, g_stamps, g_pos, pack_seg;
+        g_bsums, g_sorted, g_list, g_count, g_bbox, g_partials, g_start2, g_pairs, g_stamps, g_pos, pack_seg, reg_s, reg_t, reg_p, reg_all, reg_f, reg_g;
     HostPool pool;   // per-pair host work of batched iterations
     std::vector<unsigned long long> last_stamps;
     double evals_sum = 0.0, evals_launches = 0.0;   // diagnostic runs: distance evaluations of the fused grid launches
@@ -205,7 +205,7 @@ int kss_ctx_destroy(kss_ctx* c) {
     DevBuf* bufs[] = {&c->tgt4, &c->src0, &c->cur[0], &c->cur[1], &c->keys, &c->partials, &c->sums, &c->nn_work,
                       &c->red_work, &c->pair_red, &c->state, &c->cs, &c->scratch_a, &c->scratch_b, &c->scratch_c,
                       &c->stage_src, &c->stage_tgt, &c->stage_idx, &c->stage_d2, &c->stage_out, &c->g_counts, &c->g_start,
-                      &c->g_cursor, &c->g_bsums, &c->g_sorted, &c->g_list, &c->g_count, &c->g_bbox, &c->g_partials, &c->g_start2, &c->g_pairs, &c->g_stamps, &c->g_pos, &c->pack_seg};
+                      &c->g_cursor, &c->g_bsums, &c->g_sorted, &c->g_list, &c->g_count, &c->g_bbox, &c->g_partials, &c->g_start2, &c->g_pairs, &c->g_stamps, &c->g_pos, &c->pack_seg, &c->reg_s, &c->reg_t, &c->reg_p, &c->reg_all, &c->reg_f, &c->reg_g};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (c->h_sums) hipHostFree(c->h_sums);
@@ -311,6 +311,8 @@ int kss_profile_get(kss_ctx* c, int k, double* total_ms, int64_t* launches) {
 // ICP plan: how pairs, source blocks and target splits map onto workgroups
 // ---------------------------------------------------------------------------------------------
 namespace {
+
+int ensure_pub(kss_ctx* c);   // host-mapped result slots (defined with wait_seq)
 
 struct PairGeom {
     int64_t ns, nt;
@@ -465,6 +467,7 @@ int stage_plan(kss_ctx* c, const IcpPlan& pl) {
     KCHK(ensure(c, c->state, (size_t)pl.npairs * sizeof(PairState)));
     KCHK(ensure_pinned(c, c->h_sums, c->h_sums_cap, (size_t)pl.npairs * NSUMS * sizeof(double)));
     KCHK(ensure_pinned(c, c->h_state, c->h_state_cap, (size_t)pl.npairs * sizeof(PairState)));
+    KCHK(ensure_pub(c));
     c->tables_staged = false;
     if (!pl.grid) KCHK(stage_tables(c, pl));   // the fused cell-list path needs them only if a query falls back
     return KSS_OK;
@@ -553,15 +556,7 @@ int grid_setup(kss_ctx* c, IcpPlan& pl) {
     KCHK(ensure(c, c->g_list, (size_t)ns * sizeof(int32_t)));
     KCHK(ensure(c, c->g_pos, (size_t)ns * sizeof(int32_t)));   // previous winner of every source: -1 = none yet
     HIPCHK(c, hipMemsetAsync(c->g_pos.p, 0xff, (size_t)ns * sizeof(int32_t), c->stream));
-    if (!c->h_seq) {
-        void* p = nullptr;
-        if (hipHostMalloc(&p, NSUMS * 16, hipHostMallocMapped) != hipSuccess) return set_err(c, KSS_ERR_NOMEM, "hipHostMalloc(seq)");
-        c->h_seq = (unsigned long long*)p;
-        std::memset(p, 0, NSUMS * 16);
-        void* d = nullptr;
-        HIPCHK(c, hipHostGetDevicePointer(&d, p, 0));
-        c->h_seq_dev = (unsigned long long*)d;
-    }
+    KCHK(ensure_pub(c));
     KCHK(ensure(c, c->g_count, 64));   // [0] unresolved-list length, [1] last-workgroup ticket
     KCHK(ensure(c, c->g_partials, (size_t)grid_nn_blocks(ns) * NSUMS * sizeof(double)));
     HIPCHK(c, hipMemsetAsync(c->g_count.p, 0, 64, c->stream));
@@ -651,17 +646,34 @@ int grid_setup_batch(kss_ctx* c, IcpPlan& pl) {
     return KSS_OK;
 }
 
-// Wait for the fused grid kernel.  Its last workgroup stores every sum TOGETHER with the launch's sequence number as
-// one aligned 16-byte write into host-mapped memory ({bits(sum), seq} pairs): a slot whose sequence number matches
-// holds this launch's value, so there is no separate completion flag and no write-acknowledge round trip between
-// "sums stored" and "flag stored" on the device.  The host spins on the pairs (a stream sync costs a 5-10 us wake-up
-// per ICP iteration); after ~2 ms without progress it falls back to the stream sync, which also surfaces a faulted
-// kernel instead of spinning forever.  The sums are copied to h_sums, where the rest of the loop expects them.
-int wait_seq(kss_ctx* c) {
+// Host-mapped result slots: PUB_PAIRS x NSUMS x {bits(sum), sequence number}.  The kernel that ends an ICP iteration
+// (fused grid_nn_kernel, or finalize_sums_kernel for small batches) stores every sum TOGETHER with the launch's
+// sequence number as one aligned 16-byte write: a slot whose sequence number matches holds this launch's value, so
+// there is no separate completion flag and no write-acknowledge round trip between "sums stored" and "flag stored"
+// on the device.
+constexpr int PUB_PAIRS = 32;   // batches up to this many pairs are awaited by spinning (more slots than that cost more to poll than a sync)
+int ensure_pub(kss_ctx* c) {
+    if (c->h_seq) return KSS_OK;
+    void* p = nullptr;
+    const size_t bytes = (size_t)PUB_PAIRS * NSUMS * 16;
+    if (hipHostMalloc(&p, bytes, hipHostMallocMapped) != hipSuccess) return set_err(c, KSS_ERR_NOMEM, "hipHostMalloc(result slots)");
+    c->h_seq = (unsigned long long*)p;
+    std::memset(p, 0, bytes);
+    void* d = nullptr;
+    HIPCHK(c, hipHostGetDevicePointer(&d, p, 0));
+    c->h_seq_dev = (unsigned long long*)d;
+    return KSS_OK;
+}
+
+// Wait for the first `npairs * NSUMS` slots to carry sequence number c->seq and copy the sums to h_sums, where the rest
+// of the loop expects them.  The host spins (a stream sync costs a 5-10 us wake-up per ICP iteration); after ~2 ms
+// without progress it falls back to the stream sync, which also surfaces a faulted kernel instead of spinning forever.
+int wait_seq(kss_ctx* c, int npairs = 1) {
     const unsigned long long want = c->seq;
     double* out = (double*)c->h_sums;
+    const int nslots = npairs * NSUMS;
     auto collect = [&]() -> bool {
-        for (int k = NSUMS - 1; k >= 0; --k) {   // slot 19 is written by the highest lane: usually the last to land
+        for (int k = nslots - 1; k >= 0; --k) {   // the highest slot is usually the last to land
             if (__atomic_load_n(&c->h_seq[2 * k + 1], __ATOMIC_ACQUIRE) != want) return false;
             const unsigned long long bits = __atomic_load_n(&c->h_seq[2 * k], __ATOMIC_RELAXED);
             std::memcpy(&out[k], &bits, sizeof(double));
@@ -673,7 +685,7 @@ int wait_seq(kss_ctx* c) {
         __builtin_ia32_pause();
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (!collect()) return set_err(c, KSS_ERR_HIP, "grid kernel finished without publishing its result");
+    if (!collect()) return set_err(c, KSS_ERR_HIP, "kernel finished without publishing its result");
     return KSS_OK;
 }
 
@@ -749,11 +761,15 @@ int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, float4*
                             (const GridPairDev*)c->g_pairs.p, d_in, d_out, (const int32_t*)c->g_start.p, (const float4*)c->g_sorted.p,
                             getenv("KSS_GRID_NOPREV") ? nullptr : (int32_t*)c->g_pos.p, max_d2, (double*)c->partials.p, d_idx_out, d_d2_out);
         }
-        ProfScope ps(c, KSS_K_CORR_REDUCE);
-        launch_finalize_sums(c->stream, (const PairRed*)c->pair_red.p, pl.npairs, (const double*)c->partials.p,
-                             (double*)c->h_sums_dev, nullptr, nullptr);
+        const bool spin = pl.npairs <= PUB_PAIRS;
+        {
+            ProfScope ps(c, KSS_K_CORR_REDUCE);
+            launch_finalize_sums(c->stream, (const PairRed*)c->pair_red.p, pl.npairs, (const double*)c->partials.p,
+                                 (double*)c->h_sums_dev, nullptr, nullptr, spin ? c->h_seq_dev : nullptr, spin ? ++c->seq : 0);
+        }
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (spin) KCHK(wait_seq(c, pl.npairs));
+        else HIPCHK(c, hipStreamSynchronize(c->stream));
         return KSS_OK;
     }
     {
@@ -761,9 +777,18 @@ int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, float4*
         launch_nn_sweep(c->stream, pl.S, fma, (const NNWork*)c->nn_work.p, (int)pl.nn.size(), (const PairState*)c->state.p,
                         d_in, d_out, (const float4*)c->tgt4.p, (unsigned long long*)c->keys.p);
     }
-    reduce(nullptr, nullptr);
+    const bool spin = pl.npairs <= PUB_PAIRS;
+    {
+        ProfScope ps(c, KSS_K_CORR_REDUCE);
+        launch_corr_reduce(c->stream, (const RedWork*)c->red_work.p, (int)pl.red.size(), (const PairState*)c->state.p,
+                           d_out, (const float4*)c->tgt4.p, (const unsigned long long*)c->keys.p, max_d2,
+                           (double*)c->partials.p, d_idx_out, d_d2_out, 0);
+        launch_finalize_sums(c->stream, (const PairRed*)c->pair_red.p, pl.npairs, (const double*)c->partials.p,
+                             (double*)c->h_sums_dev, nullptr, nullptr, spin ? c->h_seq_dev : nullptr, spin ? ++c->seq : 0);
+    }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (spin) KCHK(wait_seq(c, pl.npairs));
+    else HIPCHK(c, hipStreamSynchronize(c->stream));
     return KSS_OK;
 }
 
@@ -1365,10 +1390,10 @@ int kss_register(kss_ctx* c, const double* src_sub, int64_t nss, const double* t
     if (nss <= 0 || nts <= 0 || nsf < 0 || (nsf > 0 && !src_full)) return set_err(c, KSS_ERR_ARG, "register: bad sizes");
     HIPCHK(c, hipSetDevice(c->device));
     std::memset(res, 0, sizeof *res);
-    // resident copies of S', T' (f64)
-    DevBuf dS, dT, dP, dAll;
-    auto cleanup = [&]() { if (dS.p) hipFree(dS.p); if (dT.p) hipFree(dT.p); if (dP.p) hipFree(dP.p); if (dAll.p) hipFree(dAll.p); };
-#define RCHK(expr) do { int rc_ = (expr); if (rc_ != KSS_OK) { cleanup(); return rc_; } } while (0)
+    // resident copies of S', T' (f64) in the context's grow-only workspace (no hipMalloc / hipFree per registration:
+    // each costs tens of microseconds and hipFree synchronises the device)
+    DevBuf &dS = c->reg_s, &dT = c->reg_t, &dP = c->reg_p, &dAll = c->reg_all;
+#define RCHK(expr) do { int rc_ = (expr); if (rc_ != KSS_OK) return rc_; } while (0)
     RCHK(upload(c, dS, src_sub, (size_t)nss * 3 * sizeof(double)));
     RCHK(upload(c, dT, tgt_sub, (size_t)nts * 3 * sizeof(double)));
     RCHK(ensure(c, dP, (size_t)nss * 3 * sizeof(double)));
@@ -1449,7 +1474,7 @@ int kss_register(kss_ctx* c, const double* src_sub, int64_t nss, const double* t
         res->t[i] = res->R[3 * i] * v[0] + res->R[3 * i + 1] * v[1] + res->R[3 * i + 2] * v[2] + (double)rfinal.T[4 * i + 3];
     // (a13) pointAlign = M * Rotation_Angle(pointSource) (:120/:124, :224-230)
     if (point_align && nsf > 0) {
-        DevBuf dF, dG;
+        DevBuf &dF = c->reg_f, &dG = c->reg_g;
         int rc = upload(c, dF, src_full, (size_t)nsf * 3 * sizeof(double));
         if (rc == KSS_OK) rc = ensure(c, dG, (size_t)nsf * 3 * sizeof(double));
         for (int k = 0; k < 3; ++k) pose.angle[k] = chosen[k];
@@ -1457,12 +1482,9 @@ int kss_register(kss_ctx* c, const double* src_sub, int64_t nss, const double* t
         if (rc == KSS_OK) rc = kss_transform_apply_dev(c, rfinal.T, (const double*)dG.p, nsf, (double*)dF.p);
         if (rc == KSS_OK && hipMemcpyAsync(point_align, dF.p, (size_t)nsf * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = KSS_ERR_HIP;
         if (rc == KSS_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = KSS_ERR_HIP;
-        if (dF.p) hipFree(dF.p);
-        if (dG.p) hipFree(dG.p);
-        if (rc != KSS_OK) { cleanup(); return rc; }
+        if (rc != KSS_OK) return rc;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    cleanup();
 #undef RCHK
     return KSS_OK;
 }

@@ -127,7 +127,9 @@ void launch_corr_reduce_idx(hipStream_t st, const float* d_src3, const float* d_
                             int64_t n, double max_d2, double* d_partials, int n_blocks);
 void launch_finalize_sums(hipStream_t st, const PairRed* d_pairs, int n_pairs, const double* d_partials,
                           double* d_out /* n_pairs * NSUMS, device or host-mapped */,
-                          const int32_t* d_unresolved /* may be null */, int32_t* d_unresolved_reset /* may be null */);
+                          const int32_t* d_unresolved /* may be null */, int32_t* d_unresolved_reset /* may be null */,
+                          unsigned long long* d_pub = nullptr /* host-mapped {bits, seq} pairs, may be null */,
+                          unsigned long long seq = 0);
 
 void launch_preshape_sum(hipStream_t st, const void* d_xyz, int dtype, int64_t n, double* d_partials, int n_blocks);
 void launch_preshape_centroid(hipStream_t st, const double* d_partials, int n_blocks, int64_t n, double* d_centroid);

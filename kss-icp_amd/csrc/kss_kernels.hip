@@ -15,6 +15,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "kss_internal.hpp"
 #include "kss_device.hpp"
 
@@ -318,11 +320,14 @@ void launch_corr_reduce_idx(hipStream_t st, const float* d_src3, const float* d_
                        max_d2, d_partials);
 }
 
-// final stage: sums[pair][c] = sum over that pair's partial rows, in row order (deterministic)
+// final stage: sums[pair][c] = sum over that pair's partial rows, in row order (deterministic).  With `pub` the sums
+// are ALSO published as {bits(sum), seq} 16-byte pairs into host-mapped memory (slot pair * NSUMS + c): the host spins
+// on the sequence numbers instead of paying a stream-sync wake-up per ICP iteration (see grid_nn_kernel).
 __global__ __launch_bounds__(256) void finalize_sums_kernel(const PairRed* __restrict__ pairs,
                                                             const double* __restrict__ partials,
                                                             double* __restrict__ out, const int32_t* __restrict__ unresolved,
-                                                            int32_t* __restrict__ unresolved_reset) {
+                                                            int32_t* __restrict__ unresolved_reset,
+                                                            unsigned long long* __restrict__ pub, unsigned long long seq) {
     __shared__ double shg[ROWSUM_GROUPS][NSUMS];
     const PairRed pr = pairs[blockIdx.x];
     double v = rows_column_sum(partials + (int64_t)pr.first * NSUMS, pr.count, shg);
@@ -334,13 +339,22 @@ __global__ __launch_bounds__(256) void finalize_sums_kernel(const PairRed* __res
         if (unresolved_reset) *unresolved_reset = 0;
     }
     out[(int64_t)blockIdx.x * NSUMS + c] = v;
+    if (pub) {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const unsigned long long vb = (unsigned long long)__double_as_longlong(v);
+        u32x4 w;
+        w.x = (unsigned)vb; w.y = (unsigned)(vb >> 32); w.z = (unsigned)seq; w.w = (unsigned)(seq >> 32);
+        unsigned long long* dst = pub + 2 * ((int64_t)blockIdx.x * NSUMS + c);
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(w) : "memory");
+    }
 }
 
 void launch_finalize_sums(hipStream_t st, const PairRed* d_pairs, int n_pairs, const double* d_partials, double* d_out,
-                          const int32_t* d_unresolved, int32_t* d_unresolved_reset) {
+                          const int32_t* d_unresolved, int32_t* d_unresolved_reset, unsigned long long* d_pub,
+                          unsigned long long seq) {
     if (n_pairs <= 0) return;
     hipLaunchKernelGGL(finalize_sums_kernel, dim3(n_pairs), dim3(256), 0, st, d_pairs, d_partials, d_out, d_unresolved,
-                       d_unresolved_reset);
+                       d_unresolved_reset, d_pub, seq);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -644,22 +658,31 @@ void launch_fps(hipStream_t st, const double* d_xyz, int n, int m, double* d_min
 // source point in f64 by the candidate's Euler angles, narrows to f32 (:440-442), sweeps the
 // whole target through LDS keeping only the minimum d2, and contributes sqrt((double)d2) (:444).
 // ---------------------------------------------------------------------------------------------
+template <int S>
 __global__ __launch_bounds__(256) void rot_search_kernel(const double* __restrict__ src, int ns,
                                                          const float4* __restrict__ tgt, int nt_pad,
                                                          const double* __restrict__ cs, int g,
                                                          double* __restrict__ partials) {
+    // One lane = one source point under S consecutive candidates: the target tile read from LDS (one broadcast
+    // ds_read_b128 per target) is shared by S distance evaluations, as the S sources per lane of nn_sweep_kernel.
     __shared__ float4 tile[2][NN_TILE];
-    __shared__ double sh[4][1];
-    const int cand = blockIdx.y;
-    const int ia = cand / (g * g), ib = (cand / g) % g, ic = cand % g;
+    __shared__ double sh[4][S];
+    const int g3 = g * g * g;
     const int tid = threadIdx.x;
     const int i = blockIdx.x * 256 + tid;
     const bool valid = i < ns;
-    double x = 0.0, y = 0.0, z = 0.0;
-    if (valid) { x = src[3 * (int64_t)i]; y = src[3 * (int64_t)i + 1]; z = src[3 * (int64_t)i + 2]; }
-    euler_rotate(x, y, z, cs[2 * ia], cs[2 * ia + 1], cs[2 * ib], cs[2 * ib + 1], cs[2 * ic], cs[2 * ic + 1]);
-    const float sx = (float)x, sy = (float)y, sz = (float)z;
-    float best = __builtin_inff();
+    double x0 = 0.0, y0 = 0.0, z0 = 0.0;
+    if (valid) { x0 = src[3 * (int64_t)i]; y0 = src[3 * (int64_t)i + 1]; z0 = src[3 * (int64_t)i + 2]; }
+    float sx[S], sy[S], sz[S], best[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        const int cand = min((int)blockIdx.y * S + j, g3 - 1);   // a surplus slot repeats the last candidate (not stored)
+        const int ia = cand / (g * g), ib = (cand / g) % g, ic = cand % g;
+        double x = x0, y = y0, z = z0;
+        euler_rotate(x, y, z, cs[2 * ia], cs[2 * ia + 1], cs[2 * ib], cs[2 * ib + 1], cs[2 * ic], cs[2 * ic + 1]);
+        sx[j] = (float)x; sy[j] = (float)y; sz[j] = (float)z;   // narrowed to float before the NN query (:440-442)
+        best[j] = __builtin_inff();
+    }
     const int ntiles = nt_pad / NN_TILE;
     float4 pre = tgt[tid];
     int buf = 0;
@@ -668,22 +691,35 @@ __global__ __launch_bounds__(256) void rot_search_kernel(const double* __restric
         __syncthreads();
         if (t + 1 < ntiles) pre = tgt[(t + 1) * NN_TILE + tid];
         const float4* __restrict__ tl = tile[buf];
-#pragma unroll 16
+#pragma unroll 8
         for (int u = 0; u < NN_TILE; ++u) {
             const float4 q = tl[u];
-            best = fminf(best, dist2<false>(sx, sy, sz, q.x, q.y, q.z));
+#pragma unroll
+            for (int j = 0; j < S; ++j) best[j] = fminf(best[j], dist2<false>(sx[j], sy[j], sz[j], q.x, q.y, q.z));
         }
         buf ^= 1;
     }
-    double acc[1] = {valid ? sqrt((double)best) : 0.0};
-    const double r = block_sum<1>(acc, sh);
-    if (tid == 0) partials[(int64_t)cand * gridDim.x + blockIdx.x] = r;
+    double acc[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) acc[j] = valid ? sqrt((double)best[j]) : 0.0;   // mean of sqrt(float d2) in double (:444-448)
+    const double r = block_sum<S>(acc, sh);
+    if (tid < S) {
+        const int cand = (int)blockIdx.y * S + tid;
+        if (cand < g3) partials[(int64_t)cand * gridDim.x + blockIdx.x] = r;
+    }
 }
 
 void launch_rot_search(hipStream_t st, const double* d_src, int64_t ns, const float4* d_tgt4, int64_t nt_pad,
                        const double* d_cs, int g, double* d_partials, int n_src_blocks) {
-    const dim3 grid(n_src_blocks, g * g * g);
-    hipLaunchKernelGGL(rot_search_kernel, grid, dim3(256), 0, st, d_src, (int)ns, d_tgt4, (int)nt_pad, d_cs, g, d_partials);
+    const int g3 = g * g * g;
+    // candidates per lane: 4 when that still leaves >= 4 workgroups per CU, else 2 (the loop is VALU bound and wants a
+    // few waves per SIMD to cover the LDS latency); KSS_ROT_S overrides for measurements
+    int S = (int64_t)n_src_blocks * ((g3 + 3) / 4) >= 1024 ? 4 : 2;
+    if (const char* e = getenv("KSS_ROT_S")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) S = v; }
+    const dim3 grid(n_src_blocks, (g3 + S - 1) / S);
+    if (S == 4) hipLaunchKernelGGL(rot_search_kernel<4>, grid, dim3(256), 0, st, d_src, (int)ns, d_tgt4, (int)nt_pad, d_cs, g, d_partials);
+    else if (S == 2) hipLaunchKernelGGL(rot_search_kernel<2>, grid, dim3(256), 0, st, d_src, (int)ns, d_tgt4, (int)nt_pad, d_cs, g, d_partials);
+    else hipLaunchKernelGGL(rot_search_kernel<1>, grid, dim3(256), 0, st, d_src, (int)ns, d_tgt4, (int)nt_pad, d_cs, g, d_partials);
 }
 
 }  // namespace kss

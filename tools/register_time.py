@@ -20,3 +20,16 @@ rs = ctx.profile_get(pkg.K_ROT_SEARCH); ctx.profile_enable(False)
 k = O.kssicp_register(S[O.aivs(S, m)], T[O.aivs(T, m)], S, 8.0, 1000); t2 = time.perf_counter()
 print("Bunny %d x %d -> %d samples: GPU %.2f ms (rotation search kernel %.3f ms), oracle 1 core %.0f ms, max|dR| %.1e, candidates %d" %
       (len(S), len(T), m, (t1 - t0) * 1e3, rs[0] / max(1, rs[1]), (t2 - t1) * 1e3, np.abs(r["R"] - k["R"]).max(), r["n_angle_list"]))
+# stage breakdown (wall clock through the C-ABI, second call of each)
+def tm(f, reps=5):
+    f(); t = time.perf_counter()
+    for _ in range(reps): out = f()
+    return (time.perf_counter() - t) / reps * 1e3, out
+ta, (s, _) = tm(lambda: ctx.downsample_aivs(S, m))
+tb, (t, _) = tm(lambda: ctx.downsample_aivs(T, m))
+tr, r = tm(lambda: ctx.register(s, t, S, 8.0, 1000))
+tn, _ = tm(lambda: ctx.register(s, t, None, 8.0, 1000)) if False else (0.0, None)
+print("AIVS source %.2f ms, AIVS target %.2f ms, kss_register %.2f ms (judge ICP %d iterations, E_d_init %.2e, used list %d)" %
+      (ta, tb, tr, r["icp_iterations"], r["E_d_init"], r["used_angle_list"]))
+os.environ["KSS_TIMING"] = "1"
+ctx.register(s, t, S, 8.0, 1000)
