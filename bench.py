@@ -48,6 +48,10 @@ def parse_args():
     ap.add_argument("--mode", default="auto", choices=["auto", "brute", "grid"], help="NN engine of the timed path")
     ap.add_argument("--brute-steps", type=int, default=3, help="steps of the secondary brute-force measurement (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--split-source", action="store_true",
+                    help="N > 1: ONE registration, its source rows split over the ranks (target replicated), one RCCL "
+                         "all-reduce of the 20 sums per iteration (SURVEY 8e alternative; strong scaling).  Default: one "
+                         "independent pair per rank (weak scaling, no data-path collective)")
     ap.add_argument("--prof-stride", type=int, default=8,
                     help="HIP-event timing of every n-th kernel launch inside the timed region (1 = every launch)")
     return ap.parse_args()
@@ -127,22 +131,42 @@ def main():
 
     pkg = graft.load_package()
     S = pkg.synth
-    # one independent pair per rank (pair_id = rank): the path shards over pairs with no data exchange
-    src, tgt = S.make_pair(rank, a.n, R=S.rot_axis_angle([0, 0, 1], np.deg2rad(10.0)))
+    split = a.split_source and (world > 1 or force_dist)
+    if split:
+        # ONE pair for the whole job: every rank holds the target and its contiguous block of source rows
+        src, tgt = S.make_pair(0, a.n, R=S.rot_axis_angle([0, 0, 1], np.deg2rad(10.0)))
+        lo, hi = pkg.shard.shard_range(a.n, world, rank)
+        src = np.ascontiguousarray(src[lo:hi])
+    else:
+        # one independent pair per rank (pair_id = rank): the path shards over pairs with no data exchange
+        src, tgt = S.make_pair(rank, a.n, R=S.rot_axis_angle([0, 0, 1], np.deg2rad(10.0)))
+    n_src = len(src)
     d_src = torch.from_numpy(src).to(dev)
     d_tgt = torch.from_numpy(tgt).to(dev)
     torch.cuda.synchronize()
 
     ctx = pkg.Context(local_rank)       # raises without libkssicp.so / GPU
     modes = {"auto": pkg.NN_AUTO, "brute": pkg.NN_BRUTE, "grid": pkg.NN_GRID}
+    rccl_lib = rccl_comm = keep = None
+    if split:
+        rccl_lib, rccl_comm = pkg.shard.rccl_comm(rank, world, device=dev)
+
+    keepalive = []
 
     def make_step(mode):
-        params = ctx.icp_params(max_iterations=a.iters, fixed_iterations=1, compute_fitness=1, nn_fma=a.fma,
-                                nn_sources_per_thread=a.spt, nn_target_splits=a.splits, nn_mode=modes[mode])
+        kw = dict(max_iterations=a.iters, fixed_iterations=1, compute_fitness=1, nn_fma=a.fma,
+                  nn_sources_per_thread=a.spt, nn_target_splits=a.splits, nn_mode=modes[mode])
+        if split:   # the exchange step: ncclAllReduce of the 20 sums after every pass, inside the library
+            params, link = pkg.shard.rccl_allreduce_params(ctx, pkg.binding, pkg.load_library(), rccl_comm, **kw)
+            keepalive.append(link)
+        else:
+            params = ctx.icp_params(**kw)
         RecArr = pkg.IcpResult * 1
 
         def step():
-            res = ctx.icp_dev(d_src.data_ptr(), a.n, d_tgt.data_ptr(), a.n, params)
+            res = ctx.icp_dev(d_src.data_ptr(), n_src, d_tgt.data_ptr(), a.n, params)
+            if split:
+                return res   # every rank already holds the same record
             if world > 1 or force_dist:   # final gather of the (R,t) records over RCCL/xGMI: one 96-B record per pair
                 local = pkg.shard.records_to_array(RecArr(res), rank)
                 pkg.shard.gather_records(local, world, world, rank, device=dev)
@@ -166,7 +190,7 @@ def main():
     used_grid = prof["K_GRID_NN"][1] > 0
     ev_over_s = ctx.profile_event_overhead() * 1e-3 if rank == 0 else 0.0   # event pair around an empty launch
     evals_per_launch = None
-    if used_grid and rank == 0:
+    if used_grid and rank == 0 and not split:   # (split: a step is collective, every rank would have to join)
         # untimed diagnostic step: the kernel counts its distance evaluations (mean over the step's launches)
         import ctypes as C
         lib = pkg.load_library()
@@ -195,7 +219,7 @@ def main():
         brute = (bdt, bms, bn, blast)
 
     if rank == 0:
-        value = a.steps * a.iters * world / dt
+        value = a.steps * a.iters * (1 if split else world) / dt   # split: the ranks share ONE registration
         passes = a.iters + 1
 
         def valu_roofline(raw_s, launches):
@@ -213,14 +237,16 @@ def main():
         out = {
             "metric": "icp_iterations_per_sec", "value": value, "unit": "iterations/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if split else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C2: one %dx%d uniform-sphere pair per GPU, %d fixed ICP iterations + fitness pass per step "
                                    "(exact NN + cov reduce + host 3x3 SVD), R_z(10deg), jitter 1e-3" % (a.n, a.n, a.iters),
                        "n_src": a.n, "n_tgt": a.n, "icp_iters_per_step": a.iters, "pairs_per_gpu": 1,
+                       "parallelism": ("source rows of one pair split over %d ranks, ncclAllReduce of 20 f64 per iteration" % world) if split
+                                      else "one independent pair per rank, no data-path collective",
                        "nn_engine": "cell list + brute-force fallback" if used_grid else "brute-force sweep",
                        "nn_arithmetic": "fma" if a.fma else "reference (no fma)"},
-            "correspondences_per_sec": float(a.n) * passes * a.steps * world / dt,
-            "point_pairs_per_sec_brute_force_equivalent": float(a.n) * a.n * passes * a.steps * world / dt,
+            "correspondences_per_sec": float(a.n) * passes * a.steps * (1 if split else world) / dt,
+            "point_pairs_per_sec_brute_force_equivalent": float(a.n) * a.n * passes * a.steps * (1 if split else world) / dt,
             "result": {"iterations": int(last.iterations), "fitness": float(last.fitness)},
         }
         if used_grid:
@@ -234,7 +260,7 @@ def main():
             # algorithmic bytes of one launch = what the kernel requests: per source 16 B read + 16 B
             # transformed write + 8 B key + 2 x 4 B previous-winner position, 36 cell-range bounds of 4 B, and 16 B per
             # distance evaluation (counted by the kernel itself in an untimed diagnostic step)
-            alg = a.n * (16.0 + 16.0 + 8.0 + 8.0 + 36 * 4.0) + ev * 16.0
+            alg = n_src * (16.0 + 16.0 + 8.0 + 8.0 + 36 * 4.0) + ev * 16.0
             out["roofline"] = {"kernel": "grid_nn_kernel", "bound": "hbm",
                                "bound_note": "cell-list search + correspondence sums + final reduction, one launch per ICP iteration. "
                                              "One 512-lane workgroup per CU runs once: the launch is bound by dependent L2 round "
@@ -267,6 +293,8 @@ def main():
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_1core"] = value / cb["value"]
         print(json.dumps(out), flush=True)
+    if rccl_comm is not None:
+        rccl_lib.ncclCommDestroy(rccl_comm)
     ctx.close()
     if world > 1 or force_dist:
         dist.barrier()

@@ -151,6 +151,9 @@ int kss_rotation_candidates(const double *err, int g, double step, double best_a
 
 /* ---- (a9,a11,a12) ICP driver: pcl::IterativeClosestPoint::align as configured at
  *      KSS_ICP.hpp:155-162 (x5), PCL 1.8.1 semantics ---- */
+/* In-place sum over the ranks of a job of n doubles in HOST memory; returns 0 on success.  See `allreduce` below. */
+typedef int (*kss_allreduce_fn)(void *user, double *values, int n);
+
 typedef struct {
     int    max_iterations;             /* setMaximumIterations            KSS_ICP.hpp:159 */
     double max_corr_dist;              /* setMaxCorrespondenceDistance(1) :156 */
@@ -174,6 +177,13 @@ typedef struct {
      * when compute_fitness is set) */
     int32_t *fitness_idx;
     float   *fitness_d2;
+    /* optional (the single-pair exchange step): ONE registration whose SOURCE ROWS are split over several
+     * ranks, target replicated.  Every rank calls kss_icp[_dev] with its own rows and the same target and parameters;
+     * after each NN pass the KSS_NSUMS correspondence sums are summed over the ranks through this callback, so every
+     * rank solves the same 3x3 system and applies the same transform.  The result (T, iterations, fitness over ALL
+     * source rows) is identical on every rank.  NULL = single-rank registration.  Single pair only. */
+    kss_allreduce_fn allreduce;
+    void *allreduce_user;
 } kss_icp_params;
 
 /* NN search structure.  BRUTE: the LDS-tiled source x target sweep (north star).  GRID: exact search
@@ -256,6 +266,12 @@ typedef struct {
 int kss_register(kss_ctx *ctx, const double *src_sub, int64_t nss, const double *tgt_sub, int64_t nts,
                  const double *src_full, int64_t nsf, double accurate, int iter,
                  double *point_align /* nsf*3, may be NULL */, kss_register_result *res);
+
+/* ---- (8e) RCCL-backed kss_allreduce_fn: user = &kss_rccl_link{ctx, ncclComm_t}; ncclAllReduce(sum, f64) on the
+ * context's stream between a host->device and a device->host copy of the n doubles (160 B per ICP iteration:
+ * latency bound, one collective per iteration) ---- */
+typedef struct { kss_ctx *ctx; void *rccl_comm; } kss_rccl_link;
+int kss_rccl_allreduce_sum(void *user /* kss_rccl_link* */, double *values, int n);
 
 /* ---- (8e) gather of per-pair result records over RCCL (ncclComm_t passed as void*) ----
  * all must hold world_size * n_local records; every rank receives every record. */

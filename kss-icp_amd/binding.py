@@ -24,7 +24,7 @@ SYMBOLS = [
     "kss_nn", "kss_nn_dev", "kss_cov", "kss_cov_dev", "kss_rigid_from_sums", "kss_rotation_search",
     "kss_rotation_search_dev", "kss_grid_angles", "kss_rotation_candidates", "kss_icp_default_params", "kss_icp",
     "kss_icp_dev", "kss_icp_batch", "kss_icp_batch_dev", "kss_transform_apply", "kss_transform_apply_dev",
-    "kss_pcr_qm", "kss_register", "kss_gather_results", "kss_transform_apply_f32", "kss_downsample_fps", "kss_downsample_aivs", "kss_knn", "kss_knn_dev", "kss_normals",
+    "kss_pcr_qm", "kss_register", "kss_gather_results", "kss_rccl_allreduce_sum", "kss_transform_apply_f32", "kss_downsample_fps", "kss_downsample_aivs", "kss_knn", "kss_knn_dev", "kss_normals",
 ]
 
 
@@ -37,6 +37,14 @@ class KssError(RuntimeError):
         super().__init__(msg)
 
 
+# kss_allreduce_fn: in-place sum over ranks of n doubles in host memory (kss_icp_params.allreduce)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+
+
+class RcclLink(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("rccl_comm", C.c_void_p)]
+
+
 class IcpParams(C.Structure):
     _fields_ = [("max_iterations", C.c_int), ("max_corr_dist", C.c_double),
                 ("transformation_epsilon", C.c_double), ("euclidean_fitness_epsilon", C.c_double),
@@ -45,7 +53,8 @@ class IcpParams(C.Structure):
                 ("nn_sources_per_thread", C.c_int), ("nn_target_splits", C.c_int), ("nn_mode", C.c_int),
                 ("trace_sums", C.POINTER(C.c_double)), ("trace_Tk", C.POINTER(C.c_float)),
                 ("trace_cap", C.c_int), ("trace_n", C.POINTER(C.c_int)),
-                ("fitness_idx", C.POINTER(C.c_int32)), ("fitness_d2", C.POINTER(C.c_float))]
+                ("fitness_idx", C.POINTER(C.c_int32)), ("fitness_d2", C.POINTER(C.c_float)),
+                ("allreduce", ALLREDUCE_FN), ("allreduce_user", C.c_void_p)]
 
 
 class IcpResult(C.Structure):

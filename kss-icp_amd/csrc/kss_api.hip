@@ -829,6 +829,9 @@ int icp_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P, kss_icp_res
         const float4* d_in = it == 0 ? (const float4*)c->src0.p : (const float4*)c->cur[(it - 1) & 1].p;
         float4* d_out = (float4*)c->cur[it & 1].p;
         KCHK(nn_pass(c, pl, P.nn_fma != 0, d_in, d_out, max_d2, nullptr, nullptr));
+        // source rows split over ranks: the sums of all ranks, identical on every rank from here on
+        if (P.allreduce && P.allreduce(P.allreduce_user, (double*)c->h_sums, NSUMS) != 0)
+            return set_err(c, KSS_ERR_RCCL, "icp: the allreduce callback failed");
         // per-pair solve + convergence test: pairs are independent (a large batch is split over a few host threads;
         // each pair is handled by exactly one thread, so the results do not depend on the split)
         std::atomic<int> finished{0};
@@ -886,7 +889,13 @@ int icp_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P, kss_icp_res
             d_idx = (int32_t*)c->stage_idx.p; d_d2 = (float*)c->stage_d2.p;
         }
         KCHK(nn_pass(c, pl, P.nn_fma != 0, (const float4*)c->src0.p, (float4*)c->cur[0].p, max_d2, d_idx, d_d2));
-        for (int p = 0; p < np; ++p) results[p].fitness = hsum[(size_t)p * NSUMS + 17] / (double)pl.g[p].ns;
+        if (P.allreduce) {   // mean over ALL source rows of the job
+            double v[2] = {hsum[17], (double)pl.g[0].ns};
+            if (P.allreduce(P.allreduce_user, v, 2) != 0) return set_err(c, KSS_ERR_RCCL, "icp: the allreduce callback failed");
+            results[0].fitness = v[0] / v[1];
+        } else {
+            for (int p = 0; p < np; ++p) results[p].fitness = hsum[(size_t)p * NSUMS + 17] / (double)pl.g[p].ns;
+        }
         if (d_idx) {
             const size_t n0 = (size_t)pl.g[0].ns;
             if (P.fitness_idx) HIPCHK(c, hipMemcpyAsync(P.fitness_idx, d_idx, n0 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -900,6 +909,7 @@ int icp_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P, kss_icp_res
 int icp_run_dev(kss_ctx* c, const void* d_src, const int64_t* src_off, const void* d_tgt, const int64_t* tgt_off,
                 int npairs, bool shared_target, int dtype, const kss_icp_params* p, kss_icp_result* results) {
     if (!c || !d_src || !d_tgt || !src_off || !tgt_off || !p || !results || npairs <= 0) return set_err(c, KSS_ERR_ARG, "icp: bad argument");
+    if (p->allreduce && npairs != 1) return set_err(c, KSS_ERR_ARG, "icp: the source-row split (allreduce) is for a single pair");
     HIPCHK(c, hipSetDevice(c->device));
     std::vector<int64_t> ns(npairs), nt(npairs);
     for (int i = 0; i < npairs; ++i) {
@@ -1492,6 +1502,30 @@ int kss_register(kss_ctx* c, const double* src_sub, int64_t nss, const double* t
 // ---- RCCL gather of result records ------------------------------------------------------------------------
 // ncclAllGather is resolved at run time from librccl.so so that libkssicp.so has no link-time RCCL
 // dependency (single-GPU users never load it).
+int kss_rccl_allreduce_sum(void* user, double* values, int n) {
+    kss_rccl_link* L = (kss_rccl_link*)user;
+    if (!L || !L->ctx || !L->rccl_comm || !values || n <= 0) return KSS_ERR_ARG;
+    kss_ctx* c = L->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    static allreduce_fn fn = nullptr;
+    if (!fn) {
+        void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return set_err(c, KSS_ERR_RCCL, "cannot dlopen librccl.so");
+        fn = (allreduce_fn)dlsym(h, "ncclAllReduce");
+        if (!fn) return set_err(c, KSS_ERR_RCCL, "ncclAllReduce not found in librccl.so");
+    }
+    const size_t bytes = (size_t)n * sizeof(double);
+    KCHK(ensure(c, c->sums, std::max<size_t>(bytes, NSUMS * sizeof(double))));
+    HIPCHK(c, hipMemcpyAsync(c->sums.p, values, bytes, hipMemcpyHostToDevice, c->stream));
+    const int rc = fn(c->sums.p, c->sums.p, (size_t)n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, L->rccl_comm, c->stream);
+    if (rc != 0) return set_err(c, KSS_ERR_RCCL, "ncclAllReduce failed");
+    HIPCHK(c, hipMemcpyAsync(values, c->sums.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KSS_OK;
+}
+
 int kss_gather_results(kss_ctx* c, void* rccl_comm, int world_size, const kss_icp_result* local, int n_local,
                        kss_icp_result* all) {
     if (!c || !rccl_comm || !local || !all || n_local <= 0 || world_size <= 0) return set_err(c, KSS_ERR_ARG, "gather: bad argument");

@@ -1,4 +1,4 @@
-"""Multi-GPU sharding of independent registrations.
+"""Multi-GPU sharding of the registration path.
 
 The path shards over (source, target) pairs with no data-path collective: rank r of W owns the
 contiguous block of pairs [lo, hi).  The only exchange is the final all-gather of the fixed 96-byte
@@ -58,3 +58,87 @@ def gather_records(local, npairs, world, rank, device=None):
         lo, hi = shard_range(npairs, world, r)
         out[lo:hi] = allbuf[r, :hi - lo]
     return out
+
+
+# ---- the single-pair exchange step: source rows split over ranks, target replicated ----------------
+def make_allreduce(binding, device=None, group=None):
+    """A kss_allreduce_fn (ctypes callback) that sums n host doubles over the ranks of torch.distributed
+    (backend nccl == RCCL over xGMI on GPUs, gloo in the CPU tests): the ONE collective per ICP iteration of a
+    registration whose source rows are split over ranks.  Keep the returned object alive while it is in use.
+
+    160 bytes per call: latency bound.  With `device` set the tensor lives on the GPU (what RCCL needs)."""
+    import torch
+    import torch.distributed as dist
+
+    def _cb(_user, values, n):
+        try:
+            arr = np.ctypeslib.as_array(values, shape=(int(n),))
+            t = torch.from_numpy(arr.copy())
+            if device is not None:
+                t = t.to(device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            arr[:] = t.cpu().numpy()
+            return 0
+        except Exception:      # never unwind through the C caller
+            return -1
+
+    return binding.ALLREDUCE_FN(_cb)
+
+
+def icp_split_source(ctx, binding, src_rows, tgt, allreduce, **params):
+    """ICP of ONE pair with this rank's rows of the source (shard_range over the rows) and the whole target.
+    Every rank gets the same T / iterations / fitness (fitness = mean over ALL source rows)."""
+    p = ctx.icp_params(**params)
+    p.allreduce = allreduce
+    return ctx.icp(src_rows, tgt, p)
+
+
+def _load_rccl():
+    import torch  # noqa: F401  (its librccl is the one dlopen("librccl.so") inside libkssicp.so resolves to)
+    for name in ("librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"):
+        try:
+            return C.CDLL(name)
+        except OSError:
+            continue
+    import os
+    import torch as _t
+    return C.CDLL(os.path.join(os.path.dirname(_t.__file__), "lib", "librccl.so"))
+
+
+class _UniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+def rccl_comm(rank, world, device=None):
+    """An ncclComm_t of our own over the ranks of the initialised torch.distributed job (torch does not hand out its
+    communicator): rank 0 draws the unique id, one broadcast carries its 128 bytes, every rank joins.  Returns
+    (librccl handle, comm as c_void_p); call lib.ncclCommDestroy(comm) when done.  The HIP device must be current."""
+    import torch
+    import torch.distributed as dist
+    lib = _load_rccl()
+    uid = _UniqueId()
+    if rank == 0 and lib.ncclGetUniqueId(C.byref(uid)) != 0:
+        raise RuntimeError("ncclGetUniqueId failed")
+    t = torch.from_numpy(np.frombuffer(bytes(uid), dtype=np.uint8).copy())
+    if world > 1:
+        if device is not None:
+            t = t.to(device)
+        dist.broadcast(t, src=0)
+        t = t.cpu()
+    C.memmove(C.byref(uid), t.numpy().tobytes(), 128)
+    comm = C.c_void_p()
+    lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
+    if lib.ncclCommInitRank(C.byref(comm), int(world), uid, int(rank)) != 0:
+        raise RuntimeError("ncclCommInitRank failed")
+    lib.ncclCommDestroy.argtypes = [C.c_void_p]
+    return lib, comm
+
+
+def rccl_allreduce_params(ctx, binding, library, comm, **params):
+    """kss_icp_params whose exchange step is the library's own RCCL callback (ncclAllReduce on the context's stream,
+    no Python in the loop).  Returns (params, keepalive): keep `keepalive` referenced while the params are in use."""
+    link = binding.RcclLink(ctx.h, comm)
+    p = ctx.icp_params(**params)
+    p.allreduce = C.cast(library.kss_rccl_allreduce_sum, binding.ALLREDUCE_FN)
+    p.allreduce_user = C.cast(C.pointer(link), C.c_void_p)
+    return p, link

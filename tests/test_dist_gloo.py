@@ -59,6 +59,58 @@ def test_shard_and_gather_gloo(world, npairs):
     assert all(ret.get(r, False) for r in range(world)), dict(ret)
 
 
+def _sums_numpy(moved, tgt, idx, d2, max_d2=1.0):
+    """The KSS_NSUMS correspondence sums of one rank's rows (layout of include/kssicp.h), in f64."""
+    s = np.zeros(20)
+    keep = ~(d2.astype(np.float64) > max_d2)
+    p, q = moved[keep].astype(np.float64), tgt[idx[keep]].astype(np.float64)
+    s[0] = keep.sum(); s[1:4] = p.sum(0); s[4:7] = q.sum(0); s[7:16] = (p[:, :, None] * q[:, None, :]).sum(0).reshape(-1)
+    s[16] = d2[keep].astype(np.float64).sum(); s[17] = d2.astype(np.float64).sum(); s[18] = np.sqrt(d2.astype(np.float64)).sum()
+    return s
+
+
+def _split_worker(rank, world, port, iters, ret):
+    """Source rows split over ranks, target replicated, ONE all-reduce of the sums per iteration through the
+    kss_allreduce_fn callback (gloo here, RCCL on GPUs).  The per-rank NN pass is done by the oracle (test stand-in for
+    the HIP pass); what is tested is the exchange step: same T on every rank, equal to the unsharded registration."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = graft.load_package(); O = graft.load_oracle(); S = pkg.synth
+    src, tgt = S.make_pair(7, 3000, R=S.rot_axis_angle([0.1, 0.3, 1.0], np.deg2rad(8.0)), t=(0.01, 0.0, -0.02), shape="bumpy")
+    lo, hi = pkg.shard.shard_range(len(src), world, rank)
+    rows = src[lo:hi]
+    cb = pkg.shard.make_allreduce(pkg.binding)
+    fin = np.eye(4, dtype=np.float32)
+    cur = rows.copy()
+    for _ in range(iters):
+        idx, d2 = O.nn_brute(cur, tgt)
+        sums = _sums_numpy(cur, tgt, idx, d2)
+        buf = (C.c_double * 20)(*sums)
+        assert cb(None, buf, 20) == 0
+        Tk = O.rigid_from_sums(np.array(buf[:]))
+        fin = O.mat4_mul(Tk, fin)
+        cur = O.transform_points_f32(Tk, cur)                 # PCL transforms the cloud incrementally
+    allT = [torch.zeros(16, dtype=torch.float32) for _ in range(world)]
+    dist.all_gather(allT, torch.from_numpy(np.ascontiguousarray(fin, dtype=np.float32).reshape(-1)))
+    same = all(torch.equal(allT[0], t) for t in allT)
+    ref = O.icp(src, tgt, O.icp_params(max_iterations=iters, fixed_iterations=1))
+    err = float(np.abs(ref["T"] - fin).max())
+    ret[rank] = (bool(same), err)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_split_source_exchange_gloo(world):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_split_worker, args=(world, _free_port(), 6, ret), nprocs=world, join=True)
+    for r in range(world):
+        same, err = ret[r]
+        assert same and err < 2e-6, dict(ret)      # f64 sums grouped per rank instead of serially: float round-off of T
+
+
 def test_shard_range_partitions():
     pkg = graft.load_package()
     for n in (1, 7, 8, 8192):

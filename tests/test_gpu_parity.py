@@ -296,9 +296,8 @@ def test_abi_rejects_bad_arguments(ctx, pkg):
     assert L.kss_rigid_from_sums(vp(np.zeros(20)), vp(np.zeros(16, np.float32))) == -1         # zero correspondences
 
 
-def test_gather_results_over_rccl_single_rank(ctx, pkg):
-    """kss_gather_results with a real ncclComm_t (one rank: the collective degenerates to a copy, but the dlopen of
-    librccl, the symbol lookup, the staging and the stream handling are the ones N ranks use)."""
+def _single_rank_comm():
+    """A real ncclComm_t with one rank, made through librccl directly (the same library dlopen("librccl.so") finds)."""
     import ctypes as C
     import torch  # noqa: F401  (loads torch's librccl so that dlopen("librccl.so") resolves to the same library)
     rccl = None
@@ -319,6 +318,15 @@ def test_gather_results_over_rccl_single_rank(ctx, pkg):
     comm = C.c_void_p()
     rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
     assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    return rccl, comm
+
+
+def test_gather_results_over_rccl_single_rank(ctx, pkg):
+    """kss_gather_results with a real ncclComm_t (one rank: the collective degenerates to a copy, but the dlopen of
+    librccl, the symbol lookup, the staging and the stream handling are the ones N ranks use)."""
+    import ctypes as C
+    rccl, comm = _single_rank_comm()
     n = 5
     local = (pkg.IcpResult * n)()
     for i in range(n):
@@ -331,5 +339,70 @@ def test_gather_results_over_rccl_single_rank(ctx, pkg):
     assert rc == 0, L.kss_last_error(ctx.h)
     for i in range(n):
         assert allr[i].pair_id == i and allr[i].fitness == 0.25 * i and allr[i].iterations == 10 + i and allr[i].T[7] == float(i * 16 + 7)
-    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)
+
+
+def test_split_source_icp_two_ranks_on_one_gpu(pkg):
+    """SURVEY 8e, the single-pair exchange step: source rows split over ranks, target replicated, the 20 sums summed
+    over the ranks after every pass.  Two contexts on this GPU play the two ranks (one thread each); the all-reduce
+    callback is a barrier-and-add between the threads, standing in for RCCL.  Both ranks must end with the same
+    transform, and it must match the unsharded registration."""
+    import ctypes as C
+    import threading
+    S = pkg.synth
+    src, tgt = S.make_pair(51, 40000, R=S.rot_axis_angle([0.2, 0.1, 1.0], np.deg2rad(7.0)), t=(0.01, 0.02, -0.01), shape="bumpy")
+    world = 2
+    ctxs = [pkg.Context(0) for _ in range(world)]
+    bar = threading.Barrier(world)
+    slots = [None] * world
+
+    def make_cb(rank):
+        def cb(_user, values, n):
+            try:
+                slots[rank] = np.ctypeslib.as_array(values, shape=(int(n),)).copy()
+                bar.wait(timeout=60)
+                tot = slots[0] + slots[1]                 # fixed order: both ranks get the same bits
+                bar.wait(timeout=60)
+                np.ctypeslib.as_array(values, shape=(int(n),))[:] = tot
+                return 0
+            except Exception:
+                return -1
+        return pkg.binding.ALLREDUCE_FN(cb)
+
+    out = [None] * world
+
+    def run(rank):
+        lo, hi = pkg.shard.shard_range(len(src), world, rank)
+        cb = make_cb(rank)
+        out[rank] = pkg.shard.icp_split_source(ctxs[rank], pkg.binding, src[lo:hi], tgt, cb, nn_mode=pkg.NN_GRID)
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert all(o is not None for o in out)
+    ref = ctxs[0].icp(src, tgt, ctxs[0].icp_params(nn_mode=pkg.NN_GRID))
+    assert np.array_equal(out[0]["T"], out[1]["T"]) and out[0]["iterations"] == out[1]["iterations"] and out[0]["fitness"] == out[1]["fitness"]
+    assert out[0]["iterations"] == ref["iterations"] and out[0]["converged"] == ref["converged"]
+    assert np.abs(out[0]["T"] - ref["T"]).max() < 2e-6 and abs(out[0]["fitness"] - ref["fitness"]) < 1e-9
+    for c in ctxs:
+        c.close()
+
+
+def test_split_source_icp_over_rccl_single_rank(ctx, pkg):
+    """The RCCL-backed callback (kss_rccl_allreduce_sum) with a real one-rank communicator: ncclAllReduce of the sums
+    on the context's stream every iteration; one rank's sum is itself, so the result equals the plain registration."""
+    import ctypes as C
+    rccl, comm = _single_rank_comm()
+    S = pkg.synth
+    src, tgt = S.make_pair(52, 20000, R=S.rot_axis_angle([0, 0, 1], np.deg2rad(6.0)), shape="bumpy")
+    L = pkg.load_library()
+    link = pkg.binding.RcclLink(ctx.h, comm)
+    p = ctx.icp_params()
+    p.allreduce = C.cast(L.kss_rccl_allreduce_sum, pkg.binding.ALLREDUCE_FN)
+    p.allreduce_user = C.cast(C.pointer(link), C.c_void_p)
+    a = ctx.icp(src, tgt, p)
+    b = ctx.icp(src, tgt, ctx.icp_params())
+    assert np.array_equal(a["T"], b["T"]) and a["iterations"] == b["iterations"] and a["fitness"] == b["fitness"]
     rccl.ncclCommDestroy(comm)
