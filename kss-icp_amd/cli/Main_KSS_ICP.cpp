@@ -6,7 +6,9 @@
 // lines, but takes its paths from argv like the reference's shipped executables (EXE/Readme.txt:8-15) instead
 // of the hard-coded E:// paths (:67-71).  It also prints the (s, R, t) the reference never emits.
 //
-//   usage: kss_icp source.ply target.ply [result.xyz]
+//   usage: kss_icp source target [result.xyz]
+// Inputs: ASCII or binary-little-endian .ply, or the reference's text clouds (count, then "x y z" rows: .xyz / .gird /
+// .wlop); see cloud_io.hpp.
 #include <cstdio>
 #include <exception>
 #include <iostream>
@@ -14,37 +16,18 @@
 #include <vector>
 
 #include "KSS_ICP.hpp"
-#include "PlyLoad.h"
+#include "cloud_io.hpp"
 #include "registrationMeasure.hpp"
 
 namespace {
 
-typedef std::vector<std::vector<double>> Cloud;
-
-Cloud read_ply_vertices(const std::string& path) {
-    std::vector<char> name(path.begin(), path.end());
-    name.push_back('\0');
-    CPLYLoader loader;              // same loader class name / LoadModel(char*) contract as the reference
-    loader.LoadModel(name.data());
-    return loader.points;
-}
-
-// ".xyz": first line N, then "x y z" per line, then an empty line; opened in APPEND mode like the reference
-// (Main_KSS_ICP.cpp:49-59), so running twice into the same file stacks two clouds.
-bool append_xyz(const Cloud& cloud, const std::string& path) {
-    std::FILE* f = std::fopen(path.c_str(), "a");
-    if (!f) return false;
-    std::fprintf(f, "%zu\n", cloud.size());
-    for (const std::vector<double>& p : cloud) std::fprintf(f, "%g %g %g\n", p[0], p[1], p[2]);
-    std::fprintf(f, "\n");
-    std::fclose(f);
-    return true;
-}
+using kss_cli::Cloud;
+using kss_cli::append_xyz;
 
 int run(const std::string& src_path, const std::string& tgt_path, const std::string& out_path) {
     std::cout << "start!" << std::endl << "load ply:" << std::endl;
-    const Cloud source = read_ply_vertices(src_path);
-    const Cloud target = read_ply_vertices(tgt_path);
+    const Cloud source = kss_cli::read_cloud(src_path);
+    const Cloud target = kss_cli::read_cloud(tgt_path);
     std::cout << "load ply finished." << std::endl;
     if (source.empty() || target.empty()) {
         std::cout << "empty point cloud" << std::endl;
@@ -80,7 +63,7 @@ int run(const std::string& src_path, const std::string& tgt_path, const std::str
 
 int main(int argc, char** argv) {
     if (argc < 3) {
-        std::cout << "usage: " << argv[0] << " source.ply target.ply [result.xyz]" << std::endl;
+        std::cout << "usage: " << argv[0] << " source target [result.xyz]   (.ply ascii/binary, or count + xyz rows)" << std::endl;
         return 2;
     }
     try {

@@ -93,6 +93,66 @@ def test_cli_config_c1(pkg, O, tmp_path):
     assert r.returncode != 0 and "failed" in r.stdout
 
 
+def _write_ply_binary(path, pts, with_normals=False):
+    """binary_little_endian PLY (an input format the CLI accepts beyond the reference's ASCII-only loader)."""
+    pts = np.asarray(pts, dtype="<f4")
+    props = "property float x\nproperty float y\nproperty float z\n"
+    rec = pts
+    if with_normals:
+        props = "property uchar flag\n" + props + "property double nx\n"
+        dt = np.dtype([("flag", "u1"), ("xyz", "<f4", 3), ("nx", "<f8")])
+        rec = np.zeros(len(pts), dt); rec["xyz"] = pts; rec["flag"] = 7; rec["nx"] = 0.5
+    with open(path, "wb") as f:
+        f.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\n%selement face 0\nend_header\n" % (len(pts), props)).encode())
+        f.write(rec.tobytes())
+
+
+def test_cli_input_formats_and_batch_front_end(pkg, O, tmp_path):
+    """The same pair as ASCII PLY, binary PLY (plain and with extra properties) and the reference's count + rows text
+    format must register identically; the batch front-end (the reference's commented Main_KSS_List loop) runs the
+    reference's own data/registration pairs from their .gird / .wlop files."""
+    _build()
+    S = pkg.synth
+    src, tgt = S.make_pair(3, 1500, R=S.rot_axis_angle([0.3, 0.1, 1.0], np.deg2rad(20.0)), shape="bumpy")
+    outs = []
+    for kind in ("ascii", "binary", "binary_extra", "text"):
+        ps, pt = str(tmp_path / ("s_%s" % kind)), str(tmp_path / ("t_%s" % kind))
+        if kind == "ascii":
+            ps += ".ply"; pt += ".ply"; S.write_ply(ps, src); S.write_ply(pt, tgt)
+        elif kind.startswith("binary"):
+            ps += ".ply"; pt += ".ply"
+            _write_ply_binary(ps, src, kind == "binary_extra"); _write_ply_binary(pt, tgt, kind == "binary_extra")
+        else:
+            ps += ".xyz"; pt += ".wlop"
+            for p, c in ((ps, src), (pt, tgt)):
+                with open(p, "w") as f:
+                    f.write("%d\n" % len(c)); f.write("".join("%.9g %.9g %.9g\n" % tuple(r) for r in c))
+        r = subprocess.run([os.path.join(CLI, "kss_icp"), ps, pt, str(tmp_path / ("o_%s.xyz" % kind))], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append([l for l in r.stdout.splitlines() if l.startswith(("scale:", "R:", "t:", "Registration Measure"))])
+    # float32 coordinates survive the PLY flavours exactly (all parsed as float, then widened); the text format is read
+    # as double like the reference's loadPoints, so its 9-digit decimals are not the floats' exact values: close only
+    assert len(outs[0]) == 4 and outs[1] == outs[0] and outs[2] == outs[0], outs
+    num = lambda ls: np.array([float(x) for l in ls[:3] for x in l.split()[1:]])
+    assert np.abs(num(outs[3]) - num(outs[0])).max() < 1e-5, outs
+    # batch front-end over the reference's own pairs
+    d = os.path.join(GOLDEN, "ref_data", "registration")
+    r = subprocess.run([os.path.join(CLI, "kss_icp_list"), d, str(tmp_path), "Bunny", "Horse"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for name in ("Bunny", "Horse"):
+        assert re.search(r"^%s:time: " % name, r.stdout, re.M) and re.search(r"^%s:MSE: " % name, r.stdout, re.M)
+        mse = float(re.search(r"^%s:MSE: (\S+)" % name, r.stdout, re.M).group(1))
+        Sg = np.loadtxt(os.path.join(d, name + ".gird"), skiprows=1); Tw = np.loadtxt(os.path.join(d, name + ".wlop"), skiprows=1)
+        m = min(len(Sg), len(Tw)) // 2
+        ko = O.kssicp_register(Sg[O.aivs(Sg, m)], Tw[O.aivs(Tw, m)], Sg, 8.0, 1000)      # the same pipeline on the oracle
+        assert abs(mse - O.pcr_qm(ko["pointAlign"], Tw)[0]) < 1e-4 * mse                      # (printed with 6 digits)
+        a = open(str(tmp_path / (name + "Align.xyz"))).read().split("\n")
+        t = open(str(tmp_path / (name + "Target.xyz"))).read().split("\n")
+        assert int(a[0]) == len(np.loadtxt(os.path.join(d, name + ".gird"), skiprows=1)) and int(t[0]) == len(np.loadtxt(os.path.join(d, name + ".wlop"), skiprows=1))
+    r = subprocess.run([os.path.join(CLI, "kss_icp_list"), d, str(tmp_path), "NoSuchObject"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "no source/target file" in r.stdout
+
+
 def test_aivs_matches_oracle(ctx, O, pkg, ref_pairs):
     """AIVS down-sampler (voxel grid + 8-colour per-voxel FPS + accurate cut): identical selection, in identical
     order, as the oracle's line-by-line restatement of the reference."""
