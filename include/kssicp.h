@@ -110,7 +110,7 @@ int kss_nn(kss_ctx *ctx, const float *src, int64_t ns, const float *tgt, int64_t
 int kss_nn_dev(kss_ctx *ctx, const float *d_src, int64_t ns, const float *d_tgt, int64_t nt,
                int32_t *d_idx, float *d_d2);
 
-/* ---- exact k-NN (k <= 32): pcl::KdTreeFLANN::nearestKSearch with K > 1 (ballRegionCompute.hpp:499 K = 13,
+/* ---- exact k-NN (k <= 64): pcl::KdTreeFLANN::nearestKSearch with K > 1 (ballRegionCompute.hpp:499 K = 13,
  *      Method_AIVS_SimPro.hpp:904 K = 3, Method_Octree.hpp:137, pcl::NormalEstimation K = 20) ----
  * idx / d2: nq * k entries, per query in ascending (d2, index) order; slots beyond nt hold -1 / +inf. */
 int kss_knn(kss_ctx *ctx, const float *query, int64_t nq, const float *tgt, int64_t nt, int k, int32_t *idx, float *d2);
@@ -242,6 +242,15 @@ int kss_downsample_fps(kss_ctx *ctx, const double *xyz, int64_t n, int64_t m, do
  * zero in the reference; KSS_ERR_CAPACITY if capacity is too small. */
 int kss_downsample_aivs(kss_ctx *ctx, const double *xyz, int64_t n, int64_t point_num, double *out, int64_t capacity,
                         int64_t *n_out, int32_t *out_idx);
+
+/* ---- (8f #3) octree down-sampler: PCL_octree::PCL_Octree_Simplification_WithOutNormal, Method_Octree.hpp:77-165 ----
+ * resolution = mean distance of the first 1000 points to their kn-th nearest point (kn = 2 below 80000 points, else
+ * 7 * (n / 80000) capped at 35); occupied voxels of a pcl::octree::OctreePointCloudSearch of that resolution (PCL
+ * 1.8.1 bounding-cube rules, insertion order) in depth-first order; every voxel centre replaced by its nearest
+ * cloud point (ties -> lowest index).  out_idx receives one point index per voxel (repeats possible, as in the
+ * reference); *n_out the voxel count.  Needs n >= 1000.  PCL is absent from the reference tree: parity unpinned. */
+int kss_downsample_octree(kss_ctx *ctx, const double *xyz, int64_t n, int32_t *out_idx, int64_t capacity,
+                          int64_t *n_out, double *resolution_out /* may be NULL */);
 
 /* ---- PCR_QM: registrationMeasure.hpp:47-98 -> out = {MSE, RMSE, MAE} ---- */
 int kss_pcr_qm(kss_ctx *ctx, const double *aligned, int64_t na, const double *tmpl, int64_t nt,

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "KSS_ICP.hpp"
+#include "Method_Octree.hpp"
 #include "initRegistrationKSS.hpp"
 #include "registrationMeasure.hpp"
 
@@ -49,6 +50,10 @@ int main(int argc, char** argv) {
         k2.KSSICP_init(S, T, 6);
         k2.KSSICP_Registration(1000);
         std::printf("REG scale %.17g fitness %.17g n %zu\n", k2.lastRegistration.scale, k2.lastRegistration.final_fitness, k2.pointAlign.size());
+        PCL_octree oc;
+        auto D = oc.PCL_Octree_Simplification_WithOutNormal(T);
+        auto DN = oc.PCL_Octree_Simplification(T, T);     // (normals stand-in: any per-point rows)
+        std::printf("OCTREE %zu %.17g %zu %zu first %.17g %.17g %.17g\n", D.size(), oc.lastResolution, DN[0].size(), DN[1].size(), D[0][0], D[0][1], D[0][2]);
     } catch (const std::exception& e) {
         std::printf("FAILED %s\n", e.what());
         return 1;

@@ -47,7 +47,7 @@ struct kss_ctx {
     // grow-only device workspace
     DevBuf tgt4, src0, cur[2], keys, partials, sums, nn_work, red_work, pair_red, state, cs, scratch_a,
         scratch_b, scratch_c, stage_src, stage_tgt, stage_idx, stage_d2, stage_out, g_counts, g_start, g_cursor,
-        g_bsums, g_sorted, g_list, g_count, g_bbox, g_partials, g_start2, g_pairs, g_stamps, g_pos, pack_seg, reg_s, reg_t, reg_p, reg_all, reg_f, reg_g;
+        g_bsums, g_sorted, g_list, g_count, g_bbox, g_partials, g_start2, g_pairs, g_stamps, g_pos, pack_seg, reg_s, reg_t, reg_p, reg_all, reg_f, reg_g, oct_pts, oct_cen, oct_a, oct_b, oct_tmp;
     HostPool pool;   // per-pair host work of batched iterations
     std::vector<unsigned long long> last_stamps;
     double evals_sum = 0.0, evals_launches = 0.0;   // diagnostic runs: distance evaluations of the fused grid launches
@@ -205,7 +205,7 @@ int kss_ctx_destroy(kss_ctx* c) {
     DevBuf* bufs[] = {&c->tgt4, &c->src0, &c->cur[0], &c->cur[1], &c->keys, &c->partials, &c->sums, &c->nn_work,
                       &c->red_work, &c->pair_red, &c->state, &c->cs, &c->scratch_a, &c->scratch_b, &c->scratch_c,
                       &c->stage_src, &c->stage_tgt, &c->stage_idx, &c->stage_d2, &c->stage_out, &c->g_counts, &c->g_start,
-                      &c->g_cursor, &c->g_bsums, &c->g_sorted, &c->g_list, &c->g_count, &c->g_bbox, &c->g_partials, &c->g_start2, &c->g_pairs, &c->g_stamps, &c->g_pos, &c->pack_seg, &c->reg_s, &c->reg_t, &c->reg_p, &c->reg_all, &c->reg_f, &c->reg_g};
+                      &c->g_cursor, &c->g_bsums, &c->g_sorted, &c->g_list, &c->g_count, &c->g_bbox, &c->g_partials, &c->g_start2, &c->g_pairs, &c->g_stamps, &c->g_pos, &c->pack_seg, &c->reg_s, &c->reg_t, &c->reg_p, &c->reg_all, &c->reg_f, &c->reg_g, &c->oct_pts, &c->oct_cen, &c->oct_a, &c->oct_b, &c->oct_tmp};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (c->h_sums) hipHostFree(c->h_sums);
@@ -1043,7 +1043,7 @@ int kss_nn(kss_ctx* c, const float* src, int64_t ns, const float* tgt, int64_t n
 // ---- k-NN and normals -------------------------------------------------------------------------------
 static int knn_generic_dev(kss_ctx* c, const void* d_q, int64_t nq, const void* d_t, int64_t nt, int dtype, int k, int32_t* d_idx, float* d_d2) {
     if (!c || !d_q || !d_t || !d_idx || !d_d2) return set_err(c, KSS_ERR_ARG, "knn: null argument");
-    if (nq <= 0 || nt <= 0 || k < 1 || k > 32) return set_err(c, KSS_ERR_ARG, "knn: need nq, nt > 0 and 1 <= k <= 32");
+    if (nq <= 0 || nt <= 0 || k < 1 || k > 64) return set_err(c, KSS_ERR_ARG, "knn: need nq, nt > 0 and 1 <= k <= 64");
     if (nq > 0x7fff0000ll || nt > 0x7fff0000ll) return set_err(c, KSS_ERR_ARG, "knn: cloud too large");
     HIPCHK(c, hipSetDevice(c->device));
     const int64_t nt_pad = (nt + NN_TILE - 1) / NN_TILE * NN_TILE;
@@ -1072,7 +1072,7 @@ int kss_knn_dev(kss_ctx* c, const float* d_query, int64_t nq, const float* d_tgt
 
 int kss_knn(kss_ctx* c, const float* query, int64_t nq, const float* tgt, int64_t nt, int k, int32_t* idx, float* d2) {
     if (!c || !query || !tgt || !idx || !d2) return set_err(c, KSS_ERR_ARG, "knn: null argument");
-    if (nq <= 0 || nt <= 0 || k < 1 || k > 32) return set_err(c, KSS_ERR_ARG, "knn: need nq, nt > 0 and 1 <= k <= 32");
+    if (nq <= 0 || nt <= 0 || k < 1 || k > 64) return set_err(c, KSS_ERR_ARG, "knn: need nq, nt > 0 and 1 <= k <= 64");
     HIPCHK(c, hipSetDevice(c->device));
     KCHK(upload(c, c->stage_src, query, (size_t)nq * 3 * sizeof(float)));
     KCHK(upload(c, c->stage_tgt, tgt, (size_t)nt * 3 * sizeof(float)));
@@ -1289,6 +1289,58 @@ int kss_downsample_aivs(kss_ctx* c, const double* xyz, int64_t n, int64_t point_
         out[3 * i] = xyz[3 * (size_t)s]; out[3 * i + 1] = xyz[3 * (size_t)s + 1]; out[3 * i + 2] = xyz[3 * (size_t)s + 2];
         if (out_idx) out_idx[i] = s;
     }
+    return KSS_OK;
+}
+
+// ---- octree down-sampler (Method_Octree.hpp:77-165) ----------------------------------------------------
+int kss_downsample_octree(kss_ctx* c, const double* xyz, int64_t n, int32_t* out_idx, int64_t capacity, int64_t* n_out,
+                          double* resolution_out) {
+    if (!c || !xyz || !out_idx || !n_out) return set_err(c, KSS_ERR_ARG, "downsample_octree: null argument");
+    if (n < 1000 || n > 0x7fff0000ll) return set_err(c, KSS_ERR_ARG, "downsample_octree: needs 1000 <= n < 2^31 points (the reference reads the first 1000 unconditionally)");
+    HIPCHK(c, hipSetDevice(c->device));
+    // the float cloud (cloud_i.x = pData[i][0]) on the host (box replay) and on the device
+    std::vector<float> pf((size_t)n * 3);
+    for (size_t i = 0; i < pf.size(); ++i) pf[i] = (float)xyz[i];
+    KCHK(upload(c, c->oct_pts, pf.data(), pf.size() * sizeof(float)));
+    // PCL_Octree_Resolution (:151-165) -> PCL_Octree_Estimate_Radius (:110-149): first 1000 points, kn-th neighbour
+    int kn;
+    if (n < 80000) kn = 2;
+    else { const int md = (int)(n / 80000); kn = md >= 5 ? 35 : 7 * md; }
+    KCHK(ensure(c, c->stage_idx, (size_t)1000 * kn * sizeof(int32_t)));
+    KCHK(ensure(c, c->stage_d2, (size_t)1000 * kn * sizeof(float)));
+    KCHK(knn_generic_dev(c, c->oct_pts.p, 1000, c->oct_pts.p, n, KSS_F32, kn, (int32_t*)c->stage_idx.p, (float*)c->stage_d2.p));
+    std::vector<float> kd((size_t)1000 * kn);
+    HIPCHK(c, hipMemcpyAsync(kd.data(), c->stage_d2.p, kd.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double radiusSum = 0;
+    for (int i = 0; i < 1000; ++i) radiusSum = radiusSum + std::sqrt((double)kd[(size_t)i * kn + kn - 1]);
+    radiusSum = radiusSum / 1000;
+    const float resolution = (float)radiusSum;
+    if (resolution_out) *resolution_out = (double)resolution;
+    if (!(resolution > 0.f)) return set_err(c, KSS_ERR_ARG, "downsample_octree: zero resolution (coincident points)");
+    // addPointsFromInputCloud: PCL's bounding cube, grown in insertion order
+    OctBox box;
+    std::memset(&box, 0, sizeof box);
+    box.res = (double)resolution;
+    oct_first_point(box, pf.data());
+    for (int64_t i = 0; i < n; ++i)
+        if (!oct_adopt(box, pf.data() + 3 * i)) return set_err(c, KSS_ERR_ARG, "downsample_octree: octree deeper than 21 levels");
+    // occupied voxels in depth-first order -> centres
+    KCHK(ensure(c, c->oct_cen, (size_t)n * 3 * sizeof(float)));
+    std::string err;
+    DevBuf* bufs[4] = {&c->oct_a, &c->oct_b, &c->scratch_c, &c->oct_tmp};
+    auto scratch = [c, &bufs](int which, size_t bytes) -> void* { return ensure(c, *bufs[which], bytes) == KSS_OK ? bufs[which]->p : nullptr; };
+    int m = 0;
+    const int rc = octree_voxels_device(c->stream, (const float*)c->oct_pts.p, (int)n, box, (float*)c->oct_cen.p, &m, err, scratch);
+    if (rc != KSS_OK) return set_err(c, rc, err.c_str());
+    *n_out = m;
+    if (m > capacity) return set_err(c, KSS_ERR_CAPACITY, "downsample_octree: output buffer too small");
+    // octree.nearestKSearch(centre, 1): the exact NN engine (ties -> lowest index)
+    KCHK(ensure(c, c->stage_idx, (size_t)m * sizeof(int32_t)));
+    KCHK(ensure(c, c->stage_d2, (size_t)m * sizeof(float)));
+    KCHK(kss_nn_dev(c, (const float*)c->oct_cen.p, m, (const float*)c->oct_pts.p, n, (int32_t*)c->stage_idx.p, (float*)c->stage_d2.p));
+    HIPCHK(c, hipMemcpyAsync(out_idx, c->stage_idx.p, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return KSS_OK;
 }
 

@@ -3,6 +3,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
 #include <cstdint>
 #include <functional>
 #include <string>
@@ -77,9 +80,48 @@ struct PackSeg {
     int64_t n;          // real points; slots [n, next segment) are sentinel padding
 };
 
+// PCL's octree bounding cube (kss_octree.hip; replayed on the host by oct_first_point / oct_adopt)
+struct OctBox {
+    double min[3], max[3];
+    double res;
+    int32_t depth;
+};
+
 constexpr int NN_TILE = 256;      // targets staged per LDS tile (one float4 per thread)
 constexpr int NN_SUB = 32;        // targets per sub-tile (arg-min bookkeeping granularity)
 constexpr int NN_THREADS = 256;
+
+// pcl::octree::OctreePointCloud (1.8.1) bounding-cube rules, restated from its published source (octree_pointcloud.hpp).
+// Empty octree: cube = point +- resolution / 2, then getKeyBitSize(): depth = bits of the voxel count (>= 2 per axis),
+// cube centred around the box.
+inline void oct_first_point(OctBox& b, const float* p) {
+    const float minValue = FLT_EPSILON;
+    for (int k = 0; k < 3; ++k) { b.min[k] = p[k] - b.res / 2; b.max[k] = p[k] + b.res / 2; }
+    unsigned maxv = 2;
+    for (int k = 0; k < 3; ++k) maxv = std::max(maxv, (unsigned)std::ceil((b.max[k] - b.min[k] - minValue) / b.res));
+    b.depth = (int)std::ceil(std::log2((double)maxv) - minValue);
+    const double side = (double)(1u << b.depth) * b.res;
+    for (int k = 0; k < 3; ++k) {
+        const double over = (side - (b.max[k] - b.min[k])) / 2.0;
+        if (over > minValue) { b.min[k] -= over; b.max[k] += over; }
+    }
+}
+// adoptBoundingBoxToPoint: while the point is outside [min, max), add a level -- the old cube becomes the child on the
+// far side of every violated UPPER bound (min moves down on the other axes).  false: deeper than 21 levels.
+inline bool oct_adopt(OctBox& b, const float* p) {
+    const float minValue = FLT_EPSILON;
+    for (;;) {
+        bool up[3], any = false;
+        for (int k = 0; k < 3; ++k) { up[k] = p[k] >= b.max[k]; any = any || up[k] || p[k] < b.min[k]; }
+        if (!any) return true;
+        if (b.depth >= 21) return false;
+        double side = (double)(1u << b.depth) * b.res;
+        for (int k = 0; k < 3; ++k) if (!up[k]) b.min[k] -= side;
+        ++b.depth;
+        side = (double)(1u << b.depth) * b.res - minValue;
+        for (int k = 0; k < 3; ++k) b.max[k] = b.min[k] + side;
+    }
+}
 
 // ---- kernel launchers (kss_kernels.hip) ---------------------------------------------------------
 void launch_pack_f3_to_f4(hipStream_t st, const float* d_in, int64_t n, float4* d_out, int64_t n_pad, bool sentinel);
@@ -143,6 +185,8 @@ void launch_pose_apply(hipStream_t st, const double* d_in, int64_t n, const kss_
 void launch_transform_apply_f64(hipStream_t st, const float T[16], const double* d_in, int64_t n, double* d_out);
 
 void launch_transform_apply_f32(hipStream_t st, const float T[16], const float* d_in, int64_t n, float* d_out);
+int octree_voxels_device(hipStream_t st, const float* d_pts, int n, const OctBox& box, float* d_cen, int* m_out, std::string& err,
+                         const std::function<void*(int, size_t)>& scratch);
 void launch_fps(hipStream_t st, const double* d_xyz, int n, int m, double* d_mind, int32_t* d_idx, double* d_out);
 
 void launch_rot_search(hipStream_t st, const double* d_src, int64_t ns, const float4* d_tgt4, int64_t nt_pad,

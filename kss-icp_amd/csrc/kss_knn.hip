@@ -1,7 +1,7 @@
 // kss_knn.hip -- exact k-nearest-neighbour sweep and PCL-style surface normals (the
 // "Method_Octree / pcl_kdtree NN" and "normalCompute reductions" the north star lists as replaced subsystems).
 //
-//   knn_sweep_kernel<K>   replaces pcl::KdTreeFLANN::nearestKSearch with K > 1 (ballRegionCompute.hpp:499 K=13,
+//   knn_sweep_kernel<K>   (K = 4 .. 64) replaces pcl::KdTreeFLANN::nearestKSearch with K > 1 (ballRegionCompute.hpp:499 K=13,
 //                         Method_AIVS_SimPro.hpp:904 K=3, Method_Octree.hpp:137, pcl::NormalEstimation K=20): the same
 //                         LDS-tiled source x target sweep as nn_sweep_kernel, each lane keeping a sorted top-K in
 //                         registers (strict '<' insertion while targets arrive in ascending index => equal distances
@@ -73,7 +73,8 @@ void launch_knn_sweep(hipStream_t st, const float4* d_qry, int nq, const float4*
     if (k <= 4) hipLaunchKernelGGL(knn_sweep_kernel<4>, grid, block, 0, st, d_qry, nq, d_tgt, nt_pad, d_idx, d_d2, k);
     else if (k <= 8) hipLaunchKernelGGL(knn_sweep_kernel<8>, grid, block, 0, st, d_qry, nq, d_tgt, nt_pad, d_idx, d_d2, k);
     else if (k <= 16) hipLaunchKernelGGL(knn_sweep_kernel<16>, grid, block, 0, st, d_qry, nq, d_tgt, nt_pad, d_idx, d_d2, k);
-    else hipLaunchKernelGGL(knn_sweep_kernel<32>, grid, block, 0, st, d_qry, nq, d_tgt, nt_pad, d_idx, d_d2, k);
+    else if (k <= 32) hipLaunchKernelGGL(knn_sweep_kernel<32>, grid, block, 0, st, d_qry, nq, d_tgt, nt_pad, d_idx, d_d2, k);
+    else hipLaunchKernelGGL(knn_sweep_kernel<64>, grid, block, 0, st, d_qry, nq, d_tgt, nt_pad, d_idx, d_d2, k);   // k <= 64 (octree resolution: kn = 35)
 }
 
 // ---- pcl::eigen33 smallest eigenpair, float, closed form (common/eigen.hpp) -----------------------------------------

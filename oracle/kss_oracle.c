@@ -1149,6 +1149,104 @@ void ko_normals_pcl(const double *P, int64_t n, int k, double *normals) {
     free(pf); free(idx); free(d2);
 }
 
+/* ---- octree down-sampler (Method_Octree.hpp:77-165 over PCL 1.8.1's OctreePointCloudSearch) ---------------- */
+typedef struct { double min[3], max[3], res; int depth; int defined; } ko_octbox;
+
+static void ko_oct_first_point(ko_octbox *b, const float *p) {
+    /* adoptBoundingBoxToPoint, empty octree: box = point +- resolution / 2, then getKeyBitSize() */
+    const float minValue = FLT_EPSILON;
+    for (int k = 0; k < 3; k++) { b->min[k] = p[k] - b->res / 2; b->max[k] = p[k] + b->res / 2; }
+    unsigned int maxv = 2;
+    for (int k = 0; k < 3; k++) {
+        unsigned int mk = (unsigned int)ceil((b->max[k] - b->min[k] - minValue) / b->res);
+        if (mk > maxv) maxv = mk;
+    }
+    b->depth = (int)ceil(log2((double)maxv) - minValue);
+    const double side = (double)(1u << b->depth) * b->res;
+    for (int k = 0; k < 3; k++) {   /* leaf_count_ == 0: centre the box inside the cube */
+        const double over = (side - (b->max[k] - b->min[k])) / 2.0;
+        if (over > minValue) { b->min[k] -= over; b->max[k] += over; }
+    }
+    b->defined = 1;
+}
+
+static int ko_oct_adopt(ko_octbox *b, const float *p) {
+    const float minValue = FLT_EPSILON;
+    for (;;) {
+        if (!b->defined) { ko_oct_first_point(b, p); continue; }
+        int lo[3], up[3], any = 0;
+        for (int k = 0; k < 3; k++) { lo[k] = p[k] < b->min[k]; up[k] = p[k] >= b->max[k]; any |= lo[k] | up[k]; }
+        if (!any) return 0;
+        if (b->depth >= 21) return -1;   /* 63-bit Morton codes below; PCL itself shifts an int by the depth */
+        /* one more level: the old cube becomes the child on the far side of every violated upper bound */
+        double side = (double)(1u << b->depth) * b->res;
+        for (int k = 0; k < 3; k++) if (!up[k]) b->min[k] -= side;
+        b->depth++;
+        side = (double)(1u << b->depth) * b->res - minValue;
+        for (int k = 0; k < 3; k++) b->max[k] = b->min[k] + side;
+    }
+}
+
+static int ko_cmp_u64(const void *a, const void *b) {
+    const uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+int64_t ko_octree_downsample(const double *pts, int64_t n, int32_t *out_idx, int64_t cap, double *resolution_out) {
+    if (!pts || n < 1000 || !out_idx) return -1;
+    float *pf = (float *)malloc((size_t)n * 3 * sizeof(float));
+    for (int64_t i = 0; i < 3 * n; i++) pf[i] = (float)pts[i];                 /* cloud_i.x = pData[i][0]: narrowed */
+    /* PCL_Octree_Resolution */
+    int kn;
+    if (n < 80000) kn = 2;
+    else { const int md = (int)(double)(n / 80000); kn = md >= 5 ? 35 : 7 * md; }
+    int32_t *ki = (int32_t *)malloc((size_t)1000 * kn * sizeof(int32_t));
+    float *kd = (float *)malloc((size_t)1000 * kn * sizeof(float));
+    ko_knn_brute(pf, 1000, pf, n, kn, ki, kd);
+    double radiusSum = 0;
+    for (int i = 0; i < 1000; i++) radiusSum = radiusSum + sqrt((double)kd[(size_t)i * kn + kn - 1]);
+    radiusSum = radiusSum / 1000;
+    const float resolution = (float)radiusSum;
+    free(ki); free(kd);
+    if (resolution_out) *resolution_out = (double)resolution;
+    if (!(resolution > 0.f)) { free(pf); return -2; }                          /* coincident points: PCL asserts */
+    /* addPointsFromInputCloud: grow the box in insertion order */
+    ko_octbox b; memset(&b, 0, sizeof b); b.res = (double)resolution;
+    for (int64_t i = 0; i < n; i++)
+        if (ko_oct_adopt(&b, pf + 3 * i) != 0) { free(pf); return -3; }
+    /* genOctreeKeyforPoint with the final box, packed so that ascending code == depth-first child order */
+    uint64_t *code = (uint64_t *)malloc((size_t)n * sizeof(uint64_t));
+    for (int64_t i = 0; i < n; i++) {
+        unsigned int key[3];
+        for (int k = 0; k < 3; k++) key[k] = (unsigned int)(((double)pf[3 * i + k] - b.min[k]) / b.res);
+        uint64_t c = 0;
+        for (int lev = b.depth - 1; lev >= 0; lev--)
+            c = (c << 3) | (uint64_t)((((key[0] >> lev) & 1u) << 2) | (((key[1] >> lev) & 1u) << 1) | ((key[2] >> lev) & 1u));
+        code[i] = c;
+    }
+    qsort(code, (size_t)n, sizeof(uint64_t), ko_cmp_u64);
+    int64_t m = 0;
+    for (int64_t i = 0; i < n; i++) if (i == 0 || code[i] != code[i - 1]) code[m++] = code[i];
+    /* voxel centres (genLeafNodeCenterFromOctreeKey) and their nearest cloud point */
+    float *cen = (float *)malloc((size_t)m * 3 * sizeof(float));
+    for (int64_t v = 0; v < m; v++) {
+        unsigned int key[3] = {0, 0, 0};
+        for (int lev = 0; lev < b.depth; lev++) {
+            const unsigned int tri = (unsigned int)((code[v] >> (3 * (b.depth - 1 - lev))) & 7u);
+            key[0] = (key[0] << 1) | ((tri >> 2) & 1u); key[1] = (key[1] << 1) | ((tri >> 1) & 1u); key[2] = (key[2] << 1) | (tri & 1u);
+        }
+        for (int k = 0; k < 3; k++) cen[3 * v + k] = (float)(((double)key[k] + 0.5f) * b.res + b.min[k]);
+    }
+    int32_t *nn = (int32_t *)malloc((size_t)m * sizeof(int32_t));
+    float *nd = (float *)malloc((size_t)m * sizeof(float));
+    ko_kdtree *t = ko_kdtree_build(pf, n, 15);
+    ko_kdtree_nn(t, cen, m, 0, 8, nn, nd);
+    ko_kdtree_free(t);
+    for (int64_t v = 0; v < m && v < cap; v++) out_idx[v] = nn[v];
+    free(nn); free(nd); free(cen); free(code); free(pf);
+    return m;
+}
+
 /* ------------------------------------------------------------------------------------ */
 uint64_t ko_splitmix64(uint64_t seed, uint64_t counter) {
     uint64_t z = seed + (counter + 1) * 0x9E3779B97F4A7C15ULL;

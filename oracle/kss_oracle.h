@@ -190,6 +190,20 @@ void ko_knn_brute(const float *q, int64_t nq, const float *t, int64_t nt, int k,
  *      PCL is absent from the reference tree: parity unpinned.  out: n*3 doubles. */
 void ko_normals_pcl(const double *pts, int64_t n, int k, double *normals);
 
+/* ---- octree down-sampler: PCL_octree::PCL_Octree_Simplification_WithOutNormal, Method_Octree.hpp:77-104 ----
+ * resolution = PCL_Octree_Resolution (:151-165): mean distance from each of the FIRST 1000 points to its kn-th
+ * nearest point (the point itself counts as the 1st), kn = 2 below 80000 points, else 7 * (n / 80000) capped at 35
+ * (:110-149; float cloud, sqrt and mean in double, narrowed to float).  Then a pcl::octree::OctreePointCloudSearch
+ * of that resolution over the float cloud: occupied voxel centres in the octree's depth-first order, and for each
+ * centre the nearest cloud point (K = 1).  The octree is PCL 1.8.1's, absent from the reference tree and restated
+ * from its published source (octree_pointcloud.hpp: adoptBoundingBoxToPoint -- the box starts as the first point
+ * +- resolution and doubles towards every point that falls outside, in insertion order --, getKeyBitSize,
+ * genOctreeKeyforPoint, genLeafNodeCenterFromOctreeKey; octree_base getOccupiedVoxelCentersRecursive: children in
+ * index order, x bit most significant).  NN ties go to the lowest index (PCL: traversal order).  Parity unpinned.
+ * Needs n >= 1000 (the reference indexes pData[0..999] unconditionally).  A point may be returned for several
+ * voxels, as in the reference.  Returns the number of voxels (<= cap written), or < 0 on error. */
+int64_t ko_octree_downsample(const double *pts, int64_t n, int32_t *out_idx, int64_t cap, double *resolution_out);
+
 /* ---- synthetic clouds (portable counter-based RNG) ---- */
 uint64_t ko_splitmix64(uint64_t seed, uint64_t counter);
 

@@ -89,6 +89,8 @@ def lib():
         L.ko_fps.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.ko_knn_brute.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
         L.ko_normals_pcl.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        L.ko_octree_downsample.restype = C.c_int64
+        L.ko_octree_downsample.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_double)]
         L.ko_aivs.restype = C.c_int64
         L.ko_aivs.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64]
         L.ko_splitmix64.restype = C.c_uint64
@@ -320,6 +322,17 @@ def aivs(xyz, point_num):
     if k < 0:
         raise RuntimeError("ko_aivs rc=%d" % k)
     return idx[:k].copy()
+
+
+def octree_downsample(xyz):
+    """(indices of the selected points in octree depth-first voxel order -- repeats possible --, resolution)."""
+    a = _f64(xyz)
+    idx = np.empty(len(a), np.int32)
+    res = C.c_double(0)
+    k = lib().ko_octree_downsample(_p(a), len(a), _p(idx), len(idx), C.byref(res))
+    if k < 0:
+        raise RuntimeError("ko_octree_downsample rc=%d" % k)
+    return idx[:k].copy(), res.value
 
 
 def splitmix64(seed, counter):

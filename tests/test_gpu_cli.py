@@ -69,6 +69,10 @@ def test_mirror_classes_against_oracle(O, ref_pairs):
     m = min(len(S), len(T)) // 2
     ko = O.kssicp_register(S[O.aivs(S, m)], T[O.aivs(T, m)], S, 6.0, 1000)
     assert abs(reg[0] - ko["scale"]) < 1e-12 and abs(reg[1] - ko["final_fitness"]) < 1e-8 and int(reg[2]) == len(S)
+    oc = _vals(out, "OCTREE")
+    oi, ores = O.octree_downsample(T)
+    assert int(oc[0]) == len(oi) and oc[1] == ores and int(oc[2]) == len(oi) and int(oc[3]) == len(oi) and np.array_equal(oc[4:7], T[oi[0]])
+    assert "Down-sampling Point:%d" % len(oi) in out
 
 
 def test_cli_config_c1(pkg, O, tmp_path):
@@ -178,6 +182,26 @@ def test_aivs_matches_oracle(ctx, O, pkg, ref_pairs):
         O.aivs(flat, 100)
 
 
+def test_octree_downsampler_matches_oracle(ctx, O, pkg, ref_pairs):
+    """Method_Octree.hpp: kNN-derived resolution, PCL's bounding-cube growth in insertion order, occupied voxels in
+    depth-first order, nearest cloud point per voxel centre -- identical selection, in identical order, as the oracle's
+    restatement (kn = 2 below 80000 points, 7 and 14 above)."""
+    S = pkg.synth
+    rng = np.random.default_rng(3)
+    cases = [S.bumpy(21, 1000), S.bumpy(22, 7000) * np.array([1.0, 0.4, 2.5]) - 3.0, S.sphere(23, 30000),
+             S.bumpy(24, 90000), S.bumpy(25, 170000) + 10.0, rng.normal(size=(5000, 3)), ref_pairs[("registration", "Bunny")][1]]
+    cases.append(cases[1][rng.permutation(7000)])        # insertion order changes the cube PCL grows
+    for P in cases:
+        P = np.asarray(P, dtype=np.float64)
+        idx, res = ctx.downsample_octree(P)
+        ref, rres = O.octree_downsample(P)
+        assert res == rres and res > 0, (len(P), res, rres)
+        assert np.array_equal(idx, ref), (len(P), len(idx), len(ref))
+        assert 0 < len(idx) <= len(P) and idx.min() >= 0 and idx.max() < len(P)
+    with pytest.raises(pkg.KssError):
+        ctx.downsample_octree(S.bumpy(26, 999))           # the reference reads 1000 points unconditionally
+
+
 def test_knn_and_normals_match_oracle(ctx, O, pkg, ref_pairs):
     """Exact k-NN (ascending (d2, index)) bit for bit; PCL-style normals within float round-off of the oracle's
     restatement (device atan2f/cosf/sinf differ from glibc's in the last ulps)."""
@@ -185,7 +209,7 @@ def test_knn_and_normals_match_oracle(ctx, O, pkg, ref_pairs):
     t = rng.normal(size=(3000, 3)).astype(np.float32)
     t[100] = t[7]; t[2000] = t[7]                      # duplicates: ties keep the lower index first
     q = np.concatenate([t[[7, 100]], rng.normal(size=(500, 3)).astype(np.float32)])
-    for k in (1, 3, 13, 20, 32):
+    for k in (1, 3, 13, 20, 32, 35, 64):
         idx, d2 = ctx.knn(q, t, k)
         oi, od = O.knn_brute(q, t, k)
         assert np.array_equal(idx, oi) and np.array_equal(d2.view(np.uint32), od.view(np.uint32))
@@ -200,4 +224,4 @@ def test_knn_and_normals_match_oracle(ctx, O, pkg, ref_pairs):
         assert np.mean(dev < 1e-4) > 0.995               # ill-conditioned (near-isotropic) neighbourhoods may differ more
         assert np.median(dev) < 1e-6
     with pytest.raises(pkg.KssError):
-        ctx.knn(q, t, 33)
+        ctx.knn(q, t, 65)

@@ -166,3 +166,38 @@ def test_ply_loader_rules(O, pkg, tmp_path):
     open(bad, "w").write("ply\nformat ascii 1.0\nelement vertex 1\nend_header\n0 0 0\n")
     assert O.ply_load(bad)[0] < 0
     assert O.ply_load(str(tmp_path / "c.xyz"))[0] < 0                   # extension test
+
+
+def test_octree_downsample_voxel_bookkeeping(O, pkg):
+    """ko_octree_downsample against an independent numpy replay of PCL's bounding-cube growth and voxel keys: same
+    number of occupied voxels, every selected point is a real NN of a voxel centre, insertion order matters."""
+    P = (pkg.synth.bumpy(31, 1500) * np.array([1.0, 0.5, 2.0]) + 0.7).astype(np.float64)
+    idx, res = O.octree_downsample(P)
+    pf = P.astype(np.float32)
+    d2 = ((pf[:1000, None, :].astype(np.float64) - pf[None, :, :].astype(np.float64)) ** 2).sum(-1)
+    second = np.sort(d2, axis=1)[:, 1]                                   # kn = 2: the nearest OTHER point
+    assert abs(res - np.float32(np.sqrt(second).mean())) < 1e-6 * res    # (float vs double distance arithmetic)
+    eps = float(np.finfo(np.float32).eps)
+    r = float(res)
+    mn = pf[0].astype(np.float64) - r                                    # first point: +- r/2, centred in a depth-1 cube
+    depth = 1
+    mx = mn + 2 * r
+    for p in pf.astype(np.float64):
+        while True:
+            up = p >= mx
+            if not (up.any() or (p < mn).any()):
+                break
+            mn = np.where(up, mn, mn - (1 << depth) * r)
+            depth += 1
+            mx = mn + (1 << depth) * r - eps
+    keys = np.floor((pf.astype(np.float64) - mn) / r).astype(np.int64)
+    assert len({tuple(k) for k in keys}) == len(idx)
+    cen = ((keys.astype(np.float64) + 0.5) * r + mn).astype(np.float32)
+    sel = set(idx.tolist())
+    for c in cen[::97]:                                                  # spot check: the NN of a centre was selected
+        d = ((pf - c) ** 2).sum(1)
+        assert int(np.argmin(d)) in sel
+    idx2, _ = O.octree_downsample(P[::-1].copy())
+    assert len(idx2) > 0.5 * len(idx)                                    # a different first point shifts the lattice, not the scale
+    with pytest.raises(RuntimeError):
+        O.octree_downsample(P[:999])
