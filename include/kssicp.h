@@ -121,6 +121,11 @@ int kss_knn_dev(kss_ctx *ctx, const float *d_query, int64_t nq, const float *d_t
  * closed-form smallest eigenvector, flipped towards the view point (0,0,0)) and the reference's renormalisation in
  * double.  normals: n * 3 doubles.  The reference uses k = 20. */
 int kss_normals(kss_ctx *ctx, const double *pts, int64_t n, int k, double *normals);
+/* estimateNormal_RegularNormal, normalCompute.hpp:614-742 (with kss_normals: estimateNormal_PCL_MP, :358-403):
+ * consistent orientation of given normals (n*3 doubles, in place) by level-synchronous propagation over the 8-NN
+ * graph from point 0; a normal is negated when it points away from its parent's.  The 8-NN search runs on the
+ * device, the O(8 n) propagation on the host.  Unreached points keep their normals. */
+int kss_normals_orient(kss_ctx *ctx, const double *pts, int64_t n, double *normals);
 
 /* ---- (a10) correspondence sums for TransformationEstimationSVD / umeyama (inside PCL ICP) ----
  * sums[0]=n kept (d2 <= max_d2), [1..3]=sum src, [4..6]=sum tgt[idx], [7..15]=sum src_i*tgt_j

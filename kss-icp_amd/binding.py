@@ -24,7 +24,7 @@ SYMBOLS = [
     "kss_nn", "kss_nn_dev", "kss_cov", "kss_cov_dev", "kss_rigid_from_sums", "kss_rotation_search",
     "kss_rotation_search_dev", "kss_grid_angles", "kss_rotation_candidates", "kss_icp_default_params", "kss_icp",
     "kss_icp_dev", "kss_icp_batch", "kss_icp_batch_dev", "kss_transform_apply", "kss_transform_apply_dev",
-    "kss_pcr_qm", "kss_register", "kss_gather_results", "kss_rccl_allreduce_sum", "kss_transform_apply_f32", "kss_downsample_fps", "kss_downsample_aivs", "kss_downsample_octree", "kss_knn", "kss_knn_dev", "kss_normals",
+    "kss_pcr_qm", "kss_register", "kss_gather_results", "kss_rccl_allreduce_sum", "kss_transform_apply_f32", "kss_downsample_fps", "kss_downsample_aivs", "kss_downsample_octree", "kss_knn", "kss_knn_dev", "kss_normals", "kss_normals_orient",
 ]
 
 
@@ -118,6 +118,7 @@ def load_library():
     L.kss_profile_get.argtypes = [vp, C.c_int, C.POINTER(dbl), C.POINTER(i64)]
     L.kss_profile_event_overhead.argtypes = [vp, C.POINTER(dbl)]
     L.kss_downsample_octree.argtypes = [vp, vp, i64, vp, i64, C.POINTER(i64), C.POINTER(dbl)]
+    L.kss_normals_orient.argtypes = [vp, vp, i64, vp]
     for n in ("kss_preshape_stats", "kss_preshape_stats_dev"):
         getattr(L, n).argtypes = [vp, vp, C.c_int, i64, vp, C.POINTER(dbl)]
     for n in ("kss_pose_apply", "kss_pose_apply_dev"):
@@ -416,6 +417,11 @@ class Context:
         k = C.c_int64(0)
         self._chk(self.L.kss_downsample_aivs(self.h, _p(a), len(a), int(point_num), _p(out), len(a), C.byref(k), _p(idx)), "kss_downsample_aivs")
         return out[:k.value].copy(), idx[:k.value].copy()
+
+    def normals_orient(self, pts, normals):
+        a = _f64(pts); nrm = _f64(normals).copy()
+        self._chk(self.L.kss_normals_orient(self.h, _p(a), len(a), _p(nrm)), "kss_normals_orient")
+        return nrm
 
     def downsample_octree(self, pts):
         """(selected point indices in octree depth-first voxel order -- repeats possible --, resolution)."""

@@ -4,10 +4,12 @@
 #include <cstdio>
 #include <fstream>
 #include <iostream>
+#include <string>
 #include <vector>
 
 #include "KSS_ICP.hpp"
 #include "Method_Octree.hpp"
+#include "normalCompute.hpp"
 #include "initRegistrationKSS.hpp"
 #include "registrationMeasure.hpp"
 
@@ -50,6 +52,17 @@ int main(int argc, char** argv) {
         k2.KSSICP_init(S, T, 6);
         k2.KSSICP_Registration(1000);
         std::printf("REG scale %.17g fitness %.17g n %zu\n", k2.lastRegistration.scale, k2.lastRegistration.final_fitness, k2.pointAlign.size());
+        NormalEstimation ne;
+        ne.estimateNormal_init(std::string(argv[2]) + ".normals.tmp");
+        std::remove(ne.fileNormal.c_str());
+        auto N0 = ne.estimateNormal_PCL_MP_return(T);
+        ne.estimateNormal_PCL_MP(T);
+        NormalEstimation ne2;
+        ne2.estimateNormal_init(ne.fileNormal);
+        const bool loaded = ne2.normalLoad();
+        std::printf("NORMALS %zu %zu %d %zu first %.17g %.17g %.17g oriented %.17g %.17g %.17g\n", N0.size(), ne.normalVector.size(), loaded ? 1 : 0,
+                    ne2.normalVector.size(), N0[0][0], N0[0][1], N0[0][2], ne.normalVector[5][0], ne.normalVector[5][1], ne.normalVector[5][2]);
+        std::remove(ne.fileNormal.c_str());
         PCL_octree oc;
         auto D = oc.PCL_Octree_Simplification_WithOutNormal(T);
         auto DN = oc.PCL_Octree_Simplification(T, T);     // (normals stand-in: any per-point rows)

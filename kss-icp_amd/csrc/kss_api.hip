@@ -1103,6 +1103,57 @@ int kss_normals(kss_ctx* c, const double* pts, int64_t n, int k, double* normals
     return KSS_OK;
 }
 
+// estimateNormal_RegularNormal (normalCompute.hpp:614-742): consistent orientation by level-synchronous propagation
+// over the 8-NN graph from point 0.  The 8-NN of every point is the device's work (n x 8 exact neighbours); the
+// propagation itself is an O(8 n) graph walk whose levels depend on each other, hundreds of them on a surface:
+// it runs on the host (one pass over the lists, a per-level stamp instead of the reference's quadratic
+// "already listed" scan -- same first-occurrence order, same parents, same result).
+int kss_normals_orient(kss_ctx* c, const double* pts, int64_t n, double* normals) {
+    if (!c || !pts || !normals) return set_err(c, KSS_ERR_ARG, "normals_orient: null argument");
+    if (n <= 0 || n > 0x7fff0000ll) return set_err(c, KSS_ERR_ARG, "normals_orient: bad size");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int Kn = 8;                                   // :639
+    const int k = n < Kn ? (int)n : Kn;
+    KCHK(upload(c, c->scratch_a, pts, (size_t)n * 3 * sizeof(double)));
+    KCHK(ensure(c, c->stage_idx, (size_t)n * k * sizeof(int32_t)));
+    KCHK(ensure(c, c->stage_d2, (size_t)n * k * sizeof(float)));
+    KCHK(knn_generic_dev(c, c->scratch_a.p, n, c->scratch_a.p, n, KSS_F64, k, (int32_t*)c->stage_idx.p, (float*)c->stage_d2.p));
+    std::vector<int32_t> ki((size_t)n * k);
+    std::vector<float> kd((size_t)n * k);
+    HIPCHK(c, hipMemcpyAsync(ki.data(), c->stage_idx.p, ki.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(kd.data(), c->stage_d2.p, kd.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<char> judge((size_t)n, 0);
+    std::vector<int64_t> listed((size_t)n, -1);
+    std::vector<int32_t> cur(1, 0), nxt, par;
+    judge[0] = 1;                                       // start = 0 (:616, :674)
+    for (int64_t level = 0; !cur.empty(); ++level) {
+        nxt.clear(); par.clear();
+        for (const int32_t u : cur) {
+            const size_t row = (size_t)u * k;
+            const int first = kd[row] == 0 ? 1 : 0;      // the query itself leads the list when its distance is 0 (:660-665)
+            for (int j = first; j < first + k - 1 && j < k; ++j) {
+                const int32_t v = ki[row + j];
+                if (judge[(size_t)v] || listed[(size_t)v] == level) continue;
+                listed[(size_t)v] = level;
+                nxt.push_back(v); par.push_back(u);
+            }
+        }
+        for (size_t a = 0; a < nxt.size(); ++a) {
+            const double* np_ = normals + 3 * (size_t)par[a];
+            double* ns = normals + 3 * (size_t)nxt[a];
+            double a1 = np_[0] * ns[0] + np_[1] * ns[1] + np_[2] * ns[2];
+            double a2 = -np_[0] * ns[0] - np_[1] * ns[1] - np_[2] * ns[2];
+            a1 = a1 > 1 ? 1 : (a1 < -1 ? -1 : a1);
+            a2 = a2 > 1 ? 1 : (a2 < -1 ? -1 : a2);
+            if (std::acos(a1) > std::acos(a2)) { ns[0] = -ns[0]; ns[1] = -ns[1]; ns[2] = -ns[2]; }   // :716-735
+            judge[(size_t)nxt[a]] = 1;
+        }
+        cur.swap(nxt);
+    }
+    return KSS_OK;
+}
+
 // ---- covariance sums -----------------------------------------------------------------------------
 int kss_cov_dev(kss_ctx* c, const float* d_src, const float* d_tgt, const int32_t* d_idx, int64_t n, int64_t nt,
                 double max_d2, double sums[KSS_NSUMS]) {

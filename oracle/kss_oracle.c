@@ -1149,6 +1149,60 @@ void ko_normals_pcl(const double *P, int64_t n, int k, double *normals) {
     free(pf); free(idx); free(d2);
 }
 
+/* ---- estimateNormal_RegularNormal (normalCompute.hpp:614-742) ---------------------------------------------- */
+void ko_normals_regular(const double *pts, int64_t n, double *normals) {
+    if (n <= 0) return;
+    const int Kn = 8;
+    float *pf = (float *)malloc((size_t)n * 3 * sizeof(float));
+    for (int64_t i = 0; i < 3 * n; i++) pf[i] = (float)pts[i];
+    const int k = n < Kn ? (int)n : Kn;
+    int32_t *ki = (int32_t *)malloc((size_t)n * Kn * sizeof(int32_t));
+    float *kd = (float *)malloc((size_t)n * Kn * sizeof(float));
+    ko_knn_brute(pf, n, pf, n, k, ki, kd);
+    /* neighbour lists: drop the query itself (:660-665) */
+    int32_t *nb = (int32_t *)malloc((size_t)n * (Kn - 1) * sizeof(int32_t));
+    int *nnb = (int *)malloc((size_t)n * sizeof(int));
+    for (int64_t i = 0; i < n; i++) {
+        const int first = kd[(size_t)i * k] == 0 ? 1 : 0;
+        int c = 0;
+        for (int j = first; j < first + k - 1 && j < k; j++) nb[(size_t)i * (Kn - 1) + c++] = ki[(size_t)i * k + j];
+        nnb[i] = c;
+    }
+    char *judge = (char *)calloc((size_t)n, 1);
+    int64_t *level_of = (int64_t *)malloc((size_t)n * sizeof(int64_t));   /* "already listed in this level" stamp = the :694-699 scan */
+    for (int64_t i = 0; i < n; i++) level_of[i] = -1;
+    int32_t *cur = (int32_t *)malloc((size_t)n * sizeof(int32_t)), *nxt = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+    int32_t *par = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+    int64_t ncur = 1, level = 0;
+    cur[0] = 0; judge[0] = 1;
+    while (ncur > 0) {
+        int64_t nn = 0;
+        for (int64_t a = 0; a < ncur; a++) {
+            const int32_t u = cur[a];
+            for (int j = 0; j < nnb[u]; j++) {
+                const int32_t v = nb[(size_t)u * (Kn - 1) + j];
+                if (judge[v] || level_of[v] == level) continue;
+                level_of[v] = level; nxt[nn] = v; par[nn] = u; nn++;
+            }
+        }
+        for (int64_t a = 0; a < nn; a++) {
+            const double *np_ = normals + 3 * (size_t)par[a];
+            double *ns = normals + 3 * (size_t)nxt[a];
+            double a1 = np_[0] * ns[0] + np_[1] * ns[1] + np_[2] * ns[2];
+            double a2 = -np_[0] * ns[0] - np_[1] * ns[1] - np_[2] * ns[2];
+            if (a1 > 1) a1 = 1;
+            if (a1 < -1) a1 = -1;
+            if (a2 > 1) a2 = 1;
+            if (a2 < -1) a2 = -1;
+            if (acos(a1) > acos(a2)) { ns[0] = -ns[0]; ns[1] = -ns[1]; ns[2] = -ns[2]; }
+            judge[nxt[a]] = 1;
+        }
+        int32_t *t = cur; cur = nxt; nxt = t;
+        ncur = nn; level++;
+    }
+    free(pf); free(ki); free(kd); free(nb); free(nnb); free(judge); free(level_of); free(cur); free(nxt); free(par);
+}
+
 /* ---- octree down-sampler (Method_Octree.hpp:77-165 over PCL 1.8.1's OctreePointCloudSearch) ---------------- */
 typedef struct { double min[3], max[3], res; int depth; int defined; } ko_octbox;
 

@@ -190,6 +190,16 @@ void ko_knn_brute(const float *q, int64_t nq, const float *t, int64_t nt, int k,
  *      PCL is absent from the reference tree: parity unpinned.  out: n*3 doubles. */
 void ko_normals_pcl(const double *pts, int64_t n, int k, double *normals);
 
+/* ---- normal orientation: NormalEstimation::estimateNormal_RegularNormal, normalCompute.hpp:614-742 (the second
+ *      half of estimateNormal_PCL_MP, :358-403) ----
+ * Level-synchronous propagation over the 8-NN graph of the float cloud from point 0: the neighbour list of a point
+ * is its K = 8 nearest minus itself (:660-665: entries 1..7 when the nearest distance is 0, else 0..6); a level's
+ * unvisited neighbours are taken in (frontier order, neighbour order), first occurrence wins and names the parent
+ * (:690-707); a normal is negated when acos(n_parent . n) > acos(-(n_parent . n)) with both clamped to [-1, 1]
+ * (:716-735), the parent's normal being its already re-oriented one.  Points the graph does not reach keep their
+ * normals.  kNN ties -> lowest index (FLANN: unspecified): parity unpinned.  normals: n*3 doubles, in place. */
+void ko_normals_regular(const double *pts, int64_t n, double *normals);
+
 /* ---- octree down-sampler: PCL_octree::PCL_Octree_Simplification_WithOutNormal, Method_Octree.hpp:77-104 ----
  * resolution = PCL_Octree_Resolution (:151-165): mean distance from each of the FIRST 1000 points to its kn-th
  * nearest point (the point itself counts as the 1st), kn = 2 below 80000 points, else 7 * (n / 80000) capped at 35

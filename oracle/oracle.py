@@ -89,6 +89,8 @@ def lib():
         L.ko_fps.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.ko_knn_brute.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
         L.ko_normals_pcl.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        L.ko_normals_regular.restype = None
+        L.ko_normals_regular.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         L.ko_octree_downsample.restype = C.c_int64
         L.ko_octree_downsample.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_double)]
         L.ko_aivs.restype = C.c_int64
@@ -322,6 +324,13 @@ def aivs(xyz, point_num):
     if k < 0:
         raise RuntimeError("ko_aivs rc=%d" % k)
     return idx[:k].copy()
+
+
+def normals_regular(pts, normals):
+    """estimateNormal_RegularNormal: re-oriented copy of `normals`."""
+    a = _f64(pts); nrm = _f64(normals).copy()
+    lib().ko_normals_regular(_p(a), len(a), _p(nrm))
+    return nrm
 
 
 def octree_downsample(xyz):

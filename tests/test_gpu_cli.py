@@ -69,6 +69,11 @@ def test_mirror_classes_against_oracle(O, ref_pairs):
     m = min(len(S), len(T)) // 2
     ko = O.kssicp_register(S[O.aivs(S, m)], T[O.aivs(T, m)], S, 6.0, 1000)
     assert abs(reg[0] - ko["scale"]) < 1e-12 and abs(reg[1] - ko["final_fitness"]) < 1e-8 and int(reg[2]) == len(S)
+    nv = _vals(out, "NORMALS")
+    n0 = O.normals_pcl(T, 20)
+    nr = O.normals_regular(T, n0)
+    assert [int(v) for v in nv[:4]] == [len(T), len(T), 1, len(T)]
+    assert np.abs(np.array(nv[4:7]) - n0[0]).max() < 1e-5 and np.abs(np.array(nv[7:10]) - nr[5]).max() < 1e-5
     oc = _vals(out, "OCTREE")
     oi, ores = O.octree_downsample(T)
     assert int(oc[0]) == len(oi) and oc[1] == ores and int(oc[2]) == len(oi) and int(oc[3]) == len(oi) and np.array_equal(oc[4:7], T[oi[0]])
@@ -200,6 +205,24 @@ def test_octree_downsampler_matches_oracle(ctx, O, pkg, ref_pairs):
         assert 0 < len(idx) <= len(P) and idx.min() >= 0 and idx.max() < len(P)
     with pytest.raises(pkg.KssError):
         ctx.downsample_octree(S.bumpy(26, 999))           # the reference reads 1000 points unconditionally
+
+
+def test_normal_orientation_matches_oracle(ctx, O, pkg, ref_pairs):
+    """estimateNormal_RegularNormal: propagation over the 8-NN graph from point 0.  Randomly flipped normals come back
+    consistently oriented and identical to the oracle's restatement (same graph: the device k-NN is bit-exact)."""
+    rng = np.random.default_rng(5)
+    for P in (pkg.synth.bumpy(14, 8000), ref_pairs[("registration", "Horse")][0], pkg.synth.sphere(15, 3)[:3] , pkg.synth.bumpy(16, 5)):
+        P = np.asarray(P, dtype=np.float64)
+        k = min(20, len(P))
+        n0 = O.normals_pcl(P, k) if len(P) >= 3 else np.tile([0.0, 0.0, 1.0], (len(P), 1))
+        flipped = n0 * rng.choice([-1.0, 1.0], size=(len(P), 1))
+        got = ctx.normals_orient(P, flipped)
+        ref = O.normals_regular(P, flipped)
+        assert np.array_equal(got, ref)
+        if len(P) > 100:
+            idx, _ = O.knn_brute(P.astype(np.float32), P.astype(np.float32), 8)
+            assert np.mean((got[:, None, :] * got[idx[:, 1:]]).sum(-1) > 0) > 0.95      # neighbours agree after the pass (sparse clouds keep a few sharp creases)
+            assert np.mean((flipped[:, None, :] * flipped[idx[:, 1:]]).sum(-1) > 0) < 0.6
 
 
 def test_knn_and_normals_match_oracle(ctx, O, pkg, ref_pairs):

@@ -201,3 +201,18 @@ def test_octree_downsample_voxel_bookkeeping(O, pkg):
     assert len(idx2) > 0.5 * len(idx)                                    # a different first point shifts the lattice, not the scale
     with pytest.raises(RuntimeError):
         O.octree_downsample(P[:999])
+
+
+def test_normals_regular_orients_consistently(O, pkg):
+    """estimateNormal_RegularNormal restatement: randomly flipped normals come back agreeing with their neighbours,
+    the seed (point 0) keeps its sign, a second pass changes nothing."""
+    P = pkg.synth.bumpy(33, 4000).astype(np.float64)
+    n0 = O.normals_pcl(P, 20)
+    rng = np.random.default_rng(1)
+    flipped = n0 * rng.choice([-1.0, 1.0], size=(len(P), 1))
+    r = O.normals_regular(P, flipped)
+    assert np.array_equal(r[0], flipped[0])
+    assert np.array_equal(np.abs(r), np.abs(flipped))                     # only signs change
+    idx, _ = O.knn_brute(P.astype(np.float32), P.astype(np.float32), 8)
+    assert np.mean((r[:, None, :] * r[idx[:, 1:]]).sum(-1) > 0) > 0.99
+    assert np.array_equal(O.normals_regular(P, r), r)
