@@ -1056,9 +1056,13 @@ static int knn_generic_dev(kss_ctx* c, const void* d_q, int64_t nq, const void* 
         launch_pack_f3_to_f4(c->stream, (const float*)d_q, nq, (float4*)c->src0.p, nq, false);
         launch_pack_f3_to_f4(c->stream, (const float*)d_t, nt, (float4*)c->tgt4.p, nt_pad, true);
     }
+    size_t part_bytes = 0;
+    const int n_split = knn_plan_splits((int)nq, (int)nt_pad, k, &part_bytes);   // few queries x many targets: split the targets
+    if (part_bytes) KCHK(ensure(c, c->keys, part_bytes));
     {
         ProfScope ps(c, KSS_K_NN_SWEEP);
-        launch_knn_sweep(c->stream, (const float4*)c->src0.p, (int)nq, (const float4*)c->tgt4.p, (int)nt_pad, k, d_idx, d_d2);
+        launch_knn_sweep(c->stream, (const float4*)c->src0.p, (int)nq, (const float4*)c->tgt4.p, (int)nt_pad, k, d_idx, d_d2, n_split,
+                         part_bytes ? c->keys.p : nullptr);
     }
     HIPCHK(c, hipGetLastError());
     return KSS_OK;

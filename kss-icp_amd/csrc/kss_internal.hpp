@@ -192,7 +192,9 @@ void launch_fps(hipStream_t st, const double* d_xyz, int n, int m, double* d_min
 void launch_rot_search(hipStream_t st, const double* d_src, int64_t ns, const float4* d_tgt4, int64_t nt_pad,
                        const double* d_cs /* g*2: cos,sin */, int g, double* d_partials, int n_src_blocks);
 
-void launch_knn_sweep(hipStream_t st, const float4* d_qry, int nq, const float4* d_tgt, int nt_pad, int k, int32_t* d_idx, float* d_d2);
+int knn_plan_splits(int nq, int nt_pad, int k, size_t* scratch_bytes);
+void launch_knn_sweep(hipStream_t st, const float4* d_qry, int nq, const float4* d_tgt, int nt_pad, int k, int32_t* d_idx, float* d_d2,
+                      int n_split, void* d_scratch);
 void launch_normals(hipStream_t st, const float4* d_pts, int n, const int32_t* d_knn, int k, double* d_normals);
 
 int preshape_blocks(int64_t n);

@@ -14,14 +14,21 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "kss_internal.hpp"
 #include "kss_device.hpp"
 
 namespace kss {
 
+// Work item (blockIdx.x, blockIdx.y) = 256 queries x target split blockIdx.y (tiles [y * tiles_per_split, ...)).  With one
+// split the sorted top-K goes straight to idx_out / d2_out [query][k_out]; with several, every split writes its own
+// top-K to part_* [split][query][K] and knn_merge_kernel merges them.  Splits exist because a few queries against a
+// large cloud (the octree resolution: 1000 queries x 10^6 points) would otherwise run on four workgroups.
 template <int K>
 __global__ __launch_bounds__(256) void knn_sweep_kernel(const float4* __restrict__ qry, int nq, const float4* __restrict__ tgt, int nt_pad,
-                                                        int32_t* __restrict__ idx_out, float* __restrict__ d2_out, int k_out) {
+                                                        int tiles_per_split, int32_t* __restrict__ idx_out, float* __restrict__ d2_out, int k_out,
+                                                        int32_t* __restrict__ part_idx, float* __restrict__ part_d2) {
     __shared__ float4 tile[2][NN_TILE];
     const int tid = threadIdx.x;
     const int i = blockIdx.x * 256 + tid;
@@ -32,49 +39,111 @@ __global__ __launch_bounds__(256) void knn_sweep_kernel(const float4* __restrict
     int ki[K];
 #pragma unroll
     for (int c = 0; c < K; ++c) { kd[c] = __builtin_inff(); ki[c] = -1; }
-    const int ntiles = nt_pad / NN_TILE;
-    float4 pre = tgt[tid];
+    const int t_begin = (int)blockIdx.y * tiles_per_split;
+    const int t_end = min(nt_pad / NN_TILE, t_begin + tiles_per_split);
+    float4 pre = tgt[t_begin * NN_TILE + tid];
     int buf = 0;
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = t_begin; t < t_end; ++t) {
         tile[buf][tid] = pre;
         __syncthreads();
-        if (t + 1 < ntiles) pre = tgt[(t + 1) * NN_TILE + tid];
+        if (t + 1 < t_end) pre = tgt[(t + 1) * NN_TILE + tid];
         const float4* __restrict__ tl = tile[buf];
 #pragma unroll 4
         for (int u = 0; u < NN_TILE; ++u) {
             const float4 q = tl[u];
             const float d = dist2<false>(p.x, p.y, p.z, q.x, q.y, q.z);
-            if (d < kd[K - 1]) {   // rare after the first few tiles: the top-K settles quickly
-                kd[K - 1] = d;
-                ki[K - 1] = t * NN_TILE + u;
+            const bool ins = d < kd[K - 1];
+            // A WAVE-UNIFORM branch (ballot): the insertion below is all selects, and left to itself the compiler
+            // if-converts it into ~8 K instructions executed for EVERY target (K = 32: 20x the cost of the sweep).
+            // After the first few tiles almost no target enters anyone's top-K and the branch is not taken.
+            if (__builtin_amdgcn_ballot_w64(ins) != 0ull) {
+                // shift-insert into the ascending list: entries larger than d move up one slot, d lands behind the
+                // last entry <= d (strict '<': an equal distance stays behind the earlier index).  Every new slot
+                // value depends on two FIXED registers only (descending c reads kd[c - 1] before it changes).
+                const int id = t * NN_TILE + u;
 #pragma unroll
                 for (int c = K - 1; c > 0; --c) {
-                    const bool sw = kd[c] < kd[c - 1];   // strict: an equal distance stays behind the earlier index
-                    const float fd = sw ? kd[c - 1] : kd[c], bdv = sw ? kd[c] : kd[c - 1];
-                    const int fi = sw ? ki[c - 1] : ki[c], bi = sw ? ki[c] : ki[c - 1];
-                    kd[c] = fd; ki[c] = fi; kd[c - 1] = bdv; ki[c - 1] = bi;
+                    const bool shift = ins && d < kd[c - 1];
+                    const bool place = ins && !shift && d < kd[c];
+                    kd[c] = shift ? kd[c - 1] : (place ? d : kd[c]);
+                    ki[c] = shift ? ki[c - 1] : (place ? id : ki[c]);
                 }
+                const bool front = ins && d < kd[0];
+                kd[0] = front ? d : kd[0];
+                ki[0] = front ? id : ki[0];
             }
         }
         buf ^= 1;
     }
-    if (valid) {
+    if (!valid) return;
+    if (gridDim.y == 1) {
 #pragma unroll
         for (int c = 0; c < K; ++c)
             if (c < k_out) {
                 idx_out[(int64_t)i * k_out + c] = ki[c];
                 d2_out[(int64_t)i * k_out + c] = kd[c];
             }
+    } else {
+        const int64_t base = ((int64_t)blockIdx.y * nq + i) * K;
+#pragma unroll
+        for (int c = 0; c < K; ++c) { part_idx[base + c] = ki[c]; part_d2[base + c] = kd[c]; }
     }
 }
 
-void launch_knn_sweep(hipStream_t st, const float4* d_qry, int nq, const float4* d_tgt, int nt_pad, int k, int32_t* d_idx, float* d_d2) {
-    const dim3 grid((nq + 255) / 256), block(256);
-    if (k <= 4) hipLaunchKernelGGL(knn_sweep_kernel<4>, grid, block, 0, st, d_qry, nq, d_tgt, nt_pad, d_idx, d_d2, k);
-    else if (k <= 8) hipLaunchKernelGGL(knn_sweep_kernel<8>, grid, block, 0, st, d_qry, nq, d_tgt, nt_pad, d_idx, d_d2, k);
-    else if (k <= 16) hipLaunchKernelGGL(knn_sweep_kernel<16>, grid, block, 0, st, d_qry, nq, d_tgt, nt_pad, d_idx, d_d2, k);
-    else if (k <= 32) hipLaunchKernelGGL(knn_sweep_kernel<32>, grid, block, 0, st, d_qry, nq, d_tgt, nt_pad, d_idx, d_d2, k);
-    else hipLaunchKernelGGL(knn_sweep_kernel<64>, grid, block, 0, st, d_qry, nq, d_tgt, nt_pad, d_idx, d_d2, k);   // k <= 64 (octree resolution: kn = 35)
+// merge of the per-split top-K lists of one query: each list is ascending in (d2, index) and the splits are ascending
+// index ranges, so taking the lexicographically smallest head k_out times reproduces the single-sweep order exactly.
+// One thread per query; the heads' cursors live in LDS (n_split <= KNN_MAX_SPLIT bytes per thread).
+constexpr int KNN_MAX_SPLIT = 64;
+__global__ __launch_bounds__(64) void knn_merge_kernel(const int32_t* __restrict__ part_idx, const float* __restrict__ part_d2, int nq, int K,
+                                                       int n_split, int32_t* __restrict__ idx_out, float* __restrict__ d2_out, int k_out) {
+    __shared__ unsigned char cursor[KNN_MAX_SPLIT][64];
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= nq) return;
+    for (int s = 0; s < n_split; ++s) cursor[s][threadIdx.x] = 0;
+    for (int c = 0; c < k_out; ++c) {
+        float bd = __builtin_inff();
+        int bi = -1, bs = -1;
+        for (int s = 0; s < n_split; ++s) {
+            const int cu = cursor[s][threadIdx.x];
+            if (cu >= K) continue;
+            const int64_t at = ((int64_t)s * nq + i) * K + cu;
+            const float d = part_d2[at];
+            const int id = part_idx[at];
+            if (id < 0) continue;                                   // list exhausted (fewer than K targets in the split)
+            if (bs < 0 || d < bd || (d == bd && id < bi)) { bd = d; bi = id; bs = s; }
+        }
+        idx_out[(int64_t)i * k_out + c] = bi;
+        d2_out[(int64_t)i * k_out + c] = bs >= 0 ? bd : __builtin_inff();
+        if (bs >= 0) cursor[bs][threadIdx.x] = (unsigned char)(cursor[bs][threadIdx.x] + 1);
+    }
+}
+
+// n_split and the scratch the caller must provide for it (0 bytes: single sweep)
+int knn_plan_splits(int nq, int nt_pad, int k, size_t* scratch_bytes) {
+    const int blocks = (nq + 255) / 256, tiles = nt_pad / NN_TILE;
+    int n_split = 1;
+    if (blocks < 256 && tiles >= 8) n_split = std::min(std::min(KNN_MAX_SPLIT, (1024 + blocks - 1) / blocks), tiles / 4);
+    if (n_split < 1) n_split = 1;
+    const int K = k <= 4 ? 4 : k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : 64;
+    *scratch_bytes = n_split > 1 ? (size_t)n_split * nq * K * (sizeof(int32_t) + sizeof(float)) : 0;
+    return n_split;
+}
+
+void launch_knn_sweep(hipStream_t st, const float4* d_qry, int nq, const float4* d_tgt, int nt_pad, int k, int32_t* d_idx, float* d_d2,
+                      int n_split, void* d_scratch) {
+    const int tiles = nt_pad / NN_TILE;
+    const int tps = (tiles + n_split - 1) / n_split;
+    const int planned = n_split;
+    n_split = (tiles + tps - 1) / tps;                                  // no empty trailing split
+    const dim3 grid((nq + 255) / 256, n_split), block(256);
+    const int K = k <= 4 ? 4 : k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : 64;
+    int32_t* p_idx = (int32_t*)d_scratch;
+    float* p_d2 = planned > 1 ? (float*)((char*)d_scratch + (size_t)planned * nq * K * sizeof(int32_t)) : nullptr;
+#define KSS_KNN_LAUNCH(KV) hipLaunchKernelGGL(knn_sweep_kernel<KV>, grid, block, 0, st, d_qry, nq, d_tgt, nt_pad, tps, d_idx, d_d2, k, p_idx, p_d2)
+    if (K == 4) KSS_KNN_LAUNCH(4); else if (K == 8) KSS_KNN_LAUNCH(8); else if (K == 16) KSS_KNN_LAUNCH(16); else if (K == 32) KSS_KNN_LAUNCH(32); else KSS_KNN_LAUNCH(64);
+#undef KSS_KNN_LAUNCH
+    if (n_split > 1)   // (gridDim.y == 1 wrote the final lists itself)
+        hipLaunchKernelGGL(knn_merge_kernel, dim3((nq + 63) / 64), dim3(64), 0, st, p_idx, p_d2, nq, K, n_split, d_idx, d_d2, k);
 }
 
 // ---- pcl::eigen33 smallest eigenpair, float, closed form (common/eigen.hpp) -----------------------------------------

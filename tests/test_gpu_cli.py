@@ -236,6 +236,12 @@ def test_knn_and_normals_match_oracle(ctx, O, pkg, ref_pairs):
         idx, d2 = ctx.knn(q, t, k)
         oi, od = O.knn_brute(q, t, k)
         assert np.array_equal(idx, oi) and np.array_equal(d2.view(np.uint32), od.view(np.uint32))
+    big = rng.normal(size=(70000, 3)).astype(np.float32)
+    big[40000] = big[12]; big[69999] = big[12]         # ties across target splits keep the lower index first
+    for k in (2, 7, 35):                               # few queries x many targets: the split + merge path
+        idx, d2 = ctx.knn(big[:300], big, k)
+        oi, od = O.knn_brute(big[:300], big, k)
+        assert np.array_equal(idx, oi) and np.array_equal(d2.view(np.uint32), od.view(np.uint32))
     idx, d2 = ctx.knn(q[:5], t[:4], 6)                 # fewer targets than k: -1 / +inf tail
     oi, od = O.knn_brute(q[:5], t[:4], 6)
     assert np.array_equal(idx, oi) and np.array_equal(d2, od) and (idx[:, 4:] == -1).all()
