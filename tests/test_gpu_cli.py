@@ -205,6 +205,13 @@ def test_octree_downsampler_matches_oracle(ctx, O, pkg, ref_pairs):
         assert 0 < len(idx) <= len(P) and idx.min() >= 0 and idx.max() < len(P)
     with pytest.raises(pkg.KssError):
         ctx.downsample_octree(S.bumpy(26, 999))           # the reference reads 1000 points unconditionally
+    with pytest.raises(pkg.KssError):
+        ctx.downsample_octree(np.ones((1500, 3)))          # coincident points: zero resolution (PCL asserts)
+    with pytest.raises(RuntimeError):
+        O.octree_downsample(np.ones((1500, 3)))
+    dup = np.concatenate([S.bumpy(27, 1200)] * 2)        # every point twice: kn = 2 finds the twin at distance 0 for all
+    with pytest.raises(pkg.KssError):
+        ctx.downsample_octree(dup)
 
 
 def test_normal_orientation_matches_oracle(ctx, O, pkg, ref_pairs):
