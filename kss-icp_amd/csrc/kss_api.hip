@@ -343,7 +343,14 @@ int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npairs, boo
     pl.npairs = npairs;
     pl.shared_target = shared_target;
     if (nn_mode == KSS_NN_AUTO) nn_mode = c->nn_mode;
-    pl.grid = nn_mode == KSS_NN_GRID || (nn_mode == KSS_NN_AUTO && npairs == 1 && nt[0] >= 4096 && ns[0] >= 1024);
+    // AUTO: the fused cell-list pass (one launch + a spin per iteration) beats sweep + reduce + finalize (three launches)
+    // down to a few hundred points (1.4k x 1.4k: 22 vs 36 us per iteration); below that the build (~0.1 ms) is not paid
+    // back.  KSS_GRID_MIN_* : tuning hooks.  Batches keep the brute-force engine unless they are large: the batched
+    // cell-list kernel has no brute-force fallback, and badly posed pairs (the candidate batch of kss_register) walk
+    // many shells there (measured 14.8 vs 5.8 ms).
+    static const int64_t min_nt = [] { const char* e = getenv("KSS_GRID_MIN_NT"); return e ? (int64_t)atoll(e) : (int64_t)512; }();
+    static const int64_t min_ns = [] { const char* e = getenv("KSS_GRID_MIN_NS"); return e ? (int64_t)atoll(e) : (int64_t)512; }();
+    pl.grid = nn_mode == KSS_NN_GRID || (nn_mode == KSS_NN_AUTO && npairs == 1 && nt[0] >= min_nt && ns[0] >= min_ns);
     if (npairs != 1) pl.grid = false;
     if (npairs > 1 && !shared_target) {   // batch: one cell list per pair when the pairs are big enough to pay for it
         int64_t min_nt = nt[0], tot_ns = 0;
