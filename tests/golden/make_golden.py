@@ -46,3 +46,17 @@ idx, d2 = O.nn_brute(s4, t4)
 out["g4_nn_idx"], out["g4_nn_d2"] = idx, d2
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "oracle_vectors.npz"), **out)
 print("wrote oracle_vectors.npz", {k: v.shape for k, v in out.items()})
+
+# second file (SURVEY 8c G5 + the section 8f tools): the tools around the path, on the G4 target cloud
+f = {}
+t64 = t4.astype(np.float64)
+f["g5_aivs_700"] = O.aivs(t64, 700)                                   # AIVS selection, output order
+oi, ores = O.octree_downsample(t64)
+f["g6_octree_idx"], f["g6_octree_res"] = oi, np.array([ores])
+ki, kd = O.knn_brute(t4[:64], t4, 13)
+f["g7_knn13_idx"], f["g7_knn13_d2"] = ki, kd
+n0 = O.normals_pcl(t64, 20)
+flips = np.where((np.arange(len(t64)) * 2654435761 % 7) < 3, -1.0, 1.0)[:, None]      # deterministic sign pattern
+f["g8_normals"], f["g8_oriented"] = n0, O.normals_regular(t64, n0 * flips)
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "oracle_vectors_tools.npz"), **f)
+print("wrote oracle_vectors_tools.npz", {k: v.shape for k, v in f.items()})

@@ -214,6 +214,23 @@ def test_octree_downsampler_matches_oracle(ctx, O, pkg, ref_pairs):
         ctx.downsample_octree(dup)
 
 
+def test_tools_against_committed_golden_vectors(ctx):
+    """The section-8f tools against tests/golden/oracle_vectors_tools.npz (no oracle in the loop): AIVS selection, octree
+    selection + resolution, k-NN and normal orientation exact, normals to float round-off."""
+    g = np.load(os.path.join(GOLDEN, "oracle_vectors.npz"))
+    f = np.load(os.path.join(GOLDEN, "oracle_vectors_tools.npz"))
+    t4 = g["g4_tgt"]; t64 = t4.astype(np.float64)
+    assert np.array_equal(ctx.downsample_aivs(t64, 700)[1], f["g5_aivs_700"])
+    oi, ores = ctx.downsample_octree(t64)
+    assert np.array_equal(oi, f["g6_octree_idx"]) and ores == f["g6_octree_res"][0]
+    ki, kd = ctx.knn(t4[:64], t4, 13)
+    assert np.array_equal(ki, f["g7_knn13_idx"]) and np.array_equal(kd.view(np.uint32), f["g7_knn13_d2"].view(np.uint32))
+    n0 = ctx.normals(t64, 20)
+    assert np.median(np.abs(n0 - f["g8_normals"]).max(axis=1)) < 1e-6
+    flips = np.where((np.arange(len(t64)) * 2654435761 % 7) < 3, -1.0, 1.0)[:, None]
+    assert np.array_equal(ctx.normals_orient(t64, f["g8_normals"] * flips), f["g8_oriented"])
+
+
 def test_normal_orientation_matches_oracle(ctx, O, pkg, ref_pairs):
     """estimateNormal_RegularNormal: propagation over the 8-NN graph from point 0.  Randomly flipped normals come back
     consistently oriented and identical to the oracle's restatement (same graph: the device k-NN is bit-exact)."""

@@ -216,3 +216,20 @@ def test_normals_regular_orients_consistently(O, pkg):
     idx, _ = O.knn_brute(P.astype(np.float32), P.astype(np.float32), 8)
     assert np.mean((r[:, None, :] * r[idx[:, 1:]]).sum(-1) > 0) > 0.99
     assert np.array_equal(O.normals_regular(P, r), r)
+
+
+def test_golden_tool_vectors_reproduce(O):
+    """tests/golden/oracle_vectors_tools.npz (make_golden.py): AIVS, octree, k-NN and normal orientation of the oracle
+    are pinned against drift on the G4 target cloud."""
+    g = np.load(os.path.join(GOLDEN, "oracle_vectors.npz"))
+    f = np.load(os.path.join(GOLDEN, "oracle_vectors_tools.npz"))
+    t4 = g["g4_tgt"]; t64 = t4.astype(np.float64)
+    assert np.array_equal(O.aivs(t64, 700), f["g5_aivs_700"])
+    oi, ores = O.octree_downsample(t64)
+    assert np.array_equal(oi, f["g6_octree_idx"]) and ores == f["g6_octree_res"][0]
+    ki, kd = O.knn_brute(t4[:64], t4, 13)
+    assert np.array_equal(ki, f["g7_knn13_idx"]) and np.array_equal(kd, f["g7_knn13_d2"])
+    n0 = O.normals_pcl(t64, 20)
+    assert np.array_equal(n0, f["g8_normals"])
+    flips = np.where((np.arange(len(t64)) * 2654435761 % 7) < 3, -1.0, 1.0)[:, None]
+    assert np.array_equal(O.normals_regular(t64, n0 * flips), f["g8_oriented"])
