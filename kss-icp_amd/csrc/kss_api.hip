@@ -429,6 +429,14 @@ int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npairs, boo
         // it wants many workgroups; the 240-lane final reduction handles hundreds of rows in a few microseconds)
         int64_t R = (g.ns + 256 * 512 - 1) / (256 * 512);   // <= ~512 partial rows per pair
         R = std::max<int64_t>(1, std::min<int64_t>(R, 64));
+        if (pl.gridb) {
+            // fused batched pass: a workgroup's 20-value block reduction costs about as much as searching 256 queries,
+            // so every workgroup takes up to 8 rounds of 256 queries (sums stay in registers) as long as the batch
+            // still yields ~2000 workgroups (C3: 27.8 -> 19.1 ms).  KSS_GRIDB_ROUNDS: tuning hook.
+            static const int64_t forced = [] { const char* e = getenv("KSS_GRIDB_ROUNDS"); const int64_t v = e ? atoll(e) : 0; return v >= 1 && v <= 64 ? v : 0; }();
+            const int64_t rounds = forced ? forced : std::max<int64_t>(1, std::min<int64_t>(8, tot / (256 * 2048)));
+            R = std::max<int64_t>(R, std::min<int64_t>(rounds, (g.ns + 255) / 256));
+        }
         const int64_t rchunk = 256 * R;
         const int nrb = (int)((g.ns + rchunk - 1) / rchunk);
         for (int b = 0; b < nrb; ++b) {
