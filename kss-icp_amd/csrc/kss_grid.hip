@@ -12,8 +12,14 @@
 //             distance b(r) from the query to the faces of the visited block; the search stops when
 //             best_d2 < (b(r) - eps)^2 * (1 - 1e-6), a bound that is conservative w.r.t. the f32 rounding
 //             of both the cell assignment and the distance, so it can only search MORE than needed.
-//   fallback: a query not resolved within GRID_RCAP shells is appended to a list and resolved by the
-//             brute-force sweep (nn_sweep_kernel<LIST>) -- far-away clouds never degrade below it.
+//   warm start: inside an ICP every source remembers where its previous winner sits; that point is evaluated
+//             first and its distance prunes the cells of the first block that cannot hold the winner nor a tie
+//             (block_walk); the result does not depend on it.
+//   fallback: a query not resolved within GridParams::rcap shells is appended to a list and resolved by the
+//             brute-force sweep (nn_sweep_kernel<LIST>) -- far-away clouds never degrade below it.  (The batched
+//             kernel has no fallback: it keeps adding shells.)
+//   fusion  : the correspondence sums are accumulated by the searching lanes (the winner's coordinates are still in
+//             registers) and reduced in the same launch; see grid_nn_kernel / gridb_nn_kernel.
 #pragma clang fp contract(off)
 
 #include <hip/hip_runtime.h>
