@@ -345,9 +345,9 @@ int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npairs, boo
     if (nn_mode == KSS_NN_AUTO) nn_mode = c->nn_mode;
     // AUTO: the fused cell-list pass (one launch + a spin per iteration) beats sweep + reduce + finalize (three launches)
     // down to a few hundred points (1.4k x 1.4k: 22 vs 36 us per iteration); below that the build (~0.1 ms) is not paid
-    // back.  KSS_GRID_MIN_* : tuning hooks.  Batches keep the brute-force engine unless they are large: the batched
-    // cell-list kernel has no brute-force fallback, and badly posed pairs (the candidate batch of kss_register) walk
-    // many shells there (measured 14.8 vs 5.8 ms).
+    // back.  KSS_GRID_MIN_* : tuning hooks.  Batches keep the brute-force engine unless they are large: on badly posed
+    // pairs (the candidate batch of kss_register) the batched cell-list kernel ends in its in-wave brute-force fallback,
+    // which is slower than the tiled sweep.
     static const int64_t min_nt = [] { const char* e = getenv("KSS_GRID_MIN_NT"); return e ? (int64_t)atoll(e) : (int64_t)512; }();
     static const int64_t min_ns = [] { const char* e = getenv("KSS_GRID_MIN_NS"); return e ? (int64_t)atoll(e) : (int64_t)512; }();
     pl.grid = nn_mode == KSS_NN_GRID || (nn_mode == KSS_NN_AUTO && npairs == 1 && nt[0] >= min_nt && ns[0] >= min_ns);
@@ -618,6 +618,7 @@ int grid_setup_batch(kss_ctx* c, IcpPlan& pl) {
         std::memset(&hp[p], 0, sizeof(GridPairDev));
         hp[p].tgt_base = pl.g[p].tgt_base; hp[p].tgt_n = (int32_t)pl.g[p].nt;
         hp[p].src_base = pl.g[p].src_base; hp[p].src_n = (int32_t)pl.g[p].ns;
+        hp[p].tgt_pad = pl.g[p].tgt_pad;
         sum_nt += pl.g[p].nt;
     }
     ProfScope ps(c, KSS_K_GRID_BUILD);
@@ -774,7 +775,7 @@ int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, float4*
             ProfScope ps(c, KSS_K_GRID_NN);
             launch_gridb_nn(c->stream, fma, (const RedWork*)c->red_work.p, (int)pl.red.size(), (const PairState*)c->state.p,
                             (const GridPairDev*)c->g_pairs.p, d_in, d_out, (const int32_t*)c->g_start.p, (const float4*)c->g_sorted.p,
-                            getenv("KSS_GRID_NOPREV") ? nullptr : (int32_t*)c->g_pos.p, max_d2, (double*)c->partials.p, d_idx_out, d_d2_out);
+                            (const float4*)c->tgt4.p, getenv("KSS_GRID_NOPREV") ? nullptr : (int32_t*)c->g_pos.p, max_d2, (double*)c->partials.p, d_idx_out, d_d2_out);
         }
         const bool spin = pl.npairs <= PUB_PAIRS;
         {

@@ -17,7 +17,7 @@
 //             (block_walk); the result does not depend on it.
 //   fallback: a query not resolved within GridParams::rcap shells is appended to a list and resolved by the
 //             brute-force sweep (nn_sweep_kernel<LIST>) -- far-away clouds never degrade below it.  (The batched
-//             kernel has no fallback: it keeps adding shells.)
+//             kernel sweeps the pair's targets inside the wave instead: gridb_nn_kernel.)
 //   fusion  : the correspondence sums are accumulated by the searching lanes (the winner's coordinates are still in
 //             registers) and reduced in the same launch; see grid_nn_kernel / gridb_nn_kernel.
 #pragma clang fp contract(off)
@@ -661,16 +661,21 @@ void launch_gridb_sort_sources(hipStream_t st, const float4* d_src, int total_sr
     hipLaunchKernelGGL(gridb_rank_fix_kernel, grid, block, 0, st, d_tmp, total_src, d_pairs, npairs, d_start, d_out);
 }
 
-// query + correspondence sums: one workgroup per RedWork item (<= 256 consecutive sorted sources of ONE pair per
+// query + correspondence sums: one workgroup per RedWork item (consecutive sorted sources of ONE pair, 256 per
 // round), one lane per source.  Writes the transformed source, the previous-winner position and one partial row of
 // the 20 sums (the matched target's coordinates are still in registers: no gather pass); finalize_sums_kernel then
 // adds each pair's rows in row order.
+// Fallback: a lane still unresolved after GridParams::rcap shells (a source far from its target: badly posed pairs)
+// stops adding shells; its WAVE then sweeps the pair's whole target, brute force, for exactly those lanes (every lane
+// reads the same target: uniform addresses, scalar-cache loads, no LDS and no barrier, so the common path stays
+// barrier free).  A pass therefore never costs more than the shells plus one brute-force sweep of the pair -- without
+// it the shell loop is cubic in the distance.
 template <bool FMA>
 __global__ __launch_bounds__(256) void gridb_nn_kernel(const RedWork* __restrict__ work, const PairState* __restrict__ state,
                                                        const GridPairDev* __restrict__ pairs, const float4* __restrict__ src_in,
                                                        float4* __restrict__ src_out, const int32_t* __restrict__ cell_start,
-                                                       const float4* __restrict__ sorted, int32_t* __restrict__ pos_prev,
-                                                       double max_d2, double* __restrict__ partials,
+                                                       const float4* __restrict__ sorted, const float4* __restrict__ tgt4,
+                                                       int32_t* __restrict__ pos_prev, double max_d2, double* __restrict__ partials,
                                                        int32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
     __shared__ int2 rowq[9][256];   // block_walk's per-lane range queue
     __shared__ double sh[4][NSUMS];
@@ -679,11 +684,10 @@ __global__ __launch_bounds__(256) void gridb_nn_kernel(const RedWork* __restrict
     double acc[NSUMS];
 #pragma unroll
     for (int c = 0; c < NSUMS; ++c) acc[c] = 0.0;
-    if (ps.active) {
+    if (ps.active) {   // uniform: one pair per workgroup
         const GridPairDev pr = pairs[w.pair];
         const GridParams& gp = pr.gp;
         const int32_t* __restrict__ cs = cell_start + pr.cell_base;
-        const int rmax = max(gp.gx, max(gp.gy, gp.gz));
         for (int t = threadIdx.x; t < w.src_count; t += 256) {
             const int i = w.src_begin + t;
             float4 p = src_in[i];
@@ -698,9 +702,10 @@ __global__ __launch_bounds__(256) void gridb_nn_kernel(const RedWork* __restrict
             const int cx = cell_coord(qx, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(qy, gp.oy, gp.inv_h, gp.gy),
                       cz = cell_coord(qz, gp.oz, gp.inv_h, gp.gz);
             unsigned long long key = ~0ull;
-            int kpos = 0;
+            int kpos = -1;
             float4 win = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int r = 1; r <= rmax; ++r) {
+            bool done = false;
+            for (int r = 1; r <= gp.rcap && !done; ++r) {
                 const int wd = 2 * r + 1;
                 const int x0 = max(cx - r, 0), x1 = min(cx + r, gp.gx - 1);
                 if (r == 1) {
@@ -728,8 +733,21 @@ __global__ __launch_bounds__(256) void gridb_nn_kernel(const RedWork* __restrict
                 if (cz - r > 0) b = fminf(b, qz - (gp.oz + (float)(cz - r) * gp.h));
                 if (cz + r < gp.gz - 1) b = fminf(b, (gp.oz + (float)(cz + r + 1) * gp.h) - qz);
                 const float bs = b - gp.eps;
-                if (b == __builtin_inff()) break;                              // the pair's whole grid has been visited
-                if (bs > 0.f && best < bs * bs * 0.999999f) break;             // every unvisited point is strictly farther
+                if (b == __builtin_inff()) done = key != ~0ull;                  // the pair's whole grid has been visited
+                else if (bs > 0.f && best < bs * bs * 0.999999f) done = true;    // every unvisited point is strictly farther
+            }
+            // ---- bounded fallback: brute force over the pair's targets for the lanes the shells did not resolve ----
+            if (__builtin_amdgcn_ballot_w64(!done) != 0ull) {             // wave-uniform
+                const float4* __restrict__ tp = tgt4 + pr.tgt_base;      // original order; uniform addresses below
+                for (int j = 0; j < pr.tgt_n; ++j) {
+                    const float4 q = tp[j];
+                    const float dx = qx - q.x, dy = qy - q.y, dz = qz - q.z;
+                    float d;
+                    if constexpr (FMA) d = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+                    else d = (dx * dx + dy * dy) + dz * dz;
+                    const unsigned long long kk = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(unsigned)j;
+                    if (!done && kk < key) { key = kk; win = q; kpos = -1; }   // (no position in `sorted` known: no warm start next time)
+                }
             }
             if (key != ~0ull) {   // (an empty target cannot happen: the plan rejects it)
                 const float d2 = __uint_as_float((unsigned)(key >> 32));
@@ -747,16 +765,16 @@ __global__ __launch_bounds__(256) void gridb_nn_kernel(const RedWork* __restrict
 
 void launch_gridb_nn(hipStream_t st, bool fma, const RedWork* d_work, int n_work, const PairState* d_state,
                      const GridPairDev* d_pairs, const float4* d_src_in, float4* d_src_out, const int32_t* d_cell_start,
-                     const float4* d_sorted, int32_t* d_pos, double max_d2, double* d_partials, int32_t* d_idx_out,
-                     float* d_d2_out) {
+                     const float4* d_sorted, const float4* d_tgt4, int32_t* d_pos, double max_d2, double* d_partials,
+                     int32_t* d_idx_out, float* d_d2_out) {
     if (n_work <= 0) return;
     const dim3 grid(n_work), block(256);
     if (fma)
         hipLaunchKernelGGL(gridb_nn_kernel<true>, grid, block, 0, st, d_work, d_state, d_pairs, d_src_in, d_src_out, d_cell_start,
-                           d_sorted, d_pos, max_d2, d_partials, d_idx_out, d_d2_out);
+                           d_sorted, d_tgt4, d_pos, max_d2, d_partials, d_idx_out, d_d2_out);
     else
         hipLaunchKernelGGL(gridb_nn_kernel<false>, grid, block, 0, st, d_work, d_state, d_pairs, d_src_in, d_src_out, d_cell_start,
-                           d_sorted, d_pos, max_d2, d_partials, d_idx_out, d_d2_out);
+                           d_sorted, d_tgt4, d_pos, max_d2, d_partials, d_idx_out, d_d2_out);
 }
 
 // statistics for the roofline statement: evaluations of one r = 1 pass and occupied cells (profiling only)

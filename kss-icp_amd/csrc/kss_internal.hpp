@@ -70,7 +70,7 @@ struct alignas(16) GridPairDev {
     int32_t cell_base;          // first cell of this pair in the global cell arrays
     int32_t tgt_base, tgt_n;    // target segment in tgt4 (padded layout) and its real point count
     int32_t src_base, src_n;    // source segment
-    int32_t pad;
+    int32_t tgt_pad;            // slots of the target segment in tgt4 (multiple of NN_TILE, +inf sentinels behind tgt_n)
 };
 
 // one pair's target segment for the batched pack kernel
@@ -154,8 +154,8 @@ void launch_gridb_sort_sources(hipStream_t st, const float4* d_src, int total_sr
                                float4* d_tmp, float4* d_out);
 void launch_gridb_nn(hipStream_t st, bool fma, const RedWork* d_work, int n_work, const PairState* d_state,
                      const GridPairDev* d_pairs, const float4* d_src_in, float4* d_src_out, const int32_t* d_cell_start,
-                     const float4* d_sorted, int32_t* d_pos, double max_d2, double* d_partials, int32_t* d_idx_out,
-                     float* d_d2_out);
+                     const float4* d_sorted, const float4* d_tgt4, int32_t* d_pos, double max_d2, double* d_partials,
+                     int32_t* d_idx_out, float* d_d2_out);
 void launch_grid_stats(hipStream_t st, const float4* d_src, int ns, const GridParams& gp, const int32_t* d_cell_start,
                        unsigned long long* d_out /* [0] evaluations of the 3x3x3 block, [1] occupied cells */);
 void launch_grid_sort_sources(hipStream_t st, const float4* d_src, int n, const GridParams& gp, int32_t* d_counts,
