@@ -95,7 +95,8 @@ def read_traffic(key):
         return None
 
 
-def run_steps(step, n_steps, dist, world, torch):
+def run_steps(step, n_steps, dist, world, torch, finish=None):
+    """K steps between barrier + synchronize brackets; `finish` (the batch's one result gather) runs INSIDE the bracket."""
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -103,6 +104,8 @@ def run_steps(step, n_steps, dist, world, torch):
     last = None
     for _ in range(n_steps):
         last = step()
+    if finish is not None:
+        finish()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -161,25 +164,34 @@ def main():
             keepalive.append(link)
         else:
             params = ctx.icp_params(**kw)
-        RecArr = pkg.IcpResult * 1
+        done = []
 
         def step():
             res = ctx.icp_dev(d_src.data_ptr(), n_src, d_tgt.data_ptr(), a.n, params)
-            if split:
-                return res   # every rank already holds the same record
-            if world > 1 or force_dist:   # final gather of the (R,t) records over RCCL/xGMI: one 96-B record per pair
-                local = pkg.shard.records_to_array(RecArr(res), rank)
-                pkg.shard.gather_records(local, world, world, rank, device=dev)
+            done.append(res)
             return res
-        return step
+
+        def finish():
+            # The K registrations of the timed region are this rank's shard of a K x N-pair batch: ONE all-gather of the
+            # 96-byte (R, t) records over RCCL/xGMI at the end of the batch (one collective per batch, never
+            # per pair), inside the timed bracket.  (split: every rank already holds the same record.)
+            if split or not (world > 1 or force_dist) or not done:
+                done.clear()
+                return
+            recs = (pkg.IcpResult * len(done))(*done)
+            local = pkg.shard.records_to_array(recs, rank * len(done))
+            pkg.shard.gather_records(local, world * len(done), world, rank, device=dev)
+            done.clear()
+        return step, finish
 
     # ---- primary measurement ---------------------------------------------------------------------------
-    step = make_step(a.mode)
+    step, finish = make_step(a.mode)
     for _ in range(a.warmup):
         step()
+    finish()
     ctx.profile_enable(a.prof_stride)   # HIP events around every n-th launch of the timed region
     ctx.profile_reset()
-    dt, last = run_steps(step, a.steps, dist, world, torch)
+    dt, last = run_steps(step, a.steps, dist, world, torch, finish)
     prof = {k: ctx.profile_get(getattr(pkg, k)) for k in ("K_NN_SWEEP", "K_CORR_REDUCE", "K_GRID_NN", "K_GRID_BUILD")}
     gstats = ctx.grid_stats()
     ctx.profile_enable(False)
@@ -201,6 +213,7 @@ def main():
             lib.kss_debug_grid_evals(ctx.h, buf)
             step()
             lib.kss_debug_grid_evals(ctx.h, buf)
+            finish() if world == 1 and not force_dist else None   # (drops the record; never a collective here)
         finally:
             del os.environ["KSS_GRID_STAMPS"]
         if buf[1] > 0:
@@ -209,11 +222,12 @@ def main():
     # ---- secondary: the brute-force sweep (north-star kernel), single-GPU runs only ------------------------
     brute = None
     if world == 1 and a.brute_steps > 0 and used_grid:
-        bstep = make_step("brute")
+        bstep, bfinish = make_step("brute")
         bstep()
+        bfinish()
         ctx.profile_enable(True)
         ctx.profile_reset()
-        bdt, blast = run_steps(bstep, a.brute_steps, dist, world, torch)
+        bdt, blast = run_steps(bstep, a.brute_steps, dist, world, torch, bfinish)
         bms, bn = ctx.profile_get(pkg.K_NN_SWEEP)
         ctx.profile_enable(False)
         brute = (bdt, bms, bn, blast)
@@ -242,7 +256,8 @@ def main():
                                    "(exact NN + cov reduce + host 3x3 SVD), R_z(10deg), jitter 1e-3" % (a.n, a.n, a.iters),
                        "n_src": a.n, "n_tgt": a.n, "icp_iters_per_step": a.iters, "pairs_per_gpu": 1,
                        "parallelism": ("source rows of one pair split over %d ranks, ncclAllReduce of 20 f64 per iteration" % world) if split
-                                      else "one independent pair per rank, no data-path collective",
+                                      else "independent pairs sharded over ranks (%d registrations per rank in the timed region), no data-path "
+                                           "collective, one all-gather of the 96-byte records per batch" % a.steps,
                        "nn_engine": "cell list + brute-force fallback" if used_grid else "brute-force sweep",
                        "nn_arithmetic": "fma" if a.fma else "reference (no fma)"},
             "correspondences_per_sec": float(a.n) * passes * a.steps * (1 if split else world) / dt,
