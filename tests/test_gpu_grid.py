@@ -163,3 +163,21 @@ def test_grid_batch_matches_brute_batch_and_oracle(ctx, O, pkg):
     b2 = ctx.icp_batch(src_all, so, tgt_all, to, ctx.icp_params(nn_mode=pkg.NN_BRUTE, max_iterations=4, fixed_iterations=1))
     for i in range(len(pairs)):
         assert np.abs(g2[i].matrix() - b2[i].matrix()).max() < 1e-6 and abs(g2[i].last_mse - b2[i].last_mse) < 1e-12
+
+
+def test_non_finite_coordinates_are_contained(ctx, pkg):
+    """Non-finite input must not hang or fault the search: a target with an infinite coordinate is rejected by the
+    cell-list build, a NaN source point matches nothing (it is dropped from the sums) and the rest registers normally."""
+    S = pkg.synth
+    src, tgt = S.make_pair(61, 6000, R=S.rot_axis_angle([0, 0, 1], np.deg2rad(5.0)), shape="bumpy")
+    bad_t = tgt.copy(); bad_t[17, 1] = np.inf
+    with pytest.raises(pkg.KssError) as e:
+        ctx.icp(src, bad_t, ctx.icp_params(nn_mode=pkg.NN_GRID, max_iterations=3))
+    assert e.value.status == -1
+    bad_s = src.copy(); bad_s[5] = np.nan
+    ref = ctx.icp(np.delete(src, 5, axis=0), tgt, ctx.icp_params(nn_mode=pkg.NN_BRUTE, max_iterations=5, fixed_iterations=1), trace_cap=8)
+    for mode in (pkg.NN_GRID, pkg.NN_BRUTE):
+        r = ctx.icp(bad_s, tgt, ctx.icp_params(nn_mode=mode, max_iterations=5, fixed_iterations=1, compute_fitness=0), trace_cap=8)
+        assert np.isfinite(r["T"]).all() and r["iterations"] == 5
+        assert np.array_equal(r["trace_sums"][:, 0], ref["trace_sums"][:, 0])          # 5999 correspondences every pass
+        assert np.abs(r["T"] - ref["T"]).max() < 1e-6
