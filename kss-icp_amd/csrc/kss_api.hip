@@ -333,7 +333,8 @@ struct IcpPlan {
     int64_t total_src = 0, total_tgt_pad = 0, total_keys = 0;
     bool shared_target = false;
     bool grid = false;      // exact cell-list search (single pair) with brute-force list fallback
-    bool gridb = false;     // batched cell lists, one per pair (no fallback: shells until the pair's grid is exhausted)
+    bool gridb = false;     // batched cell lists, one per pair (in-wave brute-force fallback after rcap shells)
+    bool src_in_cell_order = false;   // sources were re-ordered by a cell-list setup: .w carries the original index
     GridParams gp;
     int total_cells = 0;
 };
@@ -358,6 +359,7 @@ int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npairs, boo
         pl.gridb = nn_mode == KSS_NN_GRID || (nn_mode == KSS_NN_AUTO && min_nt >= 2048 && tot_ns >= 8192);
     }
     const bool any_grid = pl.grid || pl.gridb;
+    pl.src_in_cell_order = any_grid;
     int64_t tot = 0;
     for (int p = 0; p < npairs; ++p) {
         if (ns[p] <= 0 || nt[p] <= 0) return set_err(c, KSS_ERR_ARG, "empty cloud in ICP pair");
@@ -713,7 +715,7 @@ int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, float4*
         ProfScope ps(c, KSS_K_CORR_REDUCE);
         launch_corr_reduce(c->stream, (const RedWork*)c->red_work.p, (int)pl.red.size(), (const PairState*)c->state.p,
                            d_out, (const float4*)c->tgt4.p, (const unsigned long long*)c->keys.p, max_d2,
-                           (double*)c->partials.p, d_idx_out, d_d2_out, (pl.grid || pl.gridb) ? 1 : 0);
+                           (double*)c->partials.p, d_idx_out, d_d2_out, pl.src_in_cell_order ? 1 : 0);
         // the last kernel of the pass writes the sums straight into host-mapped pinned memory
         launch_finalize_sums(c->stream, (const PairRed*)c->pair_red.p, pl.npairs, (const double*)c->partials.p,
                              (double*)c->h_sums_dev, unresolved, reset);
@@ -798,7 +800,7 @@ int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, float4*
         ProfScope ps(c, KSS_K_CORR_REDUCE);
         launch_corr_reduce(c->stream, (const RedWork*)c->red_work.p, (int)pl.red.size(), (const PairState*)c->state.p,
                            d_out, (const float4*)c->tgt4.p, (const unsigned long long*)c->keys.p, max_d2,
-                           (double*)c->partials.p, d_idx_out, d_d2_out, 0);
+                           (double*)c->partials.p, d_idx_out, d_d2_out, pl.src_in_cell_order ? 1 : 0);
         launch_finalize_sums(c->stream, (const PairRed*)c->pair_red.p, pl.npairs, (const double*)c->partials.p,
                              (double*)c->h_sums_dev, nullptr, nullptr, spin ? c->h_seq_dev : nullptr, spin ? ++c->seq : 0);
     }
@@ -814,8 +816,10 @@ void set_state(PairState& s, const float T[16], int active, int apply) {
 }
 
 // The ICP loop over a packed workspace (src0/tgt4 already filled).
-int icp_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P, kss_icp_result* results) {
-    const int np = pl.npairs;
+int icp_loop(kss_ctx* c, const IcpPlan& pl_in, const kss_icp_params& P, kss_icp_result* results) {
+    const IcpPlan* plan = &pl_in;   // may change to the brute-force plan below
+    IcpPlan brute_plan;
+    const int np = pl_in.npairs;
     std::vector<Convergence> conv(np);
     std::vector<float> fin((size_t)np * 16), Tk((size_t)np * 16);
     std::vector<int> iters(np, 0), active(np, 1), converged(np, 0), state(np, 0);
@@ -844,7 +848,24 @@ int icp_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P, kss_icp_res
     while (n_active > 0) {
         const float4* d_in = it == 0 ? (const float4*)c->src0.p : (const float4*)c->cur[(it - 1) & 1].p;
         float4* d_out = (float4*)c->cur[it & 1].p;
-        KCHK(nn_pass(c, pl, P.nn_fma != 0, d_in, d_out, max_d2, nullptr, nullptr));
+        KCHK(nn_pass(c, *plan, P.nn_fma != 0, d_in, d_out, max_d2, nullptr, nullptr));
+        if (plan->gridb) {
+            // Batched cell lists: slot 19 counts the lanes that ended in the in-wave brute-force fallback.  When more
+            // than 10 % of the active sources did (badly posed pairs), the rest of this call runs on the brute-force
+            // engine, whose tiled sweep is several times faster at that job; the engines agree bit for bit on every
+            // correspondence, so the switch only changes speed.  The packed clouds stay where they are.
+            double fallback = 0.0, act = 0.0;
+            for (int p = 0; p < np; ++p)
+                if (active[p]) { fallback += hsum[(size_t)p * NSUMS + NSUMS - 1]; act += (double)plan->g[p].ns; }
+            if (fallback > 0.10 * act && !getenv("KSS_GRID_NOSWITCH")) {
+                std::vector<int64_t> ns(np), nt(np);
+                for (int p = 0; p < np; ++p) { ns[p] = plan->g[p].ns; nt[p] = plan->g[p].nt; }
+                KCHK(build_plan(c, ns.data(), nt.data(), np, false, P.nn_sources_per_thread, P.nn_target_splits, KSS_NN_BRUTE, brute_plan));
+                brute_plan.src_in_cell_order = true;
+                KCHK(stage_plan(c, brute_plan));
+                plan = &brute_plan;
+            }
+        }
         // source rows split over ranks: the sums of all ranks, identical on every rank from here on
         if (P.allreduce && P.allreduce(P.allreduce_user, (double*)c->h_sums, NSUMS) != 0)
             return set_err(c, KSS_ERR_RCCL, "icp: the allreduce callback failed");
@@ -900,20 +921,20 @@ int icp_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P, kss_icp_res
         int32_t* d_idx = nullptr;
         float* d_d2 = nullptr;
         if (P.fitness_idx || P.fitness_d2) {   // per-source correspondences of this pass (indexed by original source index)
-            KCHK(ensure(c, c->stage_idx, (size_t)pl.total_src * sizeof(int32_t)));
-            KCHK(ensure(c, c->stage_d2, (size_t)pl.total_src * sizeof(float)));
+            KCHK(ensure(c, c->stage_idx, (size_t)plan->total_src * sizeof(int32_t)));
+            KCHK(ensure(c, c->stage_d2, (size_t)plan->total_src * sizeof(float)));
             d_idx = (int32_t*)c->stage_idx.p; d_d2 = (float*)c->stage_d2.p;
         }
-        KCHK(nn_pass(c, pl, P.nn_fma != 0, (const float4*)c->src0.p, (float4*)c->cur[0].p, max_d2, d_idx, d_d2));
+        KCHK(nn_pass(c, *plan, P.nn_fma != 0, (const float4*)c->src0.p, (float4*)c->cur[0].p, max_d2, d_idx, d_d2));
         if (P.allreduce) {   // mean over ALL source rows of the job
-            double v[2] = {hsum[17], (double)pl.g[0].ns};
+            double v[2] = {hsum[17], (double)plan->g[0].ns};
             if (P.allreduce(P.allreduce_user, v, 2) != 0) return set_err(c, KSS_ERR_RCCL, "icp: the allreduce callback failed");
             results[0].fitness = v[0] / v[1];
         } else {
-            for (int p = 0; p < np; ++p) results[p].fitness = hsum[(size_t)p * NSUMS + 17] / (double)pl.g[p].ns;
+            for (int p = 0; p < np; ++p) results[p].fitness = hsum[(size_t)p * NSUMS + 17] / (double)plan->g[p].ns;
         }
         if (d_idx) {
-            const size_t n0 = (size_t)pl.g[0].ns;
+            const size_t n0 = (size_t)plan->g[0].ns;
             if (P.fitness_idx) HIPCHK(c, hipMemcpyAsync(P.fitness_idx, d_idx, n0 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
             if (P.fitness_d2) HIPCHK(c, hipMemcpyAsync(P.fitness_d2, d_d2, n0 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -748,6 +748,7 @@ __global__ __launch_bounds__(256) void gridb_nn_kernel(const RedWork* __restrict
                     const unsigned long long kk = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(unsigned)j;
                     if (!done && kk < key) { key = kk; win = q; kpos = -1; }   // (no position in `sorted` known: no warm start next time)
                 }
+                if (!done) acc[NSUMS - 1] += 1.0;   // slot 19: lanes that needed the fallback (the host may change engine)
             }
             if (key != ~0ull) {   // (an empty target cannot happen: the plan rejects it)
                 const float d2 = __uint_as_float((unsigned)(key >> 32));
