@@ -181,3 +181,30 @@ def test_non_finite_coordinates_are_contained(ctx, pkg):
         assert np.isfinite(r["T"]).all() and r["iterations"] == 5
         assert np.array_equal(r["trace_sums"][:, 0], ref["trace_sums"][:, 0])          # 5999 correspondences every pass
         assert np.abs(r["T"] - ref["T"]).max() < 1e-6
+
+
+def test_batch_of_badly_posed_pairs_switches_engine_without_changing_results(ctx, pkg):
+    """Sources that start far from their targets end in the batched kernel's in-wave brute-force fallback; the host then
+    moves the call to the brute-force engine.  With the switch, without it (KSS_GRID_NOSWITCH) and on the brute-force
+    engine from the start the transforms must agree."""
+    import os
+    S = pkg.synth
+    npairs, n = 6, 3000
+    src = np.empty((npairs * n, 3), np.float32); tgt = np.empty((npairs * n, 3), np.float32)
+    for i in range(npairs):
+        shift = 0.0 if i == 0 else 2.0          # one well-posed pair among badly posed ones
+        s, t = S.make_pair(70 + i, n, R=S.rot_axis_angle([0.1, 1.0, 0.4], np.deg2rad(20.0)), t=(shift, -0.4 * shift, 0.3 * shift), shape="bumpy")
+        src[i * n:(i + 1) * n] = s; tgt[i * n:(i + 1) * n] = t
+    off = np.arange(npairs + 1, dtype=np.int64) * n
+    kw = dict(max_iterations=12, fixed_iterations=1, max_corr_dist=100.0)
+    a = ctx.icp_batch(src, off, tgt, off, ctx.icp_params(nn_mode=pkg.NN_GRID, **kw))
+    os.environ["KSS_GRID_NOSWITCH"] = "1"
+    try:
+        b = ctx.icp_batch(src, off, tgt, off, ctx.icp_params(nn_mode=pkg.NN_GRID, **kw))
+    finally:
+        del os.environ["KSS_GRID_NOSWITCH"]
+    c = ctx.icp_batch(src, off, tgt, off, ctx.icp_params(nn_mode=pkg.NN_BRUTE, **kw))
+    for i in range(npairs):
+        assert a[i].iterations == b[i].iterations == c[i].iterations == 12
+        assert np.abs(a[i].matrix() - c[i].matrix()).max() < 1e-5 and np.abs(b[i].matrix() - c[i].matrix()).max() < 1e-5
+        assert abs(a[i].fitness - c[i].fitness) < 1e-9 * max(1.0, c[i].fitness) and abs(b[i].fitness - c[i].fitness) < 1e-9 * max(1.0, c[i].fitness)
