@@ -346,17 +346,18 @@ int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npairs, boo
     if (nn_mode == KSS_NN_AUTO) nn_mode = c->nn_mode;
     // AUTO: the fused cell-list pass (one launch + a spin per iteration) beats sweep + reduce + finalize (three launches)
     // down to a few hundred points (1.4k x 1.4k: 22 vs 36 us per iteration); below that the build (~0.1 ms) is not paid
-    // back.  KSS_GRID_MIN_* : tuning hooks.  Batches keep the brute-force engine unless they are large: on badly posed
-    // pairs (the candidate batch of kss_register) the batched cell-list kernel ends in its in-wave brute-force fallback,
-    // which is slower than the tiled sweep.
+    // back.  KSS_GRID_MIN_* : tuning hooks.  Pairs sharing one target (the candidate batch of kss_register, badly posed
+    // by construction) stay on the brute-force engine.
     static const int64_t min_nt = [] { const char* e = getenv("KSS_GRID_MIN_NT"); return e ? (int64_t)atoll(e) : (int64_t)512; }();
     static const int64_t min_ns = [] { const char* e = getenv("KSS_GRID_MIN_NS"); return e ? (int64_t)atoll(e) : (int64_t)512; }();
     pl.grid = nn_mode == KSS_NN_GRID || (nn_mode == KSS_NN_AUTO && npairs == 1 && nt[0] >= min_nt && ns[0] >= min_ns);
     if (npairs != 1) pl.grid = false;
-    if (npairs > 1 && !shared_target) {   // batch: one cell list per pair when the pairs are big enough to pay for it
-        int64_t min_nt = nt[0], tot_ns = 0;
-        for (int p = 0; p < npairs; ++p) { min_nt = std::min(min_nt, nt[p]); tot_ns += ns[p]; }
-        pl.gridb = nn_mode == KSS_NN_GRID || (nn_mode == KSS_NN_AUTO && min_nt >= 2048 && tot_ns >= 8192);
+    if (npairs > 1 && !shared_target) {
+        // batch: one cell list per pair.  Measured faster than the brute-force batch from 4 pairs x 600 points up
+        // (tools/batch_small.py); badly posed batches move back to brute force after one pass (icp_loop).
+        int64_t least_nt = nt[0], tot_ns = 0;
+        for (int p = 0; p < npairs; ++p) { least_nt = std::min(least_nt, nt[p]); tot_ns += ns[p]; }
+        pl.gridb = nn_mode == KSS_NN_GRID || (nn_mode == KSS_NN_AUTO && least_nt >= min_nt && tot_ns >= 4 * min_ns);
     }
     const bool any_grid = pl.grid || pl.gridb;
     pl.src_in_cell_order = any_grid;
