@@ -281,6 +281,18 @@ int kss_register(kss_ctx *ctx, const double *src_sub, int64_t nss, const double 
                  const double *src_full, int64_t nsf, double accurate, int iter,
                  double *point_align /* nsf*3, may be NULL */, kss_register_result *res);
 
+/* ---- many full KSS registrations (configs C3 / C5 read as registrations, not bare ICPs): for every pair the whole
+ * KSSICP_init + KSSICP_Registration sequence (KSS_ICP.hpp:53-131) -- pNumber = min(n_S, n_T) / 2 capped at sample_cap
+ * (2000 in the reference, :57-63), AIVS down-sampling of both clouds (farthest-point sampling when a cloud cannot be
+ * voxelised), kss_register.  A registration is a chain of small launches that leaves most of the GPU idle, so the pairs
+ * are spread over `workers` host threads, each with its own context / stream on the same device (0 = pick a default);
+ * every pair is handled by exactly one worker with the same code as the one-pair path, so results[i] does not depend
+ * on the worker count.  src_off / tgt_off are point offsets (npairs + 1 entries) into packed double[n][3] arrays.
+ * point_align_all (may be NULL) receives the aligned full-resolution sources, laid out like src_all. */
+int kss_register_batch(kss_ctx *ctx, const double *src_all, const int64_t *src_off, const double *tgt_all,
+                       const int64_t *tgt_off, int npairs, int64_t sample_cap, double accurate, int iter, int workers,
+                       double *point_align_all, kss_register_result *results);
+
 /* ---- (8e) RCCL-backed kss_allreduce_fn: user = &kss_rccl_link{ctx, ncclComm_t}; ncclAllReduce(sum, f64) on the
  * context's stream between a host->device and a device->host copy of the n doubles (160 B per ICP iteration:
  * latency bound, one collective per iteration) ---- */

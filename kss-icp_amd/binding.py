@@ -24,7 +24,7 @@ SYMBOLS = [
     "kss_nn", "kss_nn_dev", "kss_cov", "kss_cov_dev", "kss_rigid_from_sums", "kss_rotation_search",
     "kss_rotation_search_dev", "kss_grid_angles", "kss_rotation_candidates", "kss_icp_default_params", "kss_icp",
     "kss_icp_dev", "kss_icp_batch", "kss_icp_batch_dev", "kss_transform_apply", "kss_transform_apply_dev",
-    "kss_pcr_qm", "kss_register", "kss_gather_results", "kss_rccl_allreduce_sum", "kss_transform_apply_f32", "kss_downsample_fps", "kss_downsample_aivs", "kss_downsample_octree", "kss_knn", "kss_knn_dev", "kss_normals", "kss_normals_orient",
+    "kss_pcr_qm", "kss_register", "kss_register_batch", "kss_gather_results", "kss_rccl_allreduce_sum", "kss_transform_apply_f32", "kss_downsample_fps", "kss_downsample_aivs", "kss_downsample_octree", "kss_knn", "kss_knn_dev", "kss_normals", "kss_normals_orient",
 ]
 
 
@@ -119,6 +119,7 @@ def load_library():
     L.kss_profile_event_overhead.argtypes = [vp, C.POINTER(dbl)]
     L.kss_downsample_octree.argtypes = [vp, vp, i64, vp, i64, C.POINTER(i64), C.POINTER(dbl)]
     L.kss_normals_orient.argtypes = [vp, vp, i64, vp]
+    L.kss_register_batch.argtypes = [vp, vp, vp, vp, vp, C.c_int, i64, dbl, C.c_int, C.c_int, vp, vp]
     for n in ("kss_preshape_stats", "kss_preshape_stats_dev"):
         getattr(L, n).argtypes = [vp, vp, C.c_int, i64, vp, C.POINTER(dbl)]
     for n in ("kss_pose_apply", "kss_pose_apply_dev"):
@@ -422,6 +423,16 @@ class Context:
         a = _f64(pts); nrm = _f64(normals).copy()
         self._chk(self.L.kss_normals_orient(self.h, _p(a), len(a), _p(nrm)), "kss_normals_orient")
         return nrm
+
+    def register_batch(self, src_all, src_off, tgt_all, tgt_off, sample_cap=2000, accurate=8.0, iters=1000, workers=0, want_align=False):
+        s, t = _f64(src_all), _f64(tgt_all)
+        so = np.ascontiguousarray(src_off, dtype=np.int64); to = np.ascontiguousarray(tgt_off, dtype=np.int64)
+        npairs = len(so) - 1
+        res = (RegisterResult * npairs)()
+        align = np.empty_like(s) if want_align else None
+        self._chk(self.L.kss_register_batch(self.h, _p(s), _p(so), _p(t), _p(to), npairs, int(sample_cap), float(accurate), int(iters),
+                                            int(workers), _p(align) if want_align else None, C.cast(res, C.c_void_p)), "kss_register_batch")
+        return (list(res), align) if want_align else list(res)
 
     def downsample_octree(self, pts):
         """(selected point indices in octree depth-first voxel order -- repeats possible --, resolution)."""

@@ -15,7 +15,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kss_internal.hpp"
@@ -49,6 +51,7 @@ struct kss_ctx {
         scratch_b, scratch_c, stage_src, stage_tgt, stage_idx, stage_d2, stage_out, g_counts, g_start, g_cursor,
         g_bsums, g_sorted, g_list, g_count, g_bbox, g_partials, g_start2, g_pairs, g_stamps, g_pos, pack_seg, reg_s, reg_t, reg_p, reg_all, reg_f, reg_g, oct_pts, oct_cen, oct_a, oct_b, oct_tmp;
     HostPool pool;   // per-pair host work of batched iterations
+    std::vector<kss_ctx*> workers;   // contexts of kss_register_batch's worker threads (same device, own streams)
     std::vector<unsigned long long> last_stamps;
     double evals_sum = 0.0, evals_launches = 0.0;   // diagnostic runs: distance evaluations of the fused grid launches
     // pinned host staging
@@ -211,6 +214,8 @@ int kss_ctx_destroy(kss_ctx* c) {
     if (c->h_sums) hipHostFree(c->h_sums);
     if (c->h_seq) hipHostFree(c->h_seq);
     if (c->h_state) hipHostFree(c->h_state);
+    for (kss_ctx* w : c->workers) kss_ctx_destroy(w);
+    c->workers.clear();
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return KSS_OK;
@@ -1641,6 +1646,71 @@ int kss_register(kss_ctx* c, const double* src_sub, int64_t nss, const double* t
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
 #undef RCHK
+    return KSS_OK;
+}
+
+// ---- many full registrations, concurrently ----------------------------------------------------------------------
+static int downsample_for_register(kss_ctx* w, const double* xyz, int64_t n, int64_t m, std::vector<double>& out) {
+    out.resize((size_t)n * 3);
+    if (m <= 0 || m >= n) { std::memcpy(out.data(), xyz, (size_t)n * 3 * sizeof(double)); return KSS_OK; }
+    int64_t k = 0;
+    int rc = kss_downsample_aivs(w, xyz, n, m, out.data(), n, &k, nullptr);
+    if (rc == KSS_ERR_ARG) {   // degenerate extent (the reference would divide by zero): exact farthest-point sampling
+        rc = kss_downsample_fps(w, xyz, n, m, out.data(), nullptr);
+        k = m;
+    }
+    if (rc != KSS_OK) return rc;
+    out.resize((size_t)k * 3);
+    return KSS_OK;
+}
+
+int kss_register_batch(kss_ctx* c, const double* src_all, const int64_t* src_off, const double* tgt_all, const int64_t* tgt_off,
+                       int npairs, int64_t sample_cap, double accurate, int iter, int workers, double* point_align_all,
+                       kss_register_result* results) {
+    if (!c || !src_all || !src_off || !tgt_all || !tgt_off || !results || npairs <= 0) return set_err(c, KSS_ERR_ARG, "register_batch: bad argument");
+    for (int i = 0; i < npairs; ++i)
+        if (src_off[i + 1] <= src_off[i] || tgt_off[i + 1] <= tgt_off[i]) return set_err(c, KSS_ERR_ARG, "register_batch: empty cloud");
+    HIPCHK(c, hipSetDevice(c->device));
+    int nw = workers > 0 ? workers : 8;
+    nw = std::min(std::min(nw, npairs), 32);
+    while ((int)c->workers.size() < nw) {   // worker contexts live as long as the parent
+        kss_ctx* w = nullptr;
+        const int rc = kss_ctx_create(c->device, &w);
+        if (rc != KSS_OK) return set_err(c, rc, "register_batch: cannot create a worker context");
+        w->nn_mode = c->nn_mode;
+        c->workers.push_back(w);
+    }
+    std::atomic<int> next{0}, failed{KSS_OK};
+    std::string first_error;
+    std::mutex err_mutex;
+    auto run = [&](kss_ctx* w) {
+        hipSetDevice(w->device);
+        std::vector<double> ssub, tsub;
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= npairs || failed.load() != KSS_OK) return;
+            const double* S = src_all + 3 * src_off[i];
+            const double* T = tgt_all + 3 * tgt_off[i];
+            const int64_t ns = src_off[i + 1] - src_off[i], nt = tgt_off[i + 1] - tgt_off[i];
+            int64_t pNumber = std::min(ns, nt) / 2;                      // KSS_ICP.hpp:57-63
+            if (sample_cap > 0 && pNumber > sample_cap) pNumber = sample_cap;
+            int rc = downsample_for_register(w, T, nt, pNumber, tsub);    // :71-75 (target first, as the reference)
+            if (rc == KSS_OK) rc = downsample_for_register(w, S, ns, pNumber, ssub);
+            if (rc == KSS_OK)
+                rc = kss_register(w, ssub.data(), (int64_t)ssub.size() / 3, tsub.data(), (int64_t)tsub.size() / 3, S, ns, accurate, iter,
+                                  point_align_all ? point_align_all + 3 * src_off[i] : nullptr, &results[i]);
+            if (rc != KSS_OK) {
+                std::lock_guard<std::mutex> lk(err_mutex);
+                if (failed.load() == KSS_OK) { failed.store(rc); first_error = "register_batch: pair " + std::to_string(i) + ": " + w->err; }
+                return;
+            }
+        }
+    };
+    std::vector<std::thread> threads;
+    for (int k = 1; k < nw; ++k) threads.emplace_back(run, c->workers[(size_t)k]);
+    run(c->workers[0]);
+    for (std::thread& t : threads) t.join();
+    if (failed.load() != KSS_OK) return set_err(c, failed.load(), first_error.c_str());
     return KSS_OK;
 }
 

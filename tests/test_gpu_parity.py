@@ -406,3 +406,32 @@ def test_split_source_icp_over_rccl_single_rank(ctx, pkg):
     b = ctx.icp(src, tgt, ctx.icp_params())
     assert np.array_equal(a["T"], b["T"]) and a["iterations"] == b["iterations"] and a["fitness"] == b["fitness"]
     rccl.ncclCommDestroy(comm)
+
+
+def test_register_batch_equals_one_by_one(ctx, pkg, ref_pairs):
+    """kss_register_batch: many full registrations (down-sample, pre-shape, search, candidate ICPs) spread over worker
+    contexts on the same GPU.  Every pair must come out exactly as the one-pair path gives it, whatever the worker
+    count; ragged sizes, a scaled pair and the reference's own pairs."""
+    S = pkg.synth
+    clouds = []
+    for i, (n, scale, deg) in enumerate(((2400, 1.0, 25.0), (3100, 2.0, 60.0), (1800, 0.5, 140.0), (2600, 1.0, 10.0), (1200, 1.3, 200.0))):
+        s, t = S.make_pair(300 + i, n, R=S.rot_axis_angle([0.4, 0.2 + 0.1 * i, 1.0], np.deg2rad(deg)), scale=scale, t=(0.1 * i, -0.05, 0.02), shape="bumpy", n_src=n - 150)
+        clouds.append((s.astype(np.float64), t.astype(np.float64)))
+    for key in (("registration", "Bunny"), ("registration", "Horse")):
+        clouds.append(ref_pairs[key])
+    src_all = np.concatenate([c[0] for c in clouds]); tgt_all = np.concatenate([c[1] for c in clouds])
+    so = np.concatenate([[0], np.cumsum([len(c[0]) for c in clouds])]); to = np.concatenate([[0], np.cumsum([len(c[1]) for c in clouds])])
+    one = []
+    for s, t in clouds:
+        m = min(min(len(s), len(t)) // 2, 2000)
+        ss, _ = ctx.downsample_aivs(s, m); tt, _ = ctx.downsample_aivs(t, m)
+        one.append(ctx.register(ss, tt, s, 8.0, 1000))
+    for workers in (1, 3, 8):
+        res, align = ctx.register_batch(src_all, so, tgt_all, to, sample_cap=2000, accurate=8.0, iters=1000, workers=workers, want_align=True)
+        for i, (r, o) in enumerate(zip(res, one)):
+            assert r.scale == o["scale"] and list(r.angle) == list(o["angle"]) and r.final_fitness == o["final_fitness"], (workers, i)
+            assert np.array_equal(np.array(r.R).reshape(3, 3), o["R"]) and np.array_equal(np.array(r.t), o["t"])
+            assert r.icp_iterations == o["icp_iterations"] and r.n_angle_list == o["n_angle_list"] and r.angle_index == o["angle_index"]
+            assert np.array_equal(align[so[i]:so[i + 1]], o["pointAlign"])
+    with pytest.raises(pkg.KssError):
+        ctx.register_batch(src_all, np.array([0, 0, len(src_all)]), tgt_all, np.array([0, 10, len(tgt_all)]))      # an empty source
