@@ -25,28 +25,33 @@ def max_shard(npairs, world):
 
 
 def records_to_array(records, lo):
-    """ctypes IcpResult array -> uint8 [n, 96] with pair_id rewritten to the GLOBAL pair index."""
+    """ctypes record array -> uint8 [n, sizeof(record)].  kss_icp_result records (96 bytes) get pair_id rewritten to the
+    GLOBAL pair index; other fixed-size records (kss_register_result: s, R, t, ...) are copied as they are."""
     n = len(records)
-    out = np.zeros((n, RECORD_BYTES), np.uint8)
+    size = C.sizeof(records[0]) if n else RECORD_BYTES
+    out = np.zeros((n, size), np.uint8)
     for i in range(n):
-        records[i].pair_id = lo + i
+        if hasattr(records[i], "pair_id"):
+            records[i].pair_id = lo + i
         out[i] = np.frombuffer(bytes(records[i]), dtype=np.uint8)
     return out
 
 
 def array_to_records(arr, record_type):
-    arr = np.ascontiguousarray(arr, dtype=np.uint8).reshape(-1, RECORD_BYTES)
+    arr = np.ascontiguousarray(arr, dtype=np.uint8).reshape(-1, C.sizeof(record_type))
     return [record_type.from_buffer_copy(arr[i].tobytes()) for i in range(len(arr))]
 
 
-def gather_records(local, npairs, world, rank, device=None):
+def gather_records(local, npairs, world, rank, device=None, record_bytes=RECORD_BYTES):
     """All-gather the per-pair records of every rank (torch.distributed; backend nccl == RCCL on ROCm).
 
-    local: uint8 [n_local, 96].  Returns uint8 [npairs, 96] ordered by global pair id on every rank.
-    Ranks may own different counts: records are padded to the largest shard for ONE fixed-size collective."""
+    local: uint8 [n_local, B] (B = 96 for kss_icp_result; any fixed record size works).  Returns uint8 [npairs, B]
+    ordered by global pair id on every rank.  Ranks may own different counts: records are padded to the largest shard
+    for ONE fixed-size collective.  `record_bytes` is needed only by a rank that owns no record."""
     import torch
     import torch.distributed as dist
     m = max_shard(npairs, world)
+    RECORD_BYTES = int(local.shape[1]) if len(local) else int(record_bytes)
     buf = torch.zeros((m, RECORD_BYTES), dtype=torch.uint8, device=device)
     if len(local):
         buf[:len(local)] = torch.from_numpy(np.ascontiguousarray(local)).to(buf.device)

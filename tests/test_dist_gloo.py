@@ -42,6 +42,13 @@ def _worker(rank, world, port, npairs, ret):
     ok = len(out) == npairs
     for g, r in enumerate(out):
         ok = ok and r.pair_id == g and r.iterations == g + 1 and r.fitness == g * 0.5 and r.T[5] == float(g * 100 + 5)
+    # full-registration records (kss_register_result: s, R, t, ...) travel through the same gather
+    regs = (pkg.binding.RegisterResult * (hi - lo))()
+    for i in range(hi - lo):
+        regs[i].scale = 1.0 + (lo + i); regs[i].t[2] = float(lo + i); regs[i].icp_iterations = lo + i
+    allg = pkg.shard.gather_records(pkg.shard.records_to_array(regs, lo), npairs, world, rank, record_bytes=C.sizeof(pkg.binding.RegisterResult))
+    back = pkg.shard.array_to_records(allg, pkg.binding.RegisterResult)
+    ok = ok and len(back) == npairs and all(b.scale == 1.0 + g and b.t[2] == float(g) and b.icp_iterations == g for g, b in enumerate(back))
     # timing protocol of bench.py: MAX over ranks
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
