@@ -1,157 +1,9 @@
-// kss_api.hip -- C-ABI (include/kssicp.h) and host-side drivers of the registration core.
-//
-// Host code only orchestrates: per ICP iteration it launches the NN sweep + correspondence reduce,
-// copies 20 doubles per pair back, solves the 3x3 SVD (kss_host_math.hpp) and evaluates the PCL
-// convergence criteria.  There is no CPU compute fallback anywhere in this file.
+// kss_api.hip -- the C-ABI of include/kssicp.h: context and profiling entry points, and the compute entry points over
+// the engine (kss_engine.hip) and the kernel launchers (kss_kernels / kss_grid / kss_aivs / kss_knn / kss_octree .hip).
+// There is no CPU compute fallback anywhere in this file.
 #pragma clang fp contract(off)
 
-#include <dlfcn.h>
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <mutex>
-#include <string>
-#include <thread>
-#include <vector>
-
-#include "kss_internal.hpp"
-#include "kss_host_pool.hpp"
-
-using namespace kss;
-
-// ---------------------------------------------------------------------------------------------
-// context
-// ---------------------------------------------------------------------------------------------
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-};
-
-struct kss_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    std::string err;
-    int nn_mode = KSS_NN_AUTO;
-    double grid_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    double last_setup_ms = 0, last_loop_ms = 0;
-    double t_launch_us = 0, t_wait_us = 0, t_host_us = 0;   // KSS_TIMING breakdown of the fused single-pair loop
-    bool timing = false;
-    bool tables_staged = false;
-    int64_t stats_ns = -1, stats_nt = -1;
-
-    // grow-only device workspace
-    DevBuf tgt4, src0, cur[2], keys, partials, sums, nn_work, red_work, pair_red, state, cs, scratch_a,
-        scratch_b, scratch_c, stage_src, stage_tgt, stage_idx, stage_d2, stage_out, g_counts, g_start, g_cursor,
-        g_bsums, g_sorted, g_list, g_count, g_bbox, g_partials, g_start2, g_pairs, g_stamps, g_pos, pack_seg, reg_s, reg_t, reg_p, reg_all, reg_f, reg_g, oct_pts, oct_cen, oct_a, oct_b, oct_tmp;
-    HostPool pool;   // per-pair host work of batched iterations
-    std::vector<kss_ctx*> workers;   // contexts of kss_register_batch's worker threads (same device, own streams)
-    std::vector<unsigned long long> last_stamps;
-    double evals_sum = 0.0, evals_launches = 0.0;   // diagnostic runs: distance evaluations of the fused grid launches
-    // pinned host staging
-    void* h_sums = nullptr;  size_t h_sums_cap = 0;   // host-mapped: kernels write it through h_sums_dev
-    void* h_sums_dev = nullptr;
-    unsigned long long* h_seq = nullptr;       // host-mapped result of the fused grid kernel: NSUMS x {bits(sum), sequence number}
-    unsigned long long* h_seq_dev = nullptr;
-    unsigned long long seq = 0;
-    void* h_state = nullptr; size_t h_state_cap = 0;
-
-    // profiling
-    int prof = 0;                       // 0 = off, n = event-time every n-th launch of each kernel class
-    unsigned prof_tick[KSS_K_COUNT] = {};
-    struct EvPair { hipEvent_t a, b; };
-    std::vector<EvPair> ev[KSS_K_COUNT];
-    std::vector<EvPair> ev_pool;   // recycled event pairs: no hipEventCreate/Destroy inside timed loops
-    double prof_ms[KSS_K_COUNT] = {0};
-    int64_t prof_n[KSS_K_COUNT] = {0};
-};
-
-static int set_err(kss_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
-    if (c) {
-        c->err = what;
-        if (e != hipSuccess) { c->err += ": "; c->err += hipGetErrorString(e); }
-    }
-    return code;
-}
-
-#define HIPCHK(ctx, call)                                                        \
-    do {                                                                         \
-        hipError_t e_ = (call);                                                  \
-        if (e_ != hipSuccess) return set_err((ctx), KSS_ERR_HIP, #call, e_);     \
-    } while (0)
-
-static int ensure(kss_ctx* c, DevBuf& b, size_t bytes) {
-    if (bytes <= b.cap) return KSS_OK;
-    if (b.p) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, hipFree(b.p));
-        b.p = nullptr; b.cap = 0;
-    }
-    size_t want = bytes + bytes / 8 + 256;
-    hipError_t e = hipMalloc(&b.p, want);
-    if (e != hipSuccess) { b.p = nullptr; return set_err(c, KSS_ERR_NOMEM, "hipMalloc", e); }
-    b.cap = want;
-    return KSS_OK;
-}
-
-static int ensure_pinned(kss_ctx* c, void*& p, size_t& cap, size_t bytes) {
-    if (bytes <= cap) return KSS_OK;
-    if (p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipHostFree(p)); p = nullptr; cap = 0; }
-    size_t want = bytes * 2 + 256;
-    hipError_t e = hipHostMalloc(&p, want, hipHostMallocMapped);
-    if (e != hipSuccess) { p = nullptr; return set_err(c, KSS_ERR_NOMEM, "hipHostMalloc", e); }
-    cap = want;
-    if (&p == &c->h_sums) {
-        void* d = nullptr;
-        HIPCHK(c, hipHostGetDevicePointer(&d, p, 0));
-        c->h_sums_dev = d;
-    }
-    return KSS_OK;
-}
-
-#define KCHK(expr)                     \
-    do {                               \
-        int rc_ = (expr);              \
-        if (rc_ != KSS_OK) return rc_; \
-    } while (0)
-
-struct ProfScope {   // records a start/stop event pair around a launch when profiling is on
-    kss_ctx* c; int k; kss_ctx::EvPair ep; bool on;
-    ProfScope(kss_ctx* c_, int k_) : c(c_), k(k_), on(c_->prof > 0) {
-        if (on && c->prof > 1) on = (c->prof_tick[k]++ % (unsigned)c->prof) == 0;   // sampled: the events themselves cost ~3 us
-        if (!on) return;
-        if (!c->ev_pool.empty()) {
-            ep = c->ev_pool.back();
-            c->ev_pool.pop_back();
-        } else if (hipEventCreate(&ep.a) != hipSuccess || hipEventCreate(&ep.b) != hipSuccess) {
-            on = false;
-            return;
-        }
-        hipEventRecord(ep.a, c->stream);
-    }
-    ~ProfScope() {
-        if (!on) return;
-        hipEventRecord(ep.b, c->stream);
-        c->ev[k].push_back(ep);
-    }
-};
-
-static void prof_collect(kss_ctx* c) {
-    for (int k = 0; k < KSS_K_COUNT; ++k) {
-        for (auto& ep : c->ev[k]) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) { c->prof_ms[k] += ms; c->prof_n[k] += 1; }
-            c->ev_pool.push_back(ep);
-        }
-        c->ev[k].clear();
-    }
-}
+#include "kss_ctx.hpp"
 
 extern "C" {
 
@@ -313,683 +165,6 @@ int kss_profile_get(kss_ctx* c, int k, double* total_ms, int64_t* launches) {
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------
-// ICP plan: how pairs, source blocks and target splits map onto workgroups
-// ---------------------------------------------------------------------------------------------
-namespace {
-
-int ensure_pub(kss_ctx* c);   // host-mapped result slots (defined with wait_seq)
-
-struct PairGeom {
-    int64_t ns, nt;
-    int32_t src_base;      // first source in the float4 source arrays
-    int32_t tgt_base;      // first (padded) target in tgt4
-    int32_t tgt_pad;       // padded target count = n_split * chunk
-    int32_t n_split, chunk;
-    int32_t key_base;
-    int32_t n_src_blocks;
-};
-
-struct IcpPlan {
-    int npairs = 0, S = 4;
-    std::vector<PairGeom> g;
-    std::vector<NNWork> nn;
-    std::vector<RedWork> red;
-    std::vector<PairRed> pred;
-    int64_t total_src = 0, total_tgt_pad = 0, total_keys = 0;
-    bool shared_target = false;
-    bool grid = false;      // exact cell-list search (single pair) with brute-force list fallback
-    bool gridb = false;     // batched cell lists, one per pair (in-wave brute-force fallback after rcap shells)
-    bool src_in_cell_order = false;   // sources were re-ordered by a cell-list setup: .w carries the original index
-    GridParams gp;
-    int total_cells = 0;
-};
-
-int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npairs, bool shared_target,
-               int S_req, int split_req, int nn_mode, IcpPlan& pl) {
-    pl.npairs = npairs;
-    pl.shared_target = shared_target;
-    if (nn_mode == KSS_NN_AUTO) nn_mode = c->nn_mode;
-    // AUTO: the fused cell-list pass (one launch + a spin per iteration) beats sweep + reduce + finalize (three launches)
-    // down to a few hundred points (1.4k x 1.4k: 22 vs 36 us per iteration); below that the build (~0.1 ms) is not paid
-    // back.  KSS_GRID_MIN_* : tuning hooks.  Pairs sharing one target (the candidate batch of kss_register, badly posed
-    // by construction) stay on the brute-force engine.
-    static const int64_t min_nt = [] { const char* e = getenv("KSS_GRID_MIN_NT"); return e ? (int64_t)atoll(e) : (int64_t)512; }();
-    static const int64_t min_ns = [] { const char* e = getenv("KSS_GRID_MIN_NS"); return e ? (int64_t)atoll(e) : (int64_t)512; }();
-    pl.grid = nn_mode == KSS_NN_GRID || (nn_mode == KSS_NN_AUTO && npairs == 1 && nt[0] >= min_nt && ns[0] >= min_ns);
-    if (npairs != 1) pl.grid = false;
-    if (npairs > 1 && !shared_target) {
-        // batch: one cell list per pair.  Measured faster than the brute-force batch from 4 pairs x 600 points up
-        // (tools/batch_small.py); badly posed batches move back to brute force after one pass (icp_loop).
-        int64_t least_nt = nt[0], tot_ns = 0;
-        for (int p = 0; p < npairs; ++p) { least_nt = std::min(least_nt, nt[p]); tot_ns += ns[p]; }
-        pl.gridb = nn_mode == KSS_NN_GRID || (nn_mode == KSS_NN_AUTO && least_nt >= min_nt && tot_ns >= 4 * min_ns);
-    }
-    const bool any_grid = pl.grid || pl.gridb;
-    pl.src_in_cell_order = any_grid;
-    int64_t tot = 0;
-    for (int p = 0; p < npairs; ++p) {
-        if (ns[p] <= 0 || nt[p] <= 0) return set_err(c, KSS_ERR_ARG, "empty cloud in ICP pair");
-        tot += ns[p];
-    }
-    int S = S_req;
-    if (S != 1 && S != 2 && S != 4 && S != 8) S = tot >= 32768 ? 4 : (tot >= 8192 ? 2 : 1);
-    pl.S = S;
-    const int per_block = NN_THREADS * S;
-    int64_t src_blocks_total = 0;
-    for (int p = 0; p < npairs; ++p) src_blocks_total += (ns[p] + per_block - 1) / per_block;
-    // enough workgroups to keep 256 CUs x 8 resident workgroups busy with >= 2 rounds
-    int64_t want_split = 1;
-    if (src_blocks_total < 2048) want_split = (4096 + src_blocks_total - 1) / src_blocks_total;
-    if (split_req > 0) want_split = split_req;
-
-    pl.g.resize(npairs);
-    int64_t sb = 0, tb = 0, kb = 0;
-    for (int p = 0; p < npairs; ++p) {
-        PairGeom& g = pl.g[p];
-        g.ns = ns[p]; g.nt = nt[p];
-        const int64_t tiles = (nt[p] + NN_TILE - 1) / NN_TILE;
-        int64_t split = std::min<int64_t>(want_split, std::max<int64_t>(1, tiles / 2));
-        int64_t chunk_tiles = (tiles + split - 1) / split;
-        split = (tiles + chunk_tiles - 1) / chunk_tiles;
-        g.n_split = (int32_t)split;
-        g.chunk = (int32_t)(chunk_tiles * NN_TILE);
-        g.tgt_pad = g.n_split * g.chunk;
-        g.src_base = (int32_t)sb;
-        g.key_base = (int32_t)kb;
-        g.n_src_blocks = (int32_t)((ns[p] + per_block - 1) / per_block);
-        if (shared_target && p > 0) {
-            g.tgt_base = pl.g[0].tgt_base;
-        } else {
-            g.tgt_base = (int32_t)tb;
-            tb += g.tgt_pad;
-        }
-        sb += ns[p];
-        kb += any_grid ? ns[p] : (int64_t)g.n_split * ns[p];
-        if (sb > 0x7fff0000ll || tb > 0x7fff0000ll || kb > 0x7fff0000ll)
-            return set_err(c, KSS_ERR_ARG, "problem too large for 32-bit indexing");
-    }
-    pl.total_src = sb; pl.total_tgt_pad = tb; pl.total_keys = kb;
-
-    pl.nn.clear(); pl.red.clear(); pl.pred.resize(npairs);
-    int32_t prow = 0;
-    for (int p = 0; p < npairs; ++p) {
-        const PairGeom& g = pl.g[p];
-        for (int b = 0; b < (pl.gridb ? 0 : g.n_src_blocks); ++b)
-            for (int s = 0; s < g.n_split; ++s) {
-                NNWork w;
-                w.pair = p;
-                w.src_begin = g.src_base + b * per_block;
-                w.src_count = (int32_t)std::min<int64_t>(per_block, g.ns - (int64_t)b * per_block);
-                w.tgt_begin = g.tgt_base + s * g.chunk;
-                w.tgt_count = g.chunk;
-                w.tgt_pair_base = g.tgt_base;
-                w.key_begin = g.key_base + (int32_t)((int64_t)s * g.ns) + b * per_block;
-                w.write_src = s == 0;
-                if (pl.grid) {   // LIST semantics (kss_kernels.hip): offsets into the unresolved list, key row 0
-                    w.src_begin = b * per_block;
-                    w.key_begin = g.key_base;
-                    w.write_src = g.src_base;
-                }
-                pl.nn.push_back(w);
-            }
-        pl.pred[p].first = prow;
-        // reduce workgroups own 256*R consecutive sources (R = 1 up to 131k sources: the reduce is latency bound,
-        // it wants many workgroups; the 240-lane final reduction handles hundreds of rows in a few microseconds)
-        int64_t R = (g.ns + 256 * 512 - 1) / (256 * 512);   // <= ~512 partial rows per pair
-        R = std::max<int64_t>(1, std::min<int64_t>(R, 64));
-        if (pl.gridb) {
-            // fused batched pass: a workgroup's 20-value block reduction costs about as much as searching 256 queries,
-            // so every workgroup takes up to 8 rounds of 256 queries (sums stay in registers) as long as the batch
-            // still yields ~2000 workgroups (C3: 27.8 -> 19.1 ms).  KSS_GRIDB_ROUNDS: tuning hook.
-            static const int64_t forced = [] { const char* e = getenv("KSS_GRIDB_ROUNDS"); const int64_t v = e ? atoll(e) : 0; return v >= 1 && v <= 64 ? v : 0; }();
-            const int64_t rounds = forced ? forced : std::max<int64_t>(1, std::min<int64_t>(8, tot / (256 * 2048)));
-            R = std::max<int64_t>(R, std::min<int64_t>(rounds, (g.ns + 255) / 256));
-        }
-        const int64_t rchunk = 256 * R;
-        const int nrb = (int)((g.ns + rchunk - 1) / rchunk);
-        for (int b = 0; b < nrb; ++b) {
-            RedWork r;
-            r.pair = p;
-            r.src_begin = g.src_base + (int32_t)(b * rchunk);
-            r.src_count = (int32_t)std::min<int64_t>(rchunk, g.ns - (int64_t)b * rchunk);
-            r.key_begin = g.key_base + (int32_t)(b * rchunk);
-            r.key_stride = (int32_t)g.ns;
-            r.n_split = any_grid ? 1 : g.n_split;
-            r.tgt_pair_base = g.tgt_base;
-            r.partial_index = prow++;
-            pl.red.push_back(r);
-        }
-        pl.pred[p].count = nrb;
-    }
-    return KSS_OK;
-}
-
-// Work tables of the sweep / reduce kernels (uploaded lazily on the fused cell-list path).
-int stage_tables(kss_ctx* c, const IcpPlan& pl) {
-    if (c->tables_staged) return KSS_OK;
-    HIPCHK(c, hipMemcpyAsync(c->nn_work.p, pl.nn.data(), pl.nn.size() * sizeof(NNWork), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->red_work.p, pl.red.data(), pl.red.size() * sizeof(RedWork), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->pair_red.p, pl.pred.data(), pl.pred.size() * sizeof(PairRed), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));   // pageable sources: do not outlive this call unsynchronised
-    c->tables_staged = true;
-    return KSS_OK;
-}
-
-// Upload plan tables and size the workspace.
-int stage_plan(kss_ctx* c, const IcpPlan& pl) {
-    KCHK(ensure(c, c->tgt4, (size_t)pl.total_tgt_pad * sizeof(float4)));
-    KCHK(ensure(c, c->src0, (size_t)pl.total_src * sizeof(float4)));
-    KCHK(ensure(c, c->cur[0], (size_t)pl.total_src * sizeof(float4)));
-    KCHK(ensure(c, c->cur[1], (size_t)pl.total_src * sizeof(float4)));
-    KCHK(ensure(c, c->keys, (size_t)pl.total_keys * sizeof(unsigned long long)));
-    KCHK(ensure(c, c->partials, pl.red.size() * NSUMS * sizeof(double)));
-    KCHK(ensure(c, c->sums, (size_t)pl.npairs * NSUMS * sizeof(double)));
-    KCHK(ensure(c, c->nn_work, pl.nn.size() * sizeof(NNWork)));
-    KCHK(ensure(c, c->red_work, pl.red.size() * sizeof(RedWork)));
-    KCHK(ensure(c, c->pair_red, pl.pred.size() * sizeof(PairRed)));
-    KCHK(ensure(c, c->state, (size_t)pl.npairs * sizeof(PairState)));
-    KCHK(ensure_pinned(c, c->h_sums, c->h_sums_cap, (size_t)pl.npairs * NSUMS * sizeof(double)));
-    KCHK(ensure_pinned(c, c->h_state, c->h_state_cap, (size_t)pl.npairs * sizeof(PairState)));
-    KCHK(ensure_pub(c));
-    c->tables_staged = false;
-    if (!pl.grid) KCHK(stage_tables(c, pl));   // the fused cell-list path needs them only if a query falls back
-    return KSS_OK;
-}
-
-// Pack the clouds of every pair into the float4 workspace (targets sentinel padded).
-// dtype: KSS_F32 / KSS_F64 packed triples on the DEVICE; src_off/tgt_off in points.
-int pack_clouds(kss_ctx* c, const IcpPlan& pl, const void* d_src, const int64_t* src_off, const void* d_tgt,
-                const int64_t* tgt_off, int dtype) {
-    const size_t esz = dtype == KSS_F64 ? sizeof(double) : sizeof(float);
-    // sources are contiguous in both layouts
-    {
-        const char* base = (const char*)d_src + (size_t)src_off[0] * 3 * esz;
-        if (dtype == KSS_F64) launch_pack_f64_to_f4(c->stream, (const double*)base, pl.total_src, (float4*)c->src0.p, pl.total_src, false);
-        else launch_pack_f3_to_f4(c->stream, (const float*)base, pl.total_src, (float4*)c->src0.p, pl.total_src, false);
-    }
-    const int ntp = pl.shared_target ? 1 : pl.npairs;
-    if (ntp > 8) {   // many pairs: one launch over a per-pair segment table (segments are laid out back to back in tgt4)
-        std::vector<PackSeg> seg((size_t)ntp);
-        for (int p = 0; p < ntp; ++p) { seg[p].in_off = tgt_off[p]; seg[p].out_base = pl.g[p].tgt_base; seg[p].n = pl.g[p].nt; }
-        KCHK(ensure(c, c->pack_seg, seg.size() * sizeof(PackSeg)));
-        HIPCHK(c, hipMemcpyAsync(c->pack_seg.p, seg.data(), seg.size() * sizeof(PackSeg), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));   // `seg` is pageable and about to go out of scope
-        launch_pack_batch(c->stream, d_tgt, dtype, (const PackSeg*)c->pack_seg.p, ntp, pl.total_tgt_pad, (float4*)c->tgt4.p);
-        HIPCHK(c, hipGetLastError());
-        return KSS_OK;
-    }
-    for (int p = 0; p < ntp; ++p) {
-        const PairGeom& g = pl.g[p];
-        const char* base = (const char*)d_tgt + (size_t)tgt_off[p] * 3 * esz;
-        float4* out = (float4*)c->tgt4.p + g.tgt_base;
-        if (dtype == KSS_F64) launch_pack_f64_to_f4(c->stream, (const double*)base, g.nt, out, g.tgt_pad, true);
-        else launch_pack_f3_to_f4(c->stream, (const float*)base, g.nt, out, g.tgt_pad, true);
-    }
-    HIPCHK(c, hipGetLastError());
-    return KSS_OK;
-}
-
-static void choose_cells(const float mn[3], const float mx[3], int64_t nt, GridParams& gp) {
-    const float ext[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
-    const float emax = std::max(ext[0], std::max(ext[1], ext[2]));
-    // cell edge: a handful of points per occupied cell if the target is a surface (area ~ emax^2 * few)
-    float hscale = 2.0f;
-    if (const char* e = getenv("KSS_GRID_HSCALE")) { const float v = (float)atof(e); if (v > 0.05f && v < 50.f) hscale = v; }   // tuning hook
-    float h = emax * hscale * std::sqrt(3.0f / (float)nt);
-    h = std::max(h, emax / 255.5f);
-    if (!(h > 0.f)) h = 1.f;   // all targets coincide
-    gp.ox = mn[0]; gp.oy = mn[1]; gp.oz = mn[2];
-    gp.h = h; gp.inv_h = 1.0f / h;
-    gp.gx = std::max(1, std::min(256, (int)std::floor(ext[0] / h) + 1));
-    gp.gy = std::max(1, std::min(256, (int)std::floor(ext[1] / h) + 1));
-    gp.gz = std::max(1, std::min(256, (int)std::floor(ext[2] / h) + 1));
-    const float mag = std::max(std::max(std::fabs(mn[0]), std::fabs(mx[0])), std::max(std::max(std::fabs(mn[1]), std::fabs(mx[1])), std::max(std::fabs(mn[2]), std::fabs(mx[2]))));
-    gp.eps = 2e-6f * (mag + emax) + 1e-30f;
-    gp.rcap = 4;   // shells before a query goes to the brute-force list (measured on badly initialised pairs: tools/hard_case.py)
-    if (const char* e = getenv("KSS_GRID_RCAP")) { const int v = atoi(e); if (v >= 1 && v <= 64) gp.rcap = v; }   // tuning hook
-}
-
-// Build the uniform cell list over the (single) target: bbox -> cell size -> counting sort.
-int grid_setup(kss_ctx* c, IcpPlan& pl) {
-    if (!pl.grid) return KSS_OK;
-    const PairGeom& g = pl.g[0];
-    const int nt = (int)g.nt, ns = (int)g.ns;
-    const int nbb = 64;
-    KCHK(ensure(c, c->g_bbox, (size_t)nbb * 6 * sizeof(float)));
-    const float4* tgt = (const float4*)c->tgt4.p + g.tgt_base;
-    ProfScope ps(c, KSS_K_GRID_BUILD);
-    launch_grid_bbox(c->stream, tgt, nt, (float*)c->g_bbox.p, nbb);
-    std::vector<float> hb((size_t)nbb * 6);
-    HIPCHK(c, hipMemcpyAsync(hb.data(), c->g_bbox.p, hb.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int b = 0; b < nbb; ++b)
-        for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], hb[(size_t)b * 6 + k]); mx[k] = std::max(mx[k], hb[(size_t)b * 6 + 3 + k]); }
-    if (!(std::isfinite(mn[0]) && std::isfinite(mn[1]) && std::isfinite(mn[2]) && std::isfinite(mx[0]) && std::isfinite(mx[1]) && std::isfinite(mx[2])))
-        return set_err(c, KSS_ERR_ARG, "non-finite target coordinates");
-    GridParams gp;
-    choose_cells(mn, mx, nt, gp);
-    pl.gp = gp;
-    const size_t ncells = (size_t)gp.gx * gp.gy * gp.gz;
-    KCHK(ensure(c, c->g_counts, ncells * sizeof(int32_t)));
-    KCHK(ensure(c, c->g_start, (ncells + 1) * sizeof(int32_t)));
-    KCHK(ensure(c, c->g_cursor, ncells * sizeof(int32_t)));
-    KCHK(ensure(c, c->g_bsums, ((ncells + 4095) / 4096 + 1) * sizeof(int32_t)));
-    KCHK(ensure(c, c->g_sorted, (size_t)nt * sizeof(float4)));
-    KCHK(ensure(c, c->g_list, (size_t)ns * sizeof(int32_t)));
-    KCHK(ensure(c, c->g_pos, (size_t)ns * sizeof(int32_t)));   // previous winner of every source: -1 = none yet
-    HIPCHK(c, hipMemsetAsync(c->g_pos.p, 0xff, (size_t)ns * sizeof(int32_t), c->stream));
-    KCHK(ensure_pub(c));
-    KCHK(ensure(c, c->g_count, 64));   // [0] unresolved-list length, [1] last-workgroup ticket
-    KCHK(ensure(c, c->g_partials, (size_t)grid_nn_blocks(ns) * NSUMS * sizeof(double)));
-    HIPCHK(c, hipMemsetAsync(c->g_count.p, 0, 64, c->stream));
-    {
-        PairState one;
-        std::memset(&one, 0, sizeof one);
-        one.active = 1;
-        HIPCHK(c, hipMemcpyAsync(c->state.p, &one, sizeof one, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
-    launch_grid_build(c->stream, tgt, nt, gp, (int32_t*)c->g_counts.p, (int32_t*)c->g_start.p, (int32_t*)c->g_cursor.p,
-                      (int32_t*)c->g_bsums.p, (float4*)c->g_sorted.p);
-    // sources into the same cell order (original index in .w): cur[0] is the scratch of the scatter
-    KCHK(ensure(c, c->g_start2, (ncells + 1) * sizeof(int32_t)));
-    launch_grid_sort_sources(c->stream, (const float4*)c->src0.p + g.src_base, ns, gp, (int32_t*)c->g_counts.p,
-                             (int32_t*)c->g_start2.p, (int32_t*)c->g_cursor.p, (int32_t*)c->g_bsums.p,
-                             (float4*)c->cur[0].p, (float4*)c->cur[1].p);
-    HIPCHK(c, hipMemcpyAsync((float4*)c->src0.p + g.src_base, c->cur[1].p, (size_t)ns * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipGetLastError());
-    c->grid_stats[0] = gp.h; c->grid_stats[1] = gp.gx; c->grid_stats[2] = gp.gy; c->grid_stats[3] = gp.gz;
-    if (c->stats_ns != ns || c->stats_nt != nt) { c->grid_stats[4] = 0; c->grid_stats[5] = 0; }
-    c->grid_stats[6] = ns; c->grid_stats[7] = nt;
-    if (c->prof && (c->stats_ns != ns || c->stats_nt != nt)) {   // one extra small kernel, once per problem size while profiling
-        c->stats_ns = ns; c->stats_nt = nt;
-        KCHK(ensure(c, c->scratch_c, 64));
-        HIPCHK(c, hipMemsetAsync(c->scratch_c.p, 0, 16, c->stream));
-        launch_grid_stats(c->stream, (const float4*)c->src0.p + g.src_base, ns, gp, (const int32_t*)c->g_start.p, (unsigned long long*)c->scratch_c.p);
-        unsigned long long hst[2] = {0, 0};
-        HIPCHK(c, hipMemcpyAsync(hst, c->scratch_c.p, 16, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->grid_stats[5] = (double)hst[0];
-        c->grid_stats[4] = (double)hst[1];
-    }
-    return KSS_OK;
-}
-
-// Batched cell lists: one per pair, all built by the same launches.
-int grid_setup_batch(kss_ctx* c, IcpPlan& pl) {
-    if (!pl.gridb) return KSS_OK;
-    const int np = pl.npairs;
-    std::vector<GridPairDev> hp(np);
-    int64_t sum_nt = 0;
-    for (int p = 0; p < np; ++p) {
-        std::memset(&hp[p], 0, sizeof(GridPairDev));
-        hp[p].tgt_base = pl.g[p].tgt_base; hp[p].tgt_n = (int32_t)pl.g[p].nt;
-        hp[p].src_base = pl.g[p].src_base; hp[p].src_n = (int32_t)pl.g[p].ns;
-        hp[p].tgt_pad = pl.g[p].tgt_pad;
-        sum_nt += pl.g[p].nt;
-    }
-    ProfScope ps(c, KSS_K_GRID_BUILD);
-    KCHK(ensure(c, c->g_pairs, (size_t)np * sizeof(GridPairDev)));
-    KCHK(ensure(c, c->g_bbox, (size_t)np * 6 * sizeof(float)));
-    HIPCHK(c, hipMemcpyAsync(c->g_pairs.p, hp.data(), (size_t)np * sizeof(GridPairDev), hipMemcpyHostToDevice, c->stream));
-    launch_gridb_bbox(c->stream, (const float4*)c->tgt4.p, (const GridPairDev*)c->g_pairs.p, np, (float*)c->g_bbox.p);
-    std::vector<float> hb((size_t)np * 6);
-    HIPCHK(c, hipMemcpyAsync(hb.data(), c->g_bbox.p, hb.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    int64_t cells = 0;
-    for (int p = 0; p < np; ++p) {
-        const float* b = &hb[(size_t)p * 6];
-        for (int k = 0; k < 6; ++k)
-            if (!std::isfinite(b[k])) return set_err(c, KSS_ERR_ARG, "non-finite target coordinates");
-        choose_cells(b, b + 3, pl.g[p].nt, hp[p].gp);
-        hp[p].cell_base = (int32_t)cells;
-        cells += (int64_t)hp[p].gp.gx * hp[p].gp.gy * hp[p].gp.gz;
-        if (cells > 0x7fff0000ll) return set_err(c, KSS_ERR_ARG, "batch cell lists exceed 32-bit indexing");
-    }
-    pl.total_cells = (int)cells;
-    HIPCHK(c, hipMemcpyAsync(c->g_pairs.p, hp.data(), (size_t)np * sizeof(GridPairDev), hipMemcpyHostToDevice, c->stream));
-    KCHK(ensure(c, c->g_counts, (size_t)cells * sizeof(int32_t)));
-    KCHK(ensure(c, c->g_start, ((size_t)cells + 1) * sizeof(int32_t)));
-    KCHK(ensure(c, c->g_start2, ((size_t)cells + 1) * sizeof(int32_t)));
-    KCHK(ensure(c, c->g_cursor, (size_t)cells * sizeof(int32_t)));
-    KCHK(ensure(c, c->g_bsums, (((size_t)cells + 4095) / 4096 + 1) * sizeof(int32_t)));
-    KCHK(ensure(c, c->g_sorted, (size_t)sum_nt * sizeof(float4)));
-    KCHK(ensure(c, c->g_pos, (size_t)pl.total_src * sizeof(int32_t)));   // previous winners: -1 = none yet
-    HIPCHK(c, hipMemsetAsync(c->g_pos.p, 0xff, (size_t)pl.total_src * sizeof(int32_t), c->stream));
-    if ((cells + 4095) / 4096 > 1024 * 16) return set_err(c, KSS_ERR_ARG, "batch cell lists too large for the scan");
-    launch_gridb_build_targets(c->stream, (const float4*)c->tgt4.p, (int)pl.total_tgt_pad, (const GridPairDev*)c->g_pairs.p, np,
-                               (int)cells, (int32_t*)c->g_counts.p, (int32_t*)c->g_start.p, (int32_t*)c->g_cursor.p,
-                               (int32_t*)c->g_bsums.p, (float4*)c->g_sorted.p);
-    launch_gridb_sort_sources(c->stream, (const float4*)c->src0.p, (int)pl.total_src, (const GridPairDev*)c->g_pairs.p, np, (int)cells,
-                              (int32_t*)c->g_counts.p, (int32_t*)c->g_start2.p, (int32_t*)c->g_cursor.p, (int32_t*)c->g_bsums.p,
-                              (float4*)c->cur[0].p, (float4*)c->cur[1].p);
-    HIPCHK(c, hipMemcpyAsync(c->src0.p, c->cur[1].p, (size_t)pl.total_src * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));   // hp/hb are about to go out of scope
-    return KSS_OK;
-}
-
-// Host-mapped result slots: PUB_PAIRS x NSUMS x {bits(sum), sequence number}.  The kernel that ends an ICP iteration
-// (fused grid_nn_kernel, or finalize_sums_kernel for small batches) stores every sum TOGETHER with the launch's
-// sequence number as one aligned 16-byte write: a slot whose sequence number matches holds this launch's value, so
-// there is no separate completion flag and no write-acknowledge round trip between "sums stored" and "flag stored"
-// on the device.
-constexpr int PUB_PAIRS = 32;   // batches up to this many pairs are awaited by spinning (more slots than that cost more to poll than a sync)
-int ensure_pub(kss_ctx* c) {
-    if (c->h_seq) return KSS_OK;
-    void* p = nullptr;
-    const size_t bytes = (size_t)PUB_PAIRS * NSUMS * 16;
-    if (hipHostMalloc(&p, bytes, hipHostMallocMapped) != hipSuccess) return set_err(c, KSS_ERR_NOMEM, "hipHostMalloc(result slots)");
-    c->h_seq = (unsigned long long*)p;
-    std::memset(p, 0, bytes);
-    void* d = nullptr;
-    HIPCHK(c, hipHostGetDevicePointer(&d, p, 0));
-    c->h_seq_dev = (unsigned long long*)d;
-    return KSS_OK;
-}
-
-// Wait for the first `npairs * NSUMS` slots to carry sequence number c->seq and copy the sums to h_sums, where the rest
-// of the loop expects them.  The host spins (a stream sync costs a 5-10 us wake-up per ICP iteration); after ~2 ms
-// without progress it falls back to the stream sync, which also surfaces a faulted kernel instead of spinning forever.
-int wait_seq(kss_ctx* c, int npairs = 1) {
-    const unsigned long long want = c->seq;
-    double* out = (double*)c->h_sums;
-    const int nslots = npairs * NSUMS;
-    auto collect = [&]() -> bool {
-        for (int k = nslots - 1; k >= 0; --k) {   // the highest slot is usually the last to land
-            if (__atomic_load_n(&c->h_seq[2 * k + 1], __ATOMIC_ACQUIRE) != want) return false;
-            const unsigned long long bits = __atomic_load_n(&c->h_seq[2 * k], __ATOMIC_RELAXED);
-            std::memcpy(&out[k], &bits, sizeof(double));
-        }
-        return true;
-    };
-    for (long spin = 0; spin < 2000000; ++spin) {
-        if (collect()) return KSS_OK;
-        __builtin_ia32_pause();
-    }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (!collect()) return set_err(c, KSS_ERR_HIP, "kernel finished without publishing its result");
-    return KSS_OK;
-}
-
-// One NN sweep + correspondence reduce over every active pair.  h_sums receives npairs*NSUMS.
-int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, float4* d_out, double max_d2,
-            int32_t* d_idx_out, float* d_d2_out) {
-    PairState* hs = (PairState*)c->h_state;
-    auto reduce = [&](const int32_t* unresolved, int32_t* reset) {
-        ProfScope ps(c, KSS_K_CORR_REDUCE);
-        launch_corr_reduce(c->stream, (const RedWork*)c->red_work.p, (int)pl.red.size(), (const PairState*)c->state.p,
-                           d_out, (const float4*)c->tgt4.p, (const unsigned long long*)c->keys.p, max_d2,
-                           (double*)c->partials.p, d_idx_out, d_d2_out, pl.src_in_cell_order ? 1 : 0);
-        // the last kernel of the pass writes the sums straight into host-mapped pinned memory
-        launch_finalize_sums(c->stream, (const PairRed*)c->pair_red.p, pl.npairs, (const double*)c->partials.p,
-                             (double*)c->h_sums_dev, unresolved, reset);
-    };
-    if (pl.grid) {
-        // single pair: the transform rides in the kernel arguments, the device-side state (active = 1) was
-        // uploaded once by grid_setup
-        unsigned long long* stamps = nullptr;
-        const int nblk = grid_nn_blocks((int)pl.g[0].ns);
-        if (getenv("KSS_GRID_STAMPS")) {   // diagnostic build of the timeline (tools/grid_stamps.py)
-            KCHK(ensure(c, c->g_stamps, (size_t)nblk * 16 * sizeof(unsigned long long)));
-            HIPCHK(c, hipMemsetAsync(c->g_stamps.p, 0, (size_t)nblk * 16 * sizeof(unsigned long long), c->stream));
-            stamps = (unsigned long long*)c->g_stamps.p;
-        }
-        const auto tl0 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-        {
-            ProfScope ps(c, KSS_K_GRID_NN);
-            // search + correspondence sums + final reduction in ONE launch; sums land in host-mapped memory
-            launch_grid_nn(c->stream, fma, hs[0], d_in, d_out, (int)pl.g[0].ns, pl.gp, (const int32_t*)c->g_start.p,
-                           (const float4*)c->g_sorted.p, (unsigned long long*)c->keys.p, (int32_t*)c->g_list.p, (int32_t*)c->g_count.p, max_d2,
-                           (double*)c->g_partials.p, (int32_t*)c->g_count.p + 1, d_idx_out, d_d2_out,
-                           ++c->seq, c->h_seq_dev, stamps, getenv("KSS_GRID_NOPREV") ? nullptr : (int32_t*)c->g_pos.p);
-        }
-        HIPCHK(c, hipGetLastError());
-        const auto tl1 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-        KCHK(wait_seq(c));
-        if (c->timing) {
-            const auto tl2 = std::chrono::steady_clock::now();
-            c->t_launch_us += std::chrono::duration<double, std::micro>(tl1 - tl0).count();
-            c->t_wait_us += std::chrono::duration<double, std::micro>(tl2 - tl1).count();
-        }
-        if (stamps) {
-            c->last_stamps.resize((size_t)nblk * 16);
-            HIPCHK(c, hipMemcpy(c->last_stamps.data(), stamps, c->last_stamps.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-            for (int b = 0; b < nblk; ++b) c->evals_sum += (double)c->last_stamps[(size_t)b * 16 + 10];
-            c->evals_launches += 1.0;
-        }
-        if (((const double*)c->h_sums)[NSUMS - 1] > 0.0) {
-            // queries the cell search gave up on (far from the target): brute-force sweep over the list,
-            // then the reduce again over every source
-            KCHK(stage_tables(c, pl));
-            {
-                ProfScope ps(c, KSS_K_NN_SWEEP);
-                launch_nn_sweep_list(c->stream, pl.S, fma, (const NNWork*)c->nn_work.p, (int)pl.nn.size(), (const PairState*)c->state.p,
-                                     d_out, (const float4*)c->tgt4.p, (unsigned long long*)c->keys.p, (const int32_t*)c->g_list.p,
-                                     (const int32_t*)c->g_count.p);
-            }
-            reduce((const int32_t*)c->g_count.p, (int32_t*)c->g_count.p);
-            HIPCHK(c, hipGetLastError());
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-        }
-        ((double*)c->h_sums)[NSUMS - 1] = 0.0;
-        return KSS_OK;
-    }
-    HIPCHK(c, hipMemcpyAsync(c->state.p, hs, (size_t)pl.npairs * sizeof(PairState), hipMemcpyHostToDevice, c->stream));
-    if (pl.gridb) {
-        // search + correspondence sums in one launch (one partial row per workgroup), then the per-pair row sums
-        {
-            ProfScope ps(c, KSS_K_GRID_NN);
-            launch_gridb_nn(c->stream, fma, (const RedWork*)c->red_work.p, (int)pl.red.size(), (const PairState*)c->state.p,
-                            (const GridPairDev*)c->g_pairs.p, d_in, d_out, (const int32_t*)c->g_start.p, (const float4*)c->g_sorted.p,
-                            (const float4*)c->tgt4.p, getenv("KSS_GRID_NOPREV") ? nullptr : (int32_t*)c->g_pos.p, max_d2, (double*)c->partials.p, d_idx_out, d_d2_out);
-        }
-        const bool spin = pl.npairs <= PUB_PAIRS;
-        {
-            ProfScope ps(c, KSS_K_CORR_REDUCE);
-            launch_finalize_sums(c->stream, (const PairRed*)c->pair_red.p, pl.npairs, (const double*)c->partials.p,
-                                 (double*)c->h_sums_dev, nullptr, nullptr, spin ? c->h_seq_dev : nullptr, spin ? ++c->seq : 0);
-        }
-        HIPCHK(c, hipGetLastError());
-        if (spin) KCHK(wait_seq(c, pl.npairs));
-        else HIPCHK(c, hipStreamSynchronize(c->stream));
-        return KSS_OK;
-    }
-    {
-        ProfScope ps(c, KSS_K_NN_SWEEP);
-        launch_nn_sweep(c->stream, pl.S, fma, (const NNWork*)c->nn_work.p, (int)pl.nn.size(), (const PairState*)c->state.p,
-                        d_in, d_out, (const float4*)c->tgt4.p, (unsigned long long*)c->keys.p);
-    }
-    const bool spin = pl.npairs <= PUB_PAIRS;
-    {
-        ProfScope ps(c, KSS_K_CORR_REDUCE);
-        launch_corr_reduce(c->stream, (const RedWork*)c->red_work.p, (int)pl.red.size(), (const PairState*)c->state.p,
-                           d_out, (const float4*)c->tgt4.p, (const unsigned long long*)c->keys.p, max_d2,
-                           (double*)c->partials.p, d_idx_out, d_d2_out, pl.src_in_cell_order ? 1 : 0);
-        launch_finalize_sums(c->stream, (const PairRed*)c->pair_red.p, pl.npairs, (const double*)c->partials.p,
-                             (double*)c->h_sums_dev, nullptr, nullptr, spin ? c->h_seq_dev : nullptr, spin ? ++c->seq : 0);
-    }
-    HIPCHK(c, hipGetLastError());
-    if (spin) KCHK(wait_seq(c, pl.npairs));
-    else HIPCHK(c, hipStreamSynchronize(c->stream));
-    return KSS_OK;
-}
-
-void set_state(PairState& s, const float T[16], int active, int apply) {
-    for (int k = 0; k < 12; ++k) s.m[k] = T[k];
-    s.active = active; s.apply = apply; s.pad[0] = s.pad[1] = 0;
-}
-
-// The ICP loop over a packed workspace (src0/tgt4 already filled).
-int icp_loop(kss_ctx* c, const IcpPlan& pl_in, const kss_icp_params& P, kss_icp_result* results) {
-    const IcpPlan* plan = &pl_in;   // may change to the brute-force plan below
-    IcpPlan brute_plan;
-    const int np = pl_in.npairs;
-    std::vector<Convergence> conv(np);
-    std::vector<float> fin((size_t)np * 16), Tk((size_t)np * 16);
-    std::vector<int> iters(np, 0), active(np, 1), converged(np, 0), state(np, 0);
-    std::vector<double> last_mse(np, 0.0);
-    PairState* hs = (PairState*)c->h_state;
-    float I[16];
-    mat4_identity(I);
-    for (int p = 0; p < np; ++p) {
-        Convergence& cv = conv[p];
-        cv.max_iterations = P.max_iterations;
-        cv.rotation_threshold = 1.0 - P.transformation_epsilon;
-        cv.translation_threshold = P.transformation_epsilon;
-        cv.mse_rel = P.euclidean_fitness_epsilon;
-        cv.mse_abs = P.abs_mse_epsilon;
-        cv.fixed_iterations = P.fixed_iterations != 0;
-        mat4_identity(&fin[(size_t)p * 16]);
-        set_state(hs[p], I, 1, 0);
-    }
-    const double max_d2 = P.max_corr_dist * P.max_corr_dist;
-    const double* hsum = (const double*)c->h_sums;
-    if (P.trace_n) *P.trace_n = 0;
-    int n_active = P.max_iterations > 0 ? np : 0;
-    if (P.max_iterations <= 0)
-        for (int p = 0; p < np; ++p) { active[p] = 0; }
-    int it = 0;
-    while (n_active > 0) {
-        const float4* d_in = it == 0 ? (const float4*)c->src0.p : (const float4*)c->cur[(it - 1) & 1].p;
-        float4* d_out = (float4*)c->cur[it & 1].p;
-        KCHK(nn_pass(c, *plan, P.nn_fma != 0, d_in, d_out, max_d2, nullptr, nullptr));
-        if (plan->gridb) {
-            // Batched cell lists: slot 19 counts the lanes that ended in the in-wave brute-force fallback.  When more
-            // than 10 % of the active sources did (badly posed pairs), the rest of this call runs on the brute-force
-            // engine, whose tiled sweep is several times faster at that job; the engines agree bit for bit on every
-            // correspondence, so the switch only changes speed.  The packed clouds stay where they are.
-            double fallback = 0.0, act = 0.0;
-            for (int p = 0; p < np; ++p)
-                if (active[p]) { fallback += hsum[(size_t)p * NSUMS + NSUMS - 1]; act += (double)plan->g[p].ns; }
-            if (fallback > 0.10 * act && !getenv("KSS_GRID_NOSWITCH")) {
-                std::vector<int64_t> ns(np), nt(np);
-                for (int p = 0; p < np; ++p) { ns[p] = plan->g[p].ns; nt[p] = plan->g[p].nt; }
-                KCHK(build_plan(c, ns.data(), nt.data(), np, false, P.nn_sources_per_thread, P.nn_target_splits, KSS_NN_BRUTE, brute_plan));
-                brute_plan.src_in_cell_order = true;
-                KCHK(stage_plan(c, brute_plan));
-                plan = &brute_plan;
-            }
-        }
-        // source rows split over ranks: the sums of all ranks, identical on every rank from here on
-        if (P.allreduce && P.allreduce(P.allreduce_user, (double*)c->h_sums, NSUMS) != 0)
-            return set_err(c, KSS_ERR_RCCL, "icp: the allreduce callback failed");
-        // per-pair solve + convergence test: pairs are independent (a large batch is split over a few host threads;
-        // each pair is handled by exactly one thread, so the results do not depend on the split)
-        std::atomic<int> finished{0};
-        auto solve = [&](int pb, int pe) {
-            int fin_here = 0;
-            for (int p = pb; p < pe; ++p) {
-                if (!active[p]) continue;
-                const double* s = hsum + (size_t)p * NSUMS;
-                if ((int)s[0] < P.min_correspondences) {   // PCL: "Not enough correspondences found"
-                    state[p] = KSS_STATE_NO_CORRESPONDENCES; converged[p] = 0; active[p] = 0; ++fin_here;
-                    set_state(hs[p], I, 0, 0);
-                    continue;
-                }
-                float* tk = &Tk[(size_t)p * 16];
-                rigid_from_sums(s, tk);
-                mat4_mul(tk, &fin[(size_t)p * 16], &fin[(size_t)p * 16]);   // final = transformation_ * final
-                ++iters[p];
-                const double mse = s[16] / s[0];
-                last_mse[p] = mse;
-                if (p == 0 && P.trace_n && *P.trace_n < P.trace_cap) {
-                    if (P.trace_sums) std::memcpy(P.trace_sums + (size_t)(*P.trace_n) * NSUMS, s, NSUMS * sizeof(double));
-                    if (P.trace_Tk) std::memcpy(P.trace_Tk + (size_t)(*P.trace_n) * 16, tk, 16 * sizeof(float));
-                    ++*P.trace_n;
-                }
-                const bool done = conv[p].has_converged(iters[p], tk, mse);
-                state[p] = conv[p].state;
-                if (done) {
-                    converged[p] = 1; active[p] = 0; ++fin_here;
-                    set_state(hs[p], tk, 0, 1);
-                } else {
-                    set_state(hs[p], tk, 1, 1);   // next sweep applies T_k on load (transformCloud)
-                }
-            }
-            finished.fetch_add(fin_here, std::memory_order_relaxed);
-        };
-        if (np >= 64) c->pool.parallel_for(np, solve);
-        else solve(0, np);
-        n_active -= finished.load(std::memory_order_relaxed);
-        ++it;
-    }
-    for (int p = 0; p < np; ++p) {
-        kss_icp_result& r = results[p];
-        std::memcpy(r.T, &fin[(size_t)p * 16], 16 * sizeof(float));
-        r.iterations = iters[p]; r.converged = converged[p]; r.state = state[p];
-        r.last_mse = last_mse[p]; r.fitness = 0.0; r.pair_id = p;
-    }
-    if (P.compute_fitness) {
-        // getFitnessScore(): NN of final * ORIGINAL input, mean d2 over all source points
-        for (int p = 0; p < np; ++p) set_state(hs[p], &fin[(size_t)p * 16], 1, 1);
-        int32_t* d_idx = nullptr;
-        float* d_d2 = nullptr;
-        if (P.fitness_idx || P.fitness_d2) {   // per-source correspondences of this pass (indexed by original source index)
-            KCHK(ensure(c, c->stage_idx, (size_t)plan->total_src * sizeof(int32_t)));
-            KCHK(ensure(c, c->stage_d2, (size_t)plan->total_src * sizeof(float)));
-            d_idx = (int32_t*)c->stage_idx.p; d_d2 = (float*)c->stage_d2.p;
-        }
-        KCHK(nn_pass(c, *plan, P.nn_fma != 0, (const float4*)c->src0.p, (float4*)c->cur[0].p, max_d2, d_idx, d_d2));
-        if (P.allreduce) {   // mean over ALL source rows of the job
-            double v[2] = {hsum[17], (double)plan->g[0].ns};
-            if (P.allreduce(P.allreduce_user, v, 2) != 0) return set_err(c, KSS_ERR_RCCL, "icp: the allreduce callback failed");
-            results[0].fitness = v[0] / v[1];
-        } else {
-            for (int p = 0; p < np; ++p) results[p].fitness = hsum[(size_t)p * NSUMS + 17] / (double)plan->g[p].ns;
-        }
-        if (d_idx) {
-            const size_t n0 = (size_t)plan->g[0].ns;
-            if (P.fitness_idx) HIPCHK(c, hipMemcpyAsync(P.fitness_idx, d_idx, n0 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-            if (P.fitness_d2) HIPCHK(c, hipMemcpyAsync(P.fitness_d2, d_d2, n0 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-        }
-    }
-    return KSS_OK;
-}
-
-int icp_run_dev(kss_ctx* c, const void* d_src, const int64_t* src_off, const void* d_tgt, const int64_t* tgt_off,
-                int npairs, bool shared_target, int dtype, const kss_icp_params* p, kss_icp_result* results) {
-    if (!c || !d_src || !d_tgt || !src_off || !tgt_off || !p || !results || npairs <= 0) return set_err(c, KSS_ERR_ARG, "icp: bad argument");
-    if (p->allreduce && npairs != 1) return set_err(c, KSS_ERR_ARG, "icp: the source-row split (allreduce) is for a single pair");
-    HIPCHK(c, hipSetDevice(c->device));
-    std::vector<int64_t> ns(npairs), nt(npairs);
-    for (int i = 0; i < npairs; ++i) {
-        ns[i] = src_off[i + 1] - src_off[i];
-        nt[i] = shared_target ? tgt_off[1] - tgt_off[0] : tgt_off[i + 1] - tgt_off[i];
-    }
-    IcpPlan pl;
-    const auto t0 = std::chrono::steady_clock::now();
-    KCHK(build_plan(c, ns.data(), nt.data(), npairs, shared_target, p->nn_sources_per_thread, p->nn_target_splits, p->nn_mode, pl));
-    KCHK(stage_plan(c, pl));
-    KCHK(pack_clouds(c, pl, d_src, src_off, d_tgt, tgt_off, dtype));
-    KCHK(grid_setup(c, pl));
-    KCHK(grid_setup_batch(c, pl));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    const auto t1 = std::chrono::steady_clock::now();
-    c->timing = getenv("KSS_TIMING") != nullptr;
-    c->t_launch_us = c->t_wait_us = 0;
-    const int rc = icp_loop(c, pl, *p, results);
-    const auto t2 = std::chrono::steady_clock::now();
-    c->last_setup_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
-    c->last_loop_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
-    if (c->timing)
-        std::fprintf(stderr, "[kss] setup %.3f ms, loop+fitness %.3f ms (fused launches: enqueue %.1f us, wait %.1f us, rest = host math)\n",
-                     c->last_setup_ms, c->last_loop_ms, c->t_launch_us, c->t_wait_us);
-    return rc;
-}
-
-// host -> device staging of a packed cloud
-int upload(kss_ctx* c, DevBuf& b, const void* h, size_t bytes) {
-    KCHK(ensure(c, b, bytes));
-    HIPCHK(c, hipMemcpyAsync(b.p, h, bytes, hipMemcpyHostToDevice, c->stream));
-    return KSS_OK;
-}
-
-}  // namespace
-
-// ---------------------------------------------------------------------------------------------
 // C-ABI: compute entry points
 // ---------------------------------------------------------------------------------------------
 extern "C" {
@@ -1045,25 +220,6 @@ int kss_icp_batch(kss_ctx* c, const float* src_all, const int64_t* src_off, cons
 }
 
 // ---- NN -----------------------------------------------------------------------------------------
-static int nn_generic_dev(kss_ctx* c, const void* d_src, int64_t ns, const void* d_tgt, int64_t nt, int dtype,
-                          int32_t* d_idx, float* d_d2, double sums_out[NSUMS]) {
-    if (!c || !d_src || !d_tgt) return set_err(c, KSS_ERR_ARG, "nn: null cloud");
-    if (ns <= 0 || nt <= 0) return set_err(c, KSS_ERR_ARG, "nn: empty cloud");
-    HIPCHK(c, hipSetDevice(c->device));
-    IcpPlan pl;
-    KCHK(build_plan(c, &ns, &nt, 1, false, 0, 0, KSS_NN_AUTO, pl));
-    KCHK(stage_plan(c, pl));
-    const int64_t so[2] = {0, ns}, to[2] = {0, nt};
-    KCHK(pack_clouds(c, pl, d_src, so, d_tgt, to, dtype));
-    KCHK(grid_setup(c, pl));
-    float I[16];
-    mat4_identity(I);
-    set_state(((PairState*)c->h_state)[0], I, 1, 0);
-    KCHK(nn_pass(c, pl, false, (const float4*)c->src0.p, (float4*)c->cur[0].p, 1e300, d_idx, d_d2));
-    if (sums_out) std::memcpy(sums_out, c->h_sums, NSUMS * sizeof(double));
-    return KSS_OK;
-}
-
 int kss_nn_dev(kss_ctx* c, const float* d_src, int64_t ns, const float* d_tgt, int64_t nt, int32_t* d_idx, float* d_d2) {
     return nn_generic_dev(c, d_src, ns, d_tgt, nt, KSS_F32, d_idx, d_d2, nullptr);
 }

@@ -1,0 +1,169 @@
+// kss_ctx.hpp -- the context behind the opaque kss_ctx of include/kssicp.h, and the small helpers every host-side
+// translation unit of libkssicp.so uses (error reporting, grow-only device buffers, pinned staging, HIP-event timing).
+// Internal to the library.
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "kss_internal.hpp"
+#include "kss_host_pool.hpp"
+
+using namespace kss;
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct kss_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    int nn_mode = KSS_NN_AUTO;
+    double grid_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double last_setup_ms = 0, last_loop_ms = 0;
+    double t_launch_us = 0, t_wait_us = 0, t_host_us = 0;   // KSS_TIMING breakdown of the fused single-pair loop
+    bool timing = false;
+    bool tables_staged = false;
+    int64_t stats_ns = -1, stats_nt = -1;
+
+    // grow-only device workspace
+    DevBuf tgt4, src0, cur[2], keys, partials, sums, nn_work, red_work, pair_red, state, cs, scratch_a,
+        scratch_b, scratch_c, stage_src, stage_tgt, stage_idx, stage_d2, stage_out, g_counts, g_start, g_cursor,
+        g_bsums, g_sorted, g_list, g_count, g_bbox, g_partials, g_start2, g_pairs, g_stamps, g_pos, pack_seg, reg_s, reg_t, reg_p, reg_all, reg_f, reg_g, oct_pts, oct_cen, oct_a, oct_b, oct_tmp;
+    HostPool pool;   // per-pair host work of batched iterations
+    std::vector<kss_ctx*> workers;   // contexts of kss_register_batch's worker threads (same device, own streams)
+    std::vector<unsigned long long> last_stamps;
+    double evals_sum = 0.0, evals_launches = 0.0;   // diagnostic runs: distance evaluations of the fused grid launches
+    // pinned host staging
+    void* h_sums = nullptr;  size_t h_sums_cap = 0;   // host-mapped: kernels write it through h_sums_dev
+    void* h_sums_dev = nullptr;
+    unsigned long long* h_seq = nullptr;       // host-mapped result of the fused grid kernel: NSUMS x {bits(sum), sequence number}
+    unsigned long long* h_seq_dev = nullptr;
+    unsigned long long seq = 0;
+    void* h_state = nullptr; size_t h_state_cap = 0;
+
+    // profiling
+    int prof = 0;                       // 0 = off, n = event-time every n-th launch of each kernel class
+    unsigned prof_tick[KSS_K_COUNT] = {};
+    struct EvPair { hipEvent_t a, b; };
+    std::vector<EvPair> ev[KSS_K_COUNT];
+    std::vector<EvPair> ev_pool;   // recycled event pairs: no hipEventCreate/Destroy inside timed loops
+    double prof_ms[KSS_K_COUNT] = {0};
+    int64_t prof_n[KSS_K_COUNT] = {0};
+};
+
+static inline int set_err(kss_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
+    if (c) {
+        c->err = what;
+        if (e != hipSuccess) { c->err += ": "; c->err += hipGetErrorString(e); }
+    }
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                        \
+    do {                                                                         \
+        hipError_t e_ = (call);                                                  \
+        if (e_ != hipSuccess) return set_err((ctx), KSS_ERR_HIP, #call, e_);     \
+    } while (0)
+
+static inline int ensure(kss_ctx* c, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return KSS_OK;
+    if (b.p) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(b.p));
+        b.p = nullptr; b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) { b.p = nullptr; return set_err(c, KSS_ERR_NOMEM, "hipMalloc", e); }
+    b.cap = want;
+    return KSS_OK;
+}
+
+static inline int ensure_pinned(kss_ctx* c, void*& p, size_t& cap, size_t bytes) {
+    if (bytes <= cap) return KSS_OK;
+    if (p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipHostFree(p)); p = nullptr; cap = 0; }
+    size_t want = bytes * 2 + 256;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocMapped);
+    if (e != hipSuccess) { p = nullptr; return set_err(c, KSS_ERR_NOMEM, "hipHostMalloc", e); }
+    cap = want;
+    if (&p == &c->h_sums) {
+        void* d = nullptr;
+        HIPCHK(c, hipHostGetDevicePointer(&d, p, 0));
+        c->h_sums_dev = d;
+    }
+    return KSS_OK;
+}
+
+#define KCHK(expr)                     \
+    do {                               \
+        int rc_ = (expr);              \
+        if (rc_ != KSS_OK) return rc_; \
+    } while (0)
+
+struct ProfScope {   // records a start/stop event pair around a launch when profiling is on
+    kss_ctx* c; int k; kss_ctx::EvPair ep; bool on;
+    ProfScope(kss_ctx* c_, int k_) : c(c_), k(k_), on(c_->prof > 0) {
+        if (on && c->prof > 1) on = (c->prof_tick[k]++ % (unsigned)c->prof) == 0;   // sampled: the events themselves cost ~3 us
+        if (!on) return;
+        if (!c->ev_pool.empty()) {
+            ep = c->ev_pool.back();
+            c->ev_pool.pop_back();
+        } else if (hipEventCreate(&ep.a) != hipSuccess || hipEventCreate(&ep.b) != hipSuccess) {
+            on = false;
+            return;
+        }
+        hipEventRecord(ep.a, c->stream);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        hipEventRecord(ep.b, c->stream);
+        c->ev[k].push_back(ep);
+    }
+};
+
+static inline void prof_collect(kss_ctx* c) {
+    for (int k = 0; k < KSS_K_COUNT; ++k) {
+        for (auto& ep : c->ev[k]) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) { c->prof_ms[k] += ms; c->prof_n[k] += 1; }
+            c->ev_pool.push_back(ep);
+        }
+        c->ev[k].clear();
+    }
+}
+
+
+// host -> device staging of a packed cloud
+static inline int upload(kss_ctx* c, DevBuf& b, const void* h, size_t bytes) {
+    KCHK(ensure(c, b, bytes));
+    HIPCHK(c, hipMemcpyAsync(b.p, h, bytes, hipMemcpyHostToDevice, c->stream));
+    return KSS_OK;
+}
+
+// ---- the registration engine (kss_engine.hip) ---------------------------------------------------------------
+namespace kss {
+// packs the clouds of npairs pairs (device pointers, point offsets), builds the search structures and runs the ICP loop
+int icp_run_dev(kss_ctx* c, const void* d_src, const int64_t* src_off, const void* d_tgt, const int64_t* tgt_off,
+                int npairs, bool shared_target, int dtype, const kss_icp_params* p, kss_icp_result* results);
+// one exact NN pass of a single pair (+ the correspondence sums when sums_out is given)
+int nn_generic_dev(kss_ctx* c, const void* d_src, int64_t ns, const void* d_tgt, int64_t nt, int dtype,
+                   int32_t* d_idx, float* d_d2, double sums_out[NSUMS]);
+}  // namespace kss

@@ -1,5 +1,5 @@
 // kss_internal.hpp -- shared declarations between the HIP kernels (kss_kernels.hip) and the
-// C-ABI / host drivers (kss_api.hip).  Product code; gfx950 only.
+// C-ABI / host drivers (kss_ctx.hpp, kss_engine.hip, kss_api.hip).  Product code; gfx950 only.
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -11,7 +11,7 @@
 //     code with the x bit most significant at every level, so that ASCENDING CODE == PCL's depth-first child order;
 //   * sort + unique of the codes (rocPRIM device radix sort / unique) = the occupied voxels in output order;
 //   * oct_center_kernel decodes them into voxel centres (genLeafNodeCenterFromOctreeKey);
-//   * the nearest cloud point of every centre is the exact NN engine of this library (kss_api.hip).
+//   * the nearest cloud point of every centre is the exact NN engine of this library (kss_engine.hip).
 #include <cstring>
 
 #include <hip/hip_runtime.h>
