@@ -59,14 +59,19 @@ for case in range(ncases):
     src = (tgt[pick].astype(np.float64) @ R.T + t + rng.normal(size=(ns, 3)) * jit).astype(np.float32)
     for iters in (int(rng.integers(1, 4)), int(rng.integers(4, 12))):
         kw = dict(max_iterations=iters, fixed_iterations=1, max_corr_dist=float(rng.choice([1.0, 0.05, 10.0])))
-        a = ctx.icp(src, tgt, ctx.icp_params(nn_mode=pkg.NN_GRID, **kw), fitness_corr=True)
-        b = ctx.icp(src, tgt, ctx.icp_params(nn_mode=pkg.NN_BRUTE, **kw), fitness_corr=True)
+        a = ctx.icp(src, tgt, ctx.icp_params(nn_mode=pkg.NN_GRID, **kw), fitness_corr=True, trace_cap=2)
+        b = ctx.icp(src, tgt, ctx.icp_params(nn_mode=pkg.NN_BRUTE, **kw), fitness_corr=True, trace_cap=2)
         same_T = np.array_equal(a["T"], b["T"])
         exact += int(same_T); loose += int(not same_T)
         if same_T:   # identical final transform: the last pass searched identical points
             ok = np.array_equal(a["fitness_idx"], b["fitness_idx"]) and np.array_equal(a["fitness_d2"].view(np.uint32), b["fitness_d2"].view(np.uint32))
-        else:        # f64 sums are grouped differently by the two engines: T may differ by an ulp, then compare loosely
-            ok = np.abs(a["T"] - b["T"]).max() < 1e-4 * max(1.0, np.abs(b["T"]).max()) or a["state"] != b["state"]
+        else:
+            # The f64 sums are grouped differently by the two engines (1e-16 relative): T may differ by an ulp -- or by a lot
+            # when the kept correspondences are few / nearly degenerate and the 3x3 SVD is ill-conditioned (seen: 41 of 30000
+            # within max_corr_dist, identical sums, rotations 0.25 apart).  What must hold is that the FIRST pass, which both
+            # engines run on identical points, found the same correspondences: same count, same sums to round-off.
+            sa, sb = a["trace_sums"][0][:19], b["trace_sums"][0][:19]
+            ok = sa[0] == sb[0] and np.abs(sa - sb).max() <= 1e-11 * max(1.0, np.abs(sb).max())
         if not ok:
             bad += 1
             print("MISMATCH case %d kind %s ns %d nt %d iters %d sameT %s diff idx %d" % (
