@@ -65,6 +65,8 @@ int kss_ctx_destroy(kss_ctx* c) {
         if (b->p) hipFree(b->p);
     if (c->h_sums) hipHostFree(c->h_sums);
     if (c->h_seq) hipHostFree(c->h_seq);
+    if (c->h_gate) hipHostFree(c->h_gate);
+    if (c->h_xf) hipHostFree(c->h_xf);
     if (c->h_state) hipHostFree(c->h_state);
     for (kss_ctx* w : c->workers) kss_ctx_destroy(w);
     c->workers.clear();

@@ -56,6 +56,19 @@ struct kss_ctx {
     void* h_sums_dev = nullptr;
     unsigned long long* h_seq = nullptr;       // host-mapped result of the fused grid kernel: NSUMS x {bits(sum), sequence number}
     unsigned long long* h_seq_dev = nullptr;
+    // gated launches (kss_engine.hip): the next iteration's fused kernel is enqueued behind a hipStreamWaitValue64 on
+    // h_gate while the current one runs; the host releases it by writing the transform to h_xf[slot] and then the gate
+    struct Gated {
+        int supported = -1;                 // -1 unknown, 0 no, 1 yes
+        bool want_next = false;             // set by the ICP loop: another regular iteration may follow this pass
+        bool pending = false;
+        int slot = 0;
+        unsigned long long gate_val = 0, seq = 0;
+        const void* d_in = nullptr; void* d_out = nullptr;
+        bool fma = false; double max_d2 = 0.0;
+    } gated;
+    unsigned long long* h_gate = nullptr; unsigned long long* h_gate_dev = nullptr;
+    PairState* h_xf = nullptr; PairState* h_xf_dev = nullptr;
     unsigned long long seq = 0;
     void* h_state = nullptr; size_t h_state_cap = 0;
 

@@ -340,7 +340,7 @@ void launch_grid_sort_sources(hipStream_t st, const float4* d_src, int n, const 
 //   Sources the search gives up on are excluded from the sums and counted in slot 19: the host then runs the
 //   brute-force list pass + the stand-alone reduce (rare: only for sources far from the target).
 template <bool FMA, int BS>
-__global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const float4* __restrict__ src_in,
+__global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps_arg, const float4* __restrict__ src_in,
                                                       float4* __restrict__ src_out, int ns, GridParams gp,
                                                       const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
                                                       unsigned long long* __restrict__ keys,
@@ -349,7 +349,8 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
                                                       int32_t* __restrict__ idx_out,
                                                       float* __restrict__ d2_out, unsigned long long seq,
                                                       unsigned long long* __restrict__ pub,
-                                                      unsigned long long* __restrict__ stamps, int32_t* __restrict__ pos_prev) {
+                                                      unsigned long long* __restrict__ stamps, int32_t* __restrict__ pos_prev,
+                                                      const PairState* __restrict__ ps_host) {
     // diagnostic stamps (100 MHz s_memrealtime; null in production): [block*16 + {0 start, 1 searched, 2 reduced,
     // 3 ticketed}], last workgroup also [4 result stored]; search phase: 6 source loaded,
     // 8 block scanned, 9 shells done; 10 = distance evaluations of the workgroup (a count)
@@ -357,6 +358,15 @@ __global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps, const f
     // search-phase stamps drain the wave's loads first, so they time the dependent round trips (diagnostic runs only)
 #define KSS_STAMPW(k) do { if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); KSS_STAMP(k); } } while (0)
     KSS_STAMP(0);
+    // The transform normally rides in the kernel arguments.  A launch that was enqueued BEFORE its transform existed
+    // (behind a hipStreamWaitValue64 gate, see kss_engine.hip) fetches it from host-mapped memory instead -- uniform
+    // address: scalar loads, one PCIe read per CU, overlapped with the source loads below -- and leaves at once when the
+    // host cancelled it (pad[0] != 0).
+    PairState ps = ps_arg;
+    if (ps_host) {
+        ps = *ps_host;
+        if (ps.pad[0] != 0) return;   // uniform
+    }
     constexpr int FG = BS / NSUMS;           // lane groups of the two column-sum stages below
     __shared__ double shf[FG][NSUMS];
     __shared__ int s_last;
@@ -830,21 +840,21 @@ static void grid_launch(hipStream_t st, dim3 grid, const PairState& state, const
                         const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted, unsigned long long* d_keys,
                         int32_t* d_list, int32_t* d_list_count, double max_d2, double* d_partials, int32_t* d_ticket,
                         int32_t* d_idx_out, float* d_d2_out, unsigned long long seq,
-                        unsigned long long* d_pub, unsigned long long* d_stamps, int32_t* d_pos) {
+                        unsigned long long* d_pub, unsigned long long* d_stamps, int32_t* d_pos, const PairState* d_ps_host) {
     hipLaunchKernelGGL((grid_nn_kernel<FMA, BS>), grid, dim3(BS), 0, st, state, d_src_in, d_src_out, ns, gp, d_cell_start,
                        d_sorted, d_keys, d_list, d_list_count, max_d2, d_partials, d_ticket, d_idx_out, d_d2_out, seq,
-                       d_pub, d_stamps, d_pos);
+                       d_pub, d_stamps, d_pos, d_ps_host);
 }
 
 void launch_grid_nn(hipStream_t st, bool fma, const PairState& state, const float4* d_src_in, float4* d_src_out, int ns,
                     const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted,
                     unsigned long long* d_keys, int32_t* d_list, int32_t* d_list_count, double max_d2, double* d_partials,
                     int32_t* d_ticket, int32_t* d_idx_out, float* d_d2_out, unsigned long long seq,
-                    unsigned long long* d_pub, unsigned long long* d_stamps, int32_t* d_pos) {
+                    unsigned long long* d_pub, unsigned long long* d_stamps, int32_t* d_pos, const PairState* d_ps_host) {
     const dim3 grid(grid_nn_blocks(ns));
     const int bs = grid_bs();
 #define KSS_GRID_ARGS st, grid, state, d_src_in, d_src_out, ns, gp, d_cell_start, d_sorted, d_keys, d_list, d_list_count, max_d2, \
-                      d_partials, d_ticket, d_idx_out, d_d2_out, seq, d_pub, d_stamps, d_pos
+                      d_partials, d_ticket, d_idx_out, d_d2_out, seq, d_pub, d_stamps, d_pos, d_ps_host
     if (fma) { if (bs == 256) grid_launch<true, 256>(KSS_GRID_ARGS); else grid_launch<true, 512>(KSS_GRID_ARGS); }
     else     { if (bs == 256) grid_launch<false, 256>(KSS_GRID_ARGS); else grid_launch<false, 512>(KSS_GRID_ARGS); }
 #undef KSS_GRID_ARGS

@@ -143,7 +143,8 @@ void launch_grid_nn(hipStream_t st, bool fma, const PairState& state, const floa
                     const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted,
                     unsigned long long* d_keys, int32_t* d_list, int32_t* d_list_count, double max_d2, double* d_partials,
                     int32_t* d_ticket, int32_t* d_idx_out, float* d_d2_out, unsigned long long seq,
-                    unsigned long long* d_pub /* host-mapped: NSUMS x {bits(sum), seq} */, unsigned long long* d_stamps, int32_t* d_pos);
+                    unsigned long long* d_pub /* host-mapped: NSUMS x {bits(sum), seq} */, unsigned long long* d_stamps, int32_t* d_pos,
+                    const PairState* d_ps_host = nullptr /* host-mapped transform of a gated launch, else the by-value state */);
 int grid_nn_blocks(int ns);
 void launch_gridb_bbox(hipStream_t st, const float4* d_tgt, const GridPairDev* d_pairs, int npairs, float* d_bbox);
 void launch_gridb_build_targets(hipStream_t st, const float4* d_tgt, int total_tgt_pad, const GridPairDev* d_pairs, int npairs,

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import ROOT, GOLDEN
 
 pytestmark = pytest.mark.gpu
 
@@ -435,3 +435,30 @@ def test_register_batch_equals_one_by_one(ctx, pkg, ref_pairs):
             assert np.array_equal(align[so[i]:so[i + 1]], o["pointAlign"])
     with pytest.raises(pkg.KssError):
         ctx.register_batch(src_all, np.array([0, 0, len(src_all)]), tgt_all, np.array([0, 10, len(tgt_all)]))      # an empty source
+
+
+def test_gated_launches_give_the_same_registration(ctx, pkg):
+    """KSS_GATED=1 (opt-in): the next iteration's fused kernel is enqueued behind a stream wait-value gate while the
+    current one runs and fetches its transform from host-mapped memory.  Same registration, bit for bit, including a run
+    that converges early (the pre-enqueued kernel is cancelled) and one that needs the brute-force fallback."""
+    import subprocess, sys, json
+    code = r"""
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as g
+pkg = g.load_package(); S = pkg.synth; ctx = pkg.Context(0)
+out = []
+for seed, n, deg, t in ((81, 30000, 8.0, (0.01, 0.0, 0.0)), (82, 12000, 25.0, (0.3, -0.2, 0.1))):
+    src, tgt = S.make_pair(seed, n, R=S.rot_axis_angle([0.2, 0.1, 1.0], np.deg2rad(deg)), t=t, shape="bumpy")
+    for kw in (dict(), dict(max_iterations=9, fixed_iterations=1)):
+        r = ctx.icp(src, tgt, ctx.icp_params(nn_mode=pkg.NN_GRID, **kw))
+        out.append([r["T"].tolist(), r["iterations"], r["fitness"]])
+print("RESULT" + json.dumps(out))
+""" % ROOT
+    res = {}
+    for gated in ("0", "1"):
+        env = dict(os.environ, KSS_GATED=gated)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        res[gated] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT")][0][6:])
+    assert res["0"] == res["1"]
