@@ -41,6 +41,7 @@ static int ctx_create_common(int device_id, void* stream, bool borrow, kss_ctx**
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return KSS_ERR_HIP; }
         c->own_stream = true;
     }
+    kss_live_contexts().fetch_add(1);
     *out = c;
     return KSS_OK;
 }
@@ -71,6 +72,7 @@ int kss_ctx_destroy(kss_ctx* c) {
     for (kss_ctx* w : c->workers) kss_ctx_destroy(w);
     c->workers.clear();
     if (c->own_stream) hipStreamDestroy(c->stream);
+    kss_live_contexts().fetch_sub(1);
     delete c;
     return KSS_OK;
 }

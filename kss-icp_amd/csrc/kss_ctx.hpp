@@ -164,6 +164,9 @@ static inline void prof_collect(kss_ctx* c) {
 }
 
 
+// live contexts of this process (gated launches are used only while there is exactly one: see kss_engine.hip)
+inline std::atomic<int>& kss_live_contexts() { static std::atomic<int> n{0}; return n; }
+
 // host -> device staging of a packed cloud
 static inline int upload(kss_ctx* c, DevBuf& b, const void* h, size_t bytes) {
     KCHK(ensure(c, b, bytes));

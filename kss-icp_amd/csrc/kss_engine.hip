@@ -384,6 +384,8 @@ static int ensure_pub(kss_ctx* c) {
 // Wait for the first `npairs * NSUMS` slots to carry sequence number c->seq and copy the sums to h_sums, where the rest
 // of the loop expects them.  The host spins (a stream sync costs a 5-10 us wake-up per ICP iteration); after ~2 ms
 // without progress it falls back to the stream sync, which also surfaces a faulted kernel instead of spinning forever.
+static void gated_cancel(kss_ctx* c);
+
 static int wait_seq(kss_ctx* c, int npairs = 1, unsigned long long want = 0) {
     if (!want) want = c->seq;
     double* out = (double*)c->h_sums;
@@ -400,6 +402,7 @@ static int wait_seq(kss_ctx* c, int npairs = 1, unsigned long long want = 0) {
         if (collect()) return KSS_OK;
         __builtin_ia32_pause();
     }
+    gated_cancel(c);   // a pre-enqueued launch behind a closed gate would make the synchronize below wait forever
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!collect()) return set_err(c, KSS_ERR_HIP, "kernel finished without publishing its result");
     return KSS_OK;
@@ -414,14 +417,18 @@ static int wait_seq(kss_ctx* c, int npairs = 1, unsigned long long want = 0) {
 // launch, 3.4 us through a gate.  A pre-enqueued kernel the loop does not need (convergence, the brute-force fallback,
 // an error) is CANCELLED: released with pad[0] = 1, it leaves at once.  Nothing ever waits on a cancelled kernel, and
 // no path returns with the gate closed (GatedGuard), so the stream cannot be left blocked.
-// OPT-IN (KSS_GATED=1): a closed gate blocks the hardware queue its stream is mapped to, and HIP multiplexes many
-// streams onto a few hardware queues -- work of ANOTHER stream or thread can sit behind it.  That is harmless as long as
-// the host never waits for such work before opening the gate (this loop does not), but a process that runs several
-// contexts whose hosts wait on each other (the two-rank test, kss_register_batch workers feeding one another) can
-// deadlock.  Measured gain at C2: +3 to +7 % iterations/s.
+// A closed gate blocks the hardware queue its stream is mapped to, and HIP multiplexes many streams onto a few hardware
+// queues -- work of ANOTHER stream or thread can sit behind it.  That is harmless as long as no host waits for such work
+// before the gate opens.  This loop never does, and the hazards it cannot see are excluded up front: gating is used
+// only on a stream the context owns, only while the context is the only one in the process (two gated loops could each
+// wait for a kernel parked behind the other's gate), never with an all-reduce callback (its collective would queue up
+// behind the gate), and the slow path of the wait (stream synchronize) cancels the gate first.  KSS_GATED=0 turns it off.
+// Measured at C2: +3 to +7 % iterations/s.
 static bool gated_available(kss_ctx* c) {
-    static const bool want = getenv("KSS_GATED") != nullptr && atoi(getenv("KSS_GATED")) != 0;
-    if (!want) return false;
+    static const bool want = getenv("KSS_GATED") == nullptr || atoi(getenv("KSS_GATED")) != 0;   // KSS_GATED=0 switches it off
+    // only on a stream this context owns, and only while it is the ONLY context of the process: two gated loops whose
+    // kernels share a hardware queue would each wait for a kernel parked behind the other's closed gate
+    if (!want || !c->own_stream || kss_live_contexts().load() != 1) return false;
     if (c->gated.supported < 0) {
         int can = 0;
         if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device) != hipSuccess) can = 0;
