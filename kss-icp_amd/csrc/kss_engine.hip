@@ -513,14 +513,17 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
             want_seq = c->seq;
         }
         HIPCHK(c, hipGetLastError());
-        if (G.want_next && !stamps && !d_idx_out && !d_d2_out && gated_available(c)) {
+        // HIP-event timing: a bracket behind the gate would also time the dispatch that follows the wait, so the launches
+        // the profiler samples (every n-th) are plain launches; the others advance its tick here
+        const bool next_sampled = c->prof == 1 || (c->prof > 1 && c->prof_tick[KSS_K_GRID_NN] % (unsigned)c->prof == 0);
+        if (G.want_next && !next_sampled && !stamps && !d_idx_out && !d_d2_out && gated_available(c)) {
+            if (c->prof > 1) ++c->prof_tick[KSS_K_GRID_NN];
             // enqueue the NEXT iteration behind the gate while this one runs: it reads what this pass writes (d_out) and
             // writes the other ping-pong buffer
             float4* nxt_out = d_out == (float4*)c->cur[0].p ? (float4*)c->cur[1].p : (float4*)c->cur[0].p;
             G.slot ^= 1;
             if (hipStreamWaitValue64(c->stream, c->h_gate_dev, G.gate_val + 1, hipStreamWaitValueGte, 0xffffffffffffffffull) == hipSuccess) {
                 {
-                    ProfScope ps(c, KSS_K_GRID_NN);   // (after the wait packet: the events bracket the kernel, not the wait)
                     launch_grid_nn(c->stream, fma, hs[0], d_out, nxt_out, (int)pl.g[0].ns, pl.gp, (const int32_t*)c->g_start.p,
                                    (const float4*)c->g_sorted.p, (unsigned long long*)c->keys.p, (int32_t*)c->g_list.p, (int32_t*)c->g_count.p, max_d2,
                                    (double*)c->g_partials.p, (int32_t*)c->g_count.p + 1, nullptr, nullptr,
