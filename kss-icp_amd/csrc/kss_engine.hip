@@ -275,12 +275,11 @@ static int grid_setup(kss_ctx* c, IcpPlan& pl) {
     KCHK(ensure(c, c->g_count, 64));   // [0] unresolved-list length, [1] last-workgroup ticket
     KCHK(ensure(c, c->g_partials, (size_t)grid_nn_blocks(ns) * NSUMS * sizeof(double)));
     HIPCHK(c, hipMemsetAsync(c->g_count.p, 0, 64, c->stream));
-    {
-        PairState one;
-        std::memset(&one, 0, sizeof one);
-        one.active = 1;
-        HIPCHK(c, hipMemcpyAsync(c->state.p, &one, sizeof one, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+    {   // device-side state of the pair (active, identity): read by the fallback kernels only; pinned source, no sync
+        PairState* one = (PairState*)c->h_state;
+        std::memset(one, 0, sizeof *one);
+        one->active = 1;
+        HIPCHK(c, hipMemcpyAsync(c->state.p, one, sizeof *one, hipMemcpyHostToDevice, c->stream));
     }
     launch_grid_build(c->stream, tgt, nt, gp, (int32_t*)c->g_counts.p, (int32_t*)c->g_start.p, (int32_t*)c->g_cursor.p,
                       (int32_t*)c->g_bsums.p, (float4*)c->g_sorted.p);
@@ -288,8 +287,7 @@ static int grid_setup(kss_ctx* c, IcpPlan& pl) {
     KCHK(ensure(c, c->g_start2, (ncells + 1) * sizeof(int32_t)));
     launch_grid_sort_sources(c->stream, (const float4*)c->src0.p + g.src_base, ns, gp, (int32_t*)c->g_counts.p,
                              (int32_t*)c->g_start2.p, (int32_t*)c->g_cursor.p, (int32_t*)c->g_bsums.p,
-                             (float4*)c->cur[0].p, (float4*)c->cur[1].p);
-    HIPCHK(c, hipMemcpyAsync((float4*)c->src0.p + g.src_base, c->cur[1].p, (size_t)ns * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+                             (float4*)c->cur[0].p, (float4*)c->src0.p + g.src_base);   // (scatter: src0 -> cur[0]; rank fix: cur[0] -> src0)
     HIPCHK(c, hipGetLastError());
     c->grid_stats[0] = gp.h; c->grid_stats[1] = gp.gx; c->grid_stats[2] = gp.gy; c->grid_stats[3] = gp.gz;
     if (c->stats_ns != ns || c->stats_nt != nt) { c->grid_stats[4] = 0; c->grid_stats[5] = 0; }

@@ -121,10 +121,27 @@ __global__ __launch_bounds__(1024) void scan_of_block_sums_kernel(int32_t* __res
     }
 }
 
+// SELF = true (up to 1024 chunks): the workgroup adds up the chunk totals before its own by itself and the last element
+// also writes start[n] -- two launches (scan_of_block_sums, scan_tail) less per scan, which matters when a whole cell-list
+// build is ~20 launches of a few microseconds each.
+template <bool SELF>
 __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restrict__ in, int n, const int32_t* __restrict__ block_sums,
                                                          int32_t* __restrict__ out_start, int32_t* __restrict__ cursor) {
     // each lane scans 16 consecutive elements, wave/LDS scan of the lane totals, plus the workgroup offset
     __shared__ int sh[256];
+    __shared__ int sh_off[4];
+    int offset = 0;
+    if constexpr (SELF) {
+        int part = 0;
+        for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) part += block_sums[b];   // RAW chunk totals here
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+        if ((threadIdx.x & 63) == 0) sh_off[threadIdx.x >> 6] = part;
+        __syncthreads();
+        offset = sh_off[0] + sh_off[1] + sh_off[2] + sh_off[3];
+    } else {
+        offset = block_sums[blockIdx.x];   // already an exclusive scan
+    }
     const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * 16;
     int v[16];
     int s = 0;
@@ -142,18 +159,31 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restri
         sh[threadIdx.x] += t;
         __syncthreads();
     }
-    int run = block_sums[blockIdx.x] + (threadIdx.x > 0 ? sh[threadIdx.x - 1] : 0);
+    int run = offset + (threadIdx.x > 0 ? sh[threadIdx.x - 1] : 0);
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int i = base + k;
         if (i < n) { out_start[i] = run; cursor[i] = run; }
         run += v[k];
+        if (SELF && i == n - 1) out_start[n] = run;   // the total
     }
 }
 
 __global__ void scan_tail_kernel(const int32_t* __restrict__ counts, int32_t* __restrict__ start, int n) {
     // start[n] = total = start[n-1] + counts[n-1]
     if (threadIdx.x == 0 && blockIdx.x == 0) start[n] = start[n - 1] + counts[n - 1];
+}
+
+static void launch_scan(hipStream_t st, const int32_t* d_counts, int ncells, int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums) {
+    const int nb = (ncells + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(256), 0, st, d_counts, ncells, d_block_sums);
+    if (nb <= 1024) {
+        hipLaunchKernelGGL(scan_apply_kernel<true>, dim3(nb), dim3(256), 0, st, d_counts, ncells, d_block_sums, d_start, d_cursor);
+    } else {
+        hipLaunchKernelGGL(scan_of_block_sums_kernel, dim3(1), dim3(1024), 0, st, d_block_sums, nb);
+        hipLaunchKernelGGL(scan_apply_kernel<false>, dim3(nb), dim3(256), 0, st, d_counts, ncells, d_block_sums, d_start, d_cursor);
+        hipLaunchKernelGGL(scan_tail_kernel, dim3(1), dim3(64), 0, st, d_counts, d_start, ncells);
+    }
 }
 
 __global__ __launch_bounds__(256) void grid_scatter_kernel(const float4* __restrict__ tgt, int n, GridParams gp,
@@ -173,11 +203,7 @@ void launch_grid_build(hipStream_t st, const float4* d_tgt, int n, const GridPar
     const int ncells = gp.gx * gp.gy * gp.gz;
     hipMemsetAsync(d_counts, 0, (size_t)ncells * sizeof(int32_t), st);
     hipLaunchKernelGGL(grid_count_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_tgt, n, gp, d_counts);
-    const int nb = (ncells + SCAN_CHUNK - 1) / SCAN_CHUNK;
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(256), 0, st, d_counts, ncells, d_block_sums);
-    hipLaunchKernelGGL(scan_of_block_sums_kernel, dim3(1), dim3(1024), 0, st, d_block_sums, nb);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, st, d_counts, ncells, d_block_sums, d_start, d_cursor);
-    hipLaunchKernelGGL(scan_tail_kernel, dim3(1), dim3(64), 0, st, d_counts, d_start, ncells);
+    launch_scan(st, d_counts, ncells, d_start, d_cursor, d_block_sums);
     hipLaunchKernelGGL(grid_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_tgt, n, gp, d_cursor, d_sorted);
 }
 
@@ -634,14 +660,6 @@ __global__ __launch_bounds__(256) void gridb_rank_fix_kernel(const float4* __res
     int rank = 0;
     for (int k = lo; k < hi; ++k) rank += __float_as_int(tmp[k].w) < me ? 1 : 0;
     out[lo + rank] = p;
-}
-
-static void launch_scan(hipStream_t st, const int32_t* d_counts, int ncells, int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums) {
-    const int nb = (ncells + SCAN_CHUNK - 1) / SCAN_CHUNK;
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(256), 0, st, d_counts, ncells, d_block_sums);
-    hipLaunchKernelGGL(scan_of_block_sums_kernel, dim3(1), dim3(1024), 0, st, d_block_sums, nb);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, st, d_counts, ncells, d_block_sums, d_start, d_cursor);
-    hipLaunchKernelGGL(scan_tail_kernel, dim3(1), dim3(64), 0, st, d_counts, d_start, ncells);
 }
 
 void launch_gridb_bbox(hipStream_t st, const float4* d_tgt, const GridPairDev* d_pairs, int npairs, float* d_bbox) {
