@@ -61,6 +61,7 @@ static int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npai
     int64_t tot = 0;
     for (int p = 0; p < npairs; ++p) {
         if (ns[p] <= 0 || nt[p] <= 0) return set_err(c, KSS_ERR_ARG, "empty cloud in ICP pair");
+        if (ns[p] > 0x7fff0000ll || nt[p] > 0x7fff0000ll) return set_err(c, KSS_ERR_ARG, "problem too large for 32-bit indexing");
         tot += ns[p];
     }
     int S = S_req;

@@ -293,6 +293,14 @@ def test_abi_rejects_bad_arguments(ctx, pkg):
     assert L.kss_ctx_set_nn_mode(ctx.h, 7) == -1
     assert b"" != L.kss_last_error(ctx.h)
     assert L.kss_ctx_create(99, C.byref(C.c_void_p())) == -1                      # no such device
+    # maximum sizes: more points than 32-bit indexing allows are refused before anything is touched (device-pointer entry
+    # points: the pointers below are never dereferenced)
+    res = pkg.IcpResult()
+    p = ctx.icp_params()
+    assert L.kss_nn_dev(ctx.h, vp(a), 3 * 10**9, vp(a), 10, None, None) == -1
+    assert L.kss_icp_dev(ctx.h, vp(a), 10, vp(a), 2**31 + 5, C.byref(p), C.byref(res)) == -1
+    assert b"too large" in L.kss_last_error(ctx.h)
+    assert L.kss_knn_dev(ctx.h, vp(a), 3 * 10**9, vp(a), 10, 4, vp(a), vp(a)) == -1
     assert L.kss_rigid_from_sums(vp(np.zeros(20)), vp(np.zeros(16, np.float32))) == -1         # zero correspondences
 
 
