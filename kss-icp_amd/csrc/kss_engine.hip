@@ -9,6 +9,7 @@
 
 namespace kss {
 
+constexpr int PUB_PAIRS = 32;   // batches up to this many pairs are awaited by spinning (more slots than that cost more to poll than a sync)
 static int ensure_pub(kss_ctx* c);   // host-mapped result slots (defined with wait_seq)
 
 struct PairGeom {
@@ -50,11 +51,12 @@ static int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npai
     pl.grid = nn_mode == KSS_NN_GRID || (nn_mode == KSS_NN_AUTO && npairs == 1 && nt[0] >= min_nt && ns[0] >= min_ns);
     if (npairs != 1) pl.grid = false;
     if (npairs > 1 && !shared_target) {
-        // batch: one cell list per pair.  Measured faster than the brute-force batch from 4 pairs x 600 points up
-        // (tools/batch_small.py); badly posed batches move back to brute force after one pass (icp_loop).
+        // batch: one cell list per pair.  Measured against the brute-force batch (tools/batch_small.py): brute force wins
+        // at 16 pairs x 600 points, they tie at 4 x 1500, the cell lists win from 16 x 1500 and 8 x 4000 up; badly posed
+        // batches move back to brute force after one pass (icp_loop).
         int64_t least_nt = nt[0], tot_ns = 0;
         for (int p = 0; p < npairs; ++p) { least_nt = std::min(least_nt, nt[p]); tot_ns += ns[p]; }
-        pl.gridb = nn_mode == KSS_NN_GRID || (nn_mode == KSS_NN_AUTO && least_nt >= min_nt && tot_ns >= 4 * min_ns);
+        pl.gridb = nn_mode == KSS_NN_GRID || (nn_mode == KSS_NN_AUTO && least_nt >= 2 * min_nt && tot_ns >= 32 * min_ns);
     }
     const bool any_grid = pl.grid || pl.gridb;
     pl.src_in_cell_order = any_grid;
@@ -65,11 +67,21 @@ static int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npai
         tot += ns[p];
     }
     int S = S_req;
-    if (S != 1 && S != 2 && S != 4 && S != 8) S = tot >= 32768 ? 4 : (tot >= 8192 ? 2 : 1);
+    int64_t max_tiles = 1;
+    for (int p = 0; p < npairs; ++p) max_tiles = std::max<int64_t>(max_tiles, (nt[p] + NN_TILE - 1) / NN_TILE);
+    auto blocks_for = [&](int s) { int64_t b = 0; for (int p = 0; p < npairs; ++p) b += (ns[p] + (int64_t)NN_THREADS * s - 1) / ((int64_t)NN_THREADS * s); return b; };
+    bool small = false;
+    if (S != 1 && S != 2 && S != 4 && S != 8) {
+        S = tot >= 32768 ? 4 : (tot >= 8192 ? 2 : 1);
+        // small problems (a few 1-2k-point pairs: the candidate batch of kss_register) cannot fill the chip even with one
+        // target tile per workgroup: fewer sources per lane and single-tile splits give 4x the workgroups (measured: the
+        // sweep of 14 pairs x 1.4k points 38 -> 10 us)
+        while (S > 1 && blocks_for(S) * max_tiles < 2048) S /= 2;
+        small = blocks_for(S) * max_tiles < 2048;
+    }
     pl.S = S;
     const int per_block = NN_THREADS * S;
-    int64_t src_blocks_total = 0;
-    for (int p = 0; p < npairs; ++p) src_blocks_total += (ns[p] + per_block - 1) / per_block;
+    const int64_t src_blocks_total = blocks_for(S);
     // enough workgroups to keep 256 CUs x 8 resident workgroups busy with >= 2 rounds
     int64_t want_split = 1;
     if (src_blocks_total < 2048) want_split = (4096 + src_blocks_total - 1) / src_blocks_total;
@@ -81,7 +93,7 @@ static int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npai
         PairGeom& g = pl.g[p];
         g.ns = ns[p]; g.nt = nt[p];
         const int64_t tiles = (nt[p] + NN_TILE - 1) / NN_TILE;
-        int64_t split = std::min<int64_t>(want_split, std::max<int64_t>(1, tiles / 2));
+        int64_t split = std::min<int64_t>(want_split, std::max<int64_t>(1, small ? tiles : tiles / 2));
         int64_t chunk_tiles = (tiles + split - 1) / split;
         split = (tiles + chunk_tiles - 1) / chunk_tiles;
         g.n_split = (int32_t)split;
@@ -181,6 +193,8 @@ static int stage_plan(kss_ctx* c, const IcpPlan& pl) {
     KCHK(ensure(c, c->red_work, pl.red.size() * sizeof(RedWork)));
     KCHK(ensure(c, c->pair_red, pl.pred.size() * sizeof(PairRed)));
     KCHK(ensure(c, c->state, (size_t)pl.npairs * sizeof(PairState)));
+    KCHK(ensure(c, c->pair_ticket, (size_t)std::max(pl.npairs, PUB_PAIRS) * sizeof(int32_t)));
+    HIPCHK(c, hipMemsetAsync(c->pair_ticket.p, 0, (size_t)std::max(pl.npairs, PUB_PAIRS) * sizeof(int32_t), c->stream));
     KCHK(ensure_pinned(c, c->h_sums, c->h_sums_cap, (size_t)pl.npairs * NSUMS * sizeof(double)));
     KCHK(ensure_pinned(c, c->h_state, c->h_state_cap, (size_t)pl.npairs * sizeof(PairState)));
     KCHK(ensure_pub(c));
@@ -366,7 +380,6 @@ static int grid_setup_batch(kss_ctx* c, IcpPlan& pl) {
 // sequence number as one aligned 16-byte write: a slot whose sequence number matches holds this launch's value, so
 // there is no separate completion flag and no write-acknowledge round trip between "sums stored" and "flag stored"
 // on the device.
-constexpr int PUB_PAIRS = 32;   // batches up to this many pairs are awaited by spinning (more slots than that cost more to poll than a sync)
 static int ensure_pub(kss_ctx* c) {
     if (c->h_seq) return KSS_OK;
     void* p = nullptr;
@@ -604,11 +617,18 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
     const bool spin = pl.npairs <= PUB_PAIRS;
     {
         ProfScope ps(c, KSS_K_CORR_REDUCE);
-        launch_corr_reduce(c->stream, (const RedWork*)c->red_work.p, (int)pl.red.size(), d_state,
-                           d_out, (const float4*)c->tgt4.p, (const unsigned long long*)c->keys.p, max_d2,
-                           (double*)c->partials.p, d_idx_out, d_d2_out, pl.src_in_cell_order ? 1 : 0);
-        launch_finalize_sums(c->stream, (const PairRed*)c->pair_red.p, pl.npairs, (const double*)c->partials.p,
-                             (double*)c->h_sums_dev, nullptr, nullptr, spin ? c->h_seq_dev : nullptr, spin ? ++c->seq : 0);
+        if (spin) {   // small batch: the reduce also adds each pair's rows up and publishes (pair tickets zeroed by stage_plan)
+            launch_corr_reduce_publish(c->stream, (const RedWork*)c->red_work.p, (int)pl.red.size(), d_state,
+                                       d_out, (const float4*)c->tgt4.p, (const unsigned long long*)c->keys.p, max_d2,
+                                       (double*)c->partials.p, d_idx_out, d_d2_out, pl.src_in_cell_order ? 1 : 0,
+                                       (const PairRed*)c->pair_red.p, (int32_t*)c->pair_ticket.p, c->h_seq_dev, ++c->seq);
+        } else {
+            launch_corr_reduce(c->stream, (const RedWork*)c->red_work.p, (int)pl.red.size(), d_state,
+                               d_out, (const float4*)c->tgt4.p, (const unsigned long long*)c->keys.p, max_d2,
+                               (double*)c->partials.p, d_idx_out, d_d2_out, pl.src_in_cell_order ? 1 : 0);
+            launch_finalize_sums(c->stream, (const PairRed*)c->pair_red.p, pl.npairs, (const double*)c->partials.p,
+                                 (double*)c->h_sums_dev, nullptr, nullptr, nullptr, 0);
+        }
     }
     HIPCHK(c, hipGetLastError());
     if (spin) KCHK(wait_seq(c, pl.npairs));

@@ -165,6 +165,11 @@ void launch_grid_sort_sources(hipStream_t st, const float4* d_src, int n, const 
 void launch_corr_reduce(hipStream_t st, const RedWork* d_work, int n_work, const PairState* d_state,
                         const float4* d_src, const float4* d_tgt4, const unsigned long long* d_keys,
                         double max_d2, double* d_partials, int32_t* d_idx_out, float* d_d2_out, int index_in_w);
+// small batches: reduce + per-pair final sum + publication in one launch (d_pair_ticket: one zeroed int per pair)
+void launch_corr_reduce_publish(hipStream_t st, const RedWork* d_work, int n_work, const PairState* d_state,
+                                const float4* d_src, const float4* d_tgt4, const unsigned long long* d_keys,
+                                double max_d2, double* d_partials, int32_t* d_idx_out, float* d_d2_out, int index_in_w,
+                                const PairRed* d_pair_red, int32_t* d_pair_ticket, unsigned long long* d_pub, unsigned long long seq);
 // idx-driven variant for kss_cov: d2 recomputed with the reference arithmetic
 void launch_corr_reduce_idx(hipStream_t st, const float* d_src3, const float* d_tgt3, const int32_t* d_idx,
                             int64_t n, double max_d2, double* d_partials, int n_blocks);

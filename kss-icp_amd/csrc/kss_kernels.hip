@@ -250,6 +250,11 @@ void launch_nn_sweep_list(hipStream_t st, int S, bool fma, const NNWork* d_work,
 // (c) correspondence reduce: merge the per-split keys, gather the matched target, accumulate the
 // 20 sums in f64 (wave shuffle reduce -> LDS -> one partial row per workgroup).
 // ---------------------------------------------------------------------------------------------
+// FUSE = true (small batches): the pair's last workgroup to finish also adds the pair's rows up and publishes the 20 sums
+// as {bits, seq} pairs into host-mapped memory -- one launch less per ICP pass than corr_reduce + finalize_sums.  The rows
+// are handed over as in grid_nn_kernel: write-through (sc1) stores, vmcnt(0), workgroup barrier, ONE agent-scope ticket;
+// the workgroup drawing the pair's last ticket reads every row with sc1 loads, in row order (bitwise reproducible).
+template <bool FUSE>
 __global__ __launch_bounds__(256) void corr_reduce_kernel(const RedWork* __restrict__ work,
                                                           const PairState* __restrict__ state,
                                                           const float4* __restrict__ src,
@@ -257,8 +262,11 @@ __global__ __launch_bounds__(256) void corr_reduce_kernel(const RedWork* __restr
                                                           const unsigned long long* __restrict__ keys,
                                                           double max_d2, double* __restrict__ partials,
                                                           int32_t* __restrict__ idx_out,
-                                                          float* __restrict__ d2_out, int index_in_w) {
+                                                          float* __restrict__ d2_out, int index_in_w,
+                                                          const PairRed* __restrict__ pair_red, int32_t* __restrict__ pair_ticket,
+                                                          unsigned long long* __restrict__ pub, unsigned long long seq) {
     __shared__ double sh[4][NSUMS];
+    __shared__ int s_last;
     const RedWork w = work[blockIdx.x];
     double acc[NSUMS];
 #pragma unroll
@@ -283,15 +291,69 @@ __global__ __launch_bounds__(256) void corr_reduce_kernel(const RedWork* __restr
         if (d2_out) d2_out[oi] = d2;
     }
     const double r = block_sum<NSUMS>(acc, sh);
-    if (t0 < NSUMS) partials[(int64_t)w.partial_index * NSUMS + t0] = r;
+    if constexpr (!FUSE) {
+        if (t0 < NSUMS) partials[(int64_t)w.partial_index * NSUMS + t0] = r;
+    } else {
+        const PairRed pr = pair_red[w.pair];
+        if (t0 < NSUMS) {
+            __hip_atomic_store(&partials[(int64_t)w.partial_index * NSUMS + t0], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (t0 == 0) s_last = atomicAdd(&pair_ticket[w.pair], 1) == pr.count - 1;
+        __syncthreads();
+        if (!s_last) return;
+        // column sums of the pair's rows, fixed order: lane (g, c) adds rows g, g + 12, ... (sc1 loads, eight in flight),
+        // then the 12 group totals are added in group order -- a 100k-source pair has ~400 rows
+        __shared__ double shg[ROWSUM_GROUPS][NSUMS];
+        {
+            const int g = t0 / NSUMS, c = t0 % NSUMS;
+            if (g < ROWSUM_GROUPS) {
+                double a = 0.0;
+                for (int k = g; k < pr.count; k += 8 * ROWSUM_GROUPS) {
+                    double tt[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        tt[j] = k + j * ROWSUM_GROUPS < pr.count
+                                    ? __hip_atomic_load(&partials[(int64_t)(pr.first + k + j * ROWSUM_GROUPS) * NSUMS + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                    : 0.0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a += tt[j];
+                }
+                shg[g][c] = a;
+            }
+        }
+        __syncthreads();
+        if (t0 < NSUMS) {
+            double v = 0.0;
+            for (int gg = 0; gg < ROWSUM_GROUPS; ++gg) v += shg[gg][t0];
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const unsigned long long vb = (unsigned long long)__double_as_longlong(v);
+            u32x4 o;
+            o.x = (unsigned)vb; o.y = (unsigned)(vb >> 32); o.z = (unsigned)seq; o.w = (unsigned)(seq >> 32);
+            unsigned long long* dst = pub + 2 * ((int64_t)w.pair * NSUMS + t0);
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(o) : "memory");
+        }
+        if (t0 == 0) pair_ticket[w.pair] = 0;   // re-arm for the next pass (stream order makes it visible)
+    }
 }
 
 void launch_corr_reduce(hipStream_t st, const RedWork* d_work, int n_work, const PairState* d_state,
                         const float4* d_src, const float4* d_tgt4, const unsigned long long* d_keys,
                         double max_d2, double* d_partials, int32_t* d_idx_out, float* d_d2_out, int index_in_w) {
     if (n_work <= 0) return;
-    hipLaunchKernelGGL(corr_reduce_kernel, dim3(n_work), dim3(256), 0, st, d_work, d_state, d_src, d_tgt4,
-                       d_keys, max_d2, d_partials, d_idx_out, d_d2_out, index_in_w);
+    hipLaunchKernelGGL(corr_reduce_kernel<false>, dim3(n_work), dim3(256), 0, st, d_work, d_state, d_src, d_tgt4,
+                       d_keys, max_d2, d_partials, d_idx_out, d_d2_out, index_in_w, (const PairRed*)nullptr, (int32_t*)nullptr,
+                       (unsigned long long*)nullptr, 0ull);
+}
+
+void launch_corr_reduce_publish(hipStream_t st, const RedWork* d_work, int n_work, const PairState* d_state,
+                                const float4* d_src, const float4* d_tgt4, const unsigned long long* d_keys,
+                                double max_d2, double* d_partials, int32_t* d_idx_out, float* d_d2_out, int index_in_w,
+                                const PairRed* d_pair_red, int32_t* d_pair_ticket, unsigned long long* d_pub, unsigned long long seq) {
+    if (n_work <= 0) return;
+    hipLaunchKernelGGL(corr_reduce_kernel<true>, dim3(n_work), dim3(256), 0, st, d_work, d_state, d_src, d_tgt4,
+                       d_keys, max_d2, d_partials, d_idx_out, d_d2_out, index_in_w, d_pair_red, d_pair_ticket, d_pub, seq);
 }
 
 // idx-driven variant behind kss_cov(): packed float3 clouds + an index array
