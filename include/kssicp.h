@@ -88,6 +88,10 @@ int kss_preshape_stats(kss_ctx *ctx, const void *xyz, int dtype, int64_t n,
                        double centroid[3], double *mean_radius);
 int kss_preshape_stats_dev(kss_ctx *ctx, const void *d_xyz, int dtype, int64_t n,
                            double centroid[3], double *mean_radius);
+/* both clouds of a registration (:144-207 computes S and T back to back) in ONE call: two launches for the pair, no
+ * stream synchronisation; bit-identical to one call per cloud.  d_tgt may be NULL (then c_tgt / r_tgt are not written). */
+int kss_preshape_stats_pair_dev(kss_ctx *ctx, const void *d_src, int64_t ns, const void *d_tgt, int64_t nt, int dtype,
+                                double c_src[3], double *r_src, double c_tgt[3], double *r_tgt);
 
 /* ---- (a3,a7) pose application: initRegistration_Rotation[_Angle], :75-109 + :365-404 ----
  * p += shift; p = center + (p - center) * scale; then Rx(angle[0]), Ry(angle[1]), Rz(angle[2])

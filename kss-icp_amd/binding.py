@@ -20,7 +20,7 @@ F32, F64 = 0, 1
 SYMBOLS = [
     "kss_version", "kss_status_string", "kss_last_error", "kss_ctx_create", "kss_ctx_create_on_stream",
     "kss_ctx_destroy", "kss_ctx_synchronize", "kss_ctx_stream", "kss_ctx_set_nn_mode", "kss_profile_enable", "kss_profile_reset",
-    "kss_profile_get", "kss_profile_event_overhead", "kss_grid_stats", "kss_preshape_stats", "kss_preshape_stats_dev", "kss_pose_apply", "kss_pose_apply_dev",
+    "kss_profile_get", "kss_profile_event_overhead", "kss_grid_stats", "kss_preshape_stats", "kss_preshape_stats_dev", "kss_preshape_stats_pair_dev", "kss_pose_apply", "kss_pose_apply_dev",
     "kss_nn", "kss_nn_dev", "kss_cov", "kss_cov_dev", "kss_rigid_from_sums", "kss_rotation_search",
     "kss_rotation_search_dev", "kss_grid_angles", "kss_rotation_candidates", "kss_icp_default_params", "kss_icp",
     "kss_icp_dev", "kss_icp_batch", "kss_icp_batch_dev", "kss_transform_apply", "kss_transform_apply_dev",
@@ -122,6 +122,7 @@ def load_library():
     L.kss_register_batch.argtypes = [vp, vp, vp, vp, vp, C.c_int, i64, dbl, C.c_int, C.c_int, vp, vp]
     for n in ("kss_preshape_stats", "kss_preshape_stats_dev"):
         getattr(L, n).argtypes = [vp, vp, C.c_int, i64, vp, C.POINTER(dbl)]
+    L.kss_preshape_stats_pair_dev.argtypes = [vp, vp, i64, vp, i64, C.c_int, vp, C.POINTER(dbl), vp, C.POINTER(dbl)]
     for n in ("kss_pose_apply", "kss_pose_apply_dev"):
         getattr(L, n).argtypes = [vp, vp, i64, C.POINTER(Pose), vp]
     for n in ("kss_nn", "kss_nn_dev"):
@@ -280,6 +281,13 @@ class Context:
         self._chk(self.L.kss_preshape_stats_dev(self.h, C.c_void_p(int(dptr)), dtype, int(n), _p(c), C.byref(r)), "kss_preshape_stats_dev")
         return c, r.value
 
+    def preshape_stats_pair_dev(self, d_src, ns, d_tgt, nt, dtype):
+        cs, ct = np.empty(3, np.float64), np.empty(3, np.float64)
+        rs, rt = C.c_double(0), C.c_double(0)
+        self._chk(self.L.kss_preshape_stats_pair_dev(self.h, C.c_void_p(int(d_src)), int(ns), C.c_void_p(int(d_tgt)), int(nt), dtype,
+                                                     _p(cs), C.byref(rs), _p(ct), C.byref(rt)), "kss_preshape_stats_pair_dev")
+        return (cs, rs.value), (ct, rt.value)
+
     # ---- (a7)
     @staticmethod
     def make_pose(shift, center, scale, angle):
@@ -294,6 +302,9 @@ class Context:
         out = np.empty_like(a)
         self._chk(self.L.kss_pose_apply(self.h, _p(a), len(a), C.byref(pose), _p(out)), "kss_pose_apply")
         return out
+
+    def pose_apply_dev(self, d_in, n, pose, d_out):
+        self._chk(self.L.kss_pose_apply_dev(self.h, C.c_void_p(int(d_in)), int(n), C.byref(pose), C.c_void_p(int(d_out))), "kss_pose_apply_dev")
 
     def transform_apply(self, T, pts):
         a = _f64(pts)

@@ -61,7 +61,7 @@ int kss_ctx_destroy(kss_ctx* c) {
     DevBuf* bufs[] = {&c->tgt4, &c->src0, &c->cur[0], &c->cur[1], &c->keys, &c->partials, &c->sums, &c->nn_work,
                       &c->red_work, &c->pair_red, &c->state, &c->cs, &c->scratch_a, &c->scratch_b, &c->scratch_c,
                       &c->stage_src, &c->stage_tgt, &c->stage_idx, &c->stage_d2, &c->stage_out, &c->g_counts, &c->g_start,
-                      &c->g_cursor, &c->g_bsums, &c->g_sorted, &c->g_list, &c->g_count, &c->g_bbox, &c->g_partials, &c->g_start2, &c->g_pairs, &c->g_stamps, &c->g_pos, &c->pack_seg, &c->reg_s, &c->reg_t, &c->reg_p, &c->reg_all, &c->reg_f, &c->reg_g, &c->oct_pts, &c->oct_cen, &c->oct_a, &c->oct_b, &c->oct_tmp, &c->pair_ticket};
+                      &c->g_cursor, &c->g_bsums, &c->g_sorted, &c->g_list, &c->g_count, &c->g_bbox, &c->g_partials, &c->g_start2, &c->g_pairs, &c->g_stamps, &c->g_pos, &c->pack_seg, &c->reg_s, &c->reg_t, &c->reg_p, &c->reg_all, &c->reg_f, &c->reg_g, &c->oct_pts, &c->oct_cen, &c->oct_a, &c->oct_b, &c->oct_tmp, &c->pair_ticket, &c->pre_partials, &c->pre_state};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (c->h_sums) hipHostFree(c->h_sums);
@@ -404,30 +404,45 @@ int kss_rigid_from_sums(const double sums[KSS_NSUMS], float T[16]) {
 }
 
 // ---- pre-shape ------------------------------------------------------------------------------------
-int kss_preshape_stats_dev(kss_ctx* c, const void* d_xyz, int dtype, int64_t n, double centroid[3], double* mean_radius) {
-    if (!c || !d_xyz || !centroid || !mean_radius) return set_err(c, KSS_ERR_ARG, "preshape: null argument");
-    if (n <= 0) return set_err(c, KSS_ERR_ARG, "preshape: empty cloud");
+// Both clouds of a registration in one call: two launches (sum + centroid, radius + publication), no stream
+// synchronisation -- the host spins on the {value, sequence number} slots the second launch writes.
+
+int kss_preshape_stats_pair_dev(kss_ctx* c, const void* d_src, int64_t ns, const void* d_tgt, int64_t nt, int dtype,
+                                double c_src[3], double* r_src, double c_tgt[3], double* r_tgt) {
+    if (!c || !d_src || !c_src || !r_src) return set_err(c, KSS_ERR_ARG, "preshape: null argument");
+    if (d_tgt && (!c_tgt || !r_tgt)) return set_err(c, KSS_ERR_ARG, "preshape: null argument");
+    if (ns <= 0 || (d_tgt && nt <= 0)) return set_err(c, KSS_ERR_ARG, "preshape: empty cloud");
     if (dtype != KSS_F32 && dtype != KSS_F64) return set_err(c, KSS_ERR_ARG, "preshape: bad dtype");
     HIPCHK(c, hipSetDevice(c->device));
-    const int nb = preshape_blocks(n);
-    KCHK(ensure(c, c->partials, (size_t)nb * 4 * sizeof(double)));
-    KCHK(ensure(c, c->sums, 8 * sizeof(double)));
-    KCHK(ensure_pinned(c, c->h_sums, c->h_sums_cap, 8 * sizeof(double)));
-    double* d_cent = (double*)c->sums.p;   // [0..2] centroid, [4] radius sum
+    const void* xyz[2] = {d_src, d_tgt};
+    const int64_t n[2] = {ns, d_tgt ? nt : 0};
+    const int nb = preshape_blocks(ns) + (d_tgt ? preshape_blocks(nt) : 0);
+    KCHK(ensure(c, c->pre_partials, (size_t)nb * 4 * sizeof(double)));
+    if (!c->pre_state.p) {
+        KCHK(ensure(c, c->pre_state, 128));   // [0, 16): four tickets, [64, 128): two centroids
+        HIPCHK(c, hipMemsetAsync(c->pre_state.p, 0, 128, c->stream));
+    }
+    KCHK(ensure_pub_slots(c));
     {
         ProfScope ps(c, KSS_K_PRESHAPE);
-        launch_preshape_sum(c->stream, d_xyz, dtype, n, (double*)c->partials.p, nb);
-        launch_preshape_centroid(c->stream, (const double*)c->partials.p, nb, n, d_cent);
-        launch_preshape_radius(c->stream, d_xyz, dtype, n, d_cent, (double*)c->partials.p, nb);
-        launch_sum_columns(c->stream, (const double*)c->partials.p, nb, 1, d_cent + 4);
+        launch_preshape_pair(c->stream, xyz, n, dtype, (double*)c->pre_partials.p, (int32_t*)c->pre_state.p,
+                             (double*)((char*)c->pre_state.p + 64), c->h_seq_dev, ++c->seq);
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->h_sums, d_cent, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    const double* h = (const double*)c->h_sums;
-    centroid[0] = h[0]; centroid[1] = h[1]; centroid[2] = h[2];
-    *mean_radius = h[4] / (double)n;
+    double h[8];
+    KCHK(wait_slots(c, d_tgt ? 8 : 4, h));
+    c_src[0] = h[0]; c_src[1] = h[1]; c_src[2] = h[2];
+    *r_src = h[3] / (double)ns;
+    if (d_tgt) {
+        c_tgt[0] = h[4]; c_tgt[1] = h[5]; c_tgt[2] = h[6];
+        *r_tgt = h[7] / (double)nt;
+    }
     return KSS_OK;
+}
+
+int kss_preshape_stats_dev(kss_ctx* c, const void* d_xyz, int dtype, int64_t n, double centroid[3], double* mean_radius) {
+    if (!c || !d_xyz || !centroid || !mean_radius) return set_err(c, KSS_ERR_ARG, "preshape: null argument");
+    return kss_preshape_stats_pair_dev(c, d_xyz, n, nullptr, 0, dtype, centroid, mean_radius, nullptr, nullptr);
 }
 
 int kss_preshape_stats(kss_ctx* c, const void* xyz, int dtype, int64_t n, double centroid[3], double* mean_radius) {
@@ -719,8 +734,7 @@ int kss_register(kss_ctx* c, const double* src_sub, int64_t nss, const double* t
     RCHK(ensure(c, dP, (size_t)nss * 3 * sizeof(double)));
     // (a2) pre-shape
     double cS[3], cT[3], rS, rT;
-    RCHK(kss_preshape_stats_dev(c, dS.p, KSS_F64, nss, cS, &rS));
-    RCHK(kss_preshape_stats_dev(c, dT.p, KSS_F64, nts, cT, &rT));
+    RCHK(kss_preshape_stats_pair_dev(c, dS.p, nss, dT.p, nts, KSS_F64, cS, &rS, cT, &rT));
     kss_pose pose;
     for (int k = 0; k < 3; ++k) { pose.shift[k] = cT[k] - cS[k]; pose.center[k] = cT[k]; pose.angle[k] = 0.0; }
     pose.scale = rT / rS;

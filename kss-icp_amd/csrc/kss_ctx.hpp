@@ -46,7 +46,7 @@ struct kss_ctx {
     // grow-only device workspace
     DevBuf tgt4, src0, cur[2], keys, partials, sums, nn_work, red_work, pair_red, state, cs, scratch_a,
         scratch_b, scratch_c, stage_src, stage_tgt, stage_idx, stage_d2, stage_out, g_counts, g_start, g_cursor,
-        g_bsums, g_sorted, g_list, g_count, g_bbox, g_partials, g_start2, g_pairs, g_stamps, g_pos, pack_seg, reg_s, reg_t, reg_p, reg_all, reg_f, reg_g, oct_pts, oct_cen, oct_a, oct_b, oct_tmp, pair_ticket;
+        g_bsums, g_sorted, g_list, g_count, g_bbox, g_partials, g_start2, g_pairs, g_stamps, g_pos, pack_seg, reg_s, reg_t, reg_p, reg_all, reg_f, reg_g, oct_pts, oct_cen, oct_a, oct_b, oct_tmp, pair_ticket, pre_partials, pre_state;
     HostPool pool;   // per-pair host work of batched iterations
     std::vector<kss_ctx*> workers;   // contexts of kss_register_batch's worker threads (same device, own streams)
     std::vector<unsigned long long> last_stamps;
@@ -182,4 +182,7 @@ int icp_run_dev(kss_ctx* c, const void* d_src, const int64_t* src_off, const voi
 // one exact NN pass of a single pair (+ the correspondence sums when sums_out is given)
 int nn_generic_dev(kss_ctx* c, const void* d_src, int64_t ns, const void* d_tgt, int64_t nt, int dtype,
                    int32_t* d_idx, float* d_d2, double sums_out[NSUMS]);
+// host-mapped {value, sequence number} result slots: allocate them; wait for the first nslots of launch c->seq
+int ensure_pub_slots(kss_ctx* c);
+int wait_slots(kss_ctx* c, int nslots, double* out);
 }  // namespace kss

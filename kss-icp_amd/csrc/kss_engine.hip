@@ -420,6 +420,27 @@ static int wait_seq(kss_ctx* c, int npairs = 1, unsigned long long want = 0) {
     return KSS_OK;
 }
 
+// the first `nslots` result slots of the launch with sequence number c->seq, as doubles (pre-shape statistics)
+int ensure_pub_slots(kss_ctx* c) { return ensure_pub(c); }
+int wait_slots(kss_ctx* c, int nslots, double* out) {
+    const unsigned long long want = c->seq;
+    auto collect = [&]() -> bool {
+        for (int k = nslots - 1; k >= 0; --k) {
+            if (__atomic_load_n(&c->h_seq[2 * k + 1], __ATOMIC_ACQUIRE) != want) return false;
+            const unsigned long long bits = __atomic_load_n(&c->h_seq[2 * k], __ATOMIC_RELAXED);
+            std::memcpy(&out[k], &bits, sizeof(double));
+        }
+        return true;
+    };
+    for (long spin = 0; spin < 2000000; ++spin) {
+        if (collect()) return KSS_OK;
+        __builtin_ia32_pause();
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // surfaces a faulted kernel instead of spinning forever
+    if (!collect()) return set_err(c, KSS_ERR_HIP, "kernel finished without publishing its result");
+    return KSS_OK;
+}
+
 // ---- gated launches of the fused single-pair pass -------------------------------------------------------------
 // Per ICP iteration the host has to see the sums, solve, and only then can the next launch carry the new transform:
 // hipLaunchKernel (~3 us on the host) and the dispatch that follows sit on the critical path.  With gating the NEXT

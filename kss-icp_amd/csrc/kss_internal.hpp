@@ -179,10 +179,9 @@ void launch_finalize_sums(hipStream_t st, const PairRed* d_pairs, int n_pairs, c
                           unsigned long long* d_pub = nullptr /* host-mapped {bits, seq} pairs, may be null */,
                           unsigned long long seq = 0);
 
-void launch_preshape_sum(hipStream_t st, const void* d_xyz, int dtype, int64_t n, double* d_partials, int n_blocks);
-void launch_preshape_centroid(hipStream_t st, const double* d_partials, int n_blocks, int64_t n, double* d_centroid);
-void launch_preshape_radius(hipStream_t st, const void* d_xyz, int dtype, int64_t n, const double* d_centroid,
-                            double* d_partials, int n_blocks);
+// pre-shape statistics of one or two clouds: two launches, result published to host-mapped {bits, seq} slots
+void launch_preshape_pair(hipStream_t st, const void* const d_xyz[2], const int64_t n[2], int dtype, double* d_partials,
+                          int32_t* d_tickets, double* d_cent, unsigned long long* d_pub, unsigned long long seq);
 void launch_sum_columns(hipStream_t st, const double* d_partials, int n_rows, int n_cols, double* d_out);
 void launch_row_sums(hipStream_t st, const double* d_partials, int n_rows, int n_cols, double scale, double* d_out);
 

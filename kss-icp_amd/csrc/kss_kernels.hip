@@ -420,7 +420,19 @@ void launch_finalize_sums(hipStream_t st, const PairRed* d_pairs, int n_pairs, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// (a) KSS pre-shape statistics (initRegistration_MiddleAlign): two streaming passes, f64.
+// (a) KSS pre-shape statistics (initRegistration_MiddleAlign, initRegistrationKSS.hpp:144-207): centroid and mean
+// distance to the centroid of ONE OR TWO clouds (source and target of a registration) in TWO launches and no stream
+// synchronisation:
+//   launch A  every workgroup sums its slice (f64) -> one partial row; the workgroup that draws the cloud's last
+//             ticket adds the rows in row order and stores centroid = sum / n;
+//   launch B  every workgroup sums sqrt(|p - centroid|^2) over the SAME slice (one IEEE f64 sqrt per point; the slice is
+//             still in that XCD's L2 at <= a few million points) -> partial row; the last workgroup of the cloud adds
+//             the rows and publishes {centroid, radius sum} as {bits, sequence number} 16-byte pairs into host-mapped
+//             memory, where the host spins on the sequence numbers (as the ICP loop does).
+// A kernel boundary (~2 us) is cheaper than a grid-wide barrier (4-7 us, MI355X_MICROARCH.md price list) and has no
+// co-residency requirement.  Row hand-off as in grid_nn_kernel: sc1 stores, vmcnt(0), workgroup barrier, one ticket.
+// The block decomposition of a cloud depends on its size only, so "both clouds in one call" and "one call per cloud"
+// give the same bits.
 // ---------------------------------------------------------------------------------------------
 int preshape_blocks(int64_t n) {
     int64_t b = (n + 255) / 256;
@@ -429,47 +441,171 @@ int preshape_blocks(int64_t n) {
     return (int)b;
 }
 
+struct PreCloud {
+    const void* xyz;
+    int64_t n;
+    int32_t first_block, n_blocks;
+    int32_t kind;      // 0: f64 triples, 1: f32 triples (scalar loads), 2: f32 read as a flat float4 stream
+    int32_t pad;
+};
+struct PreArgs { PreCloud c[2]; int32_t nclouds; };
+
 template <typename T>
-__global__ __launch_bounds__(256) void preshape_sum_kernel(const T* __restrict__ xyz, int64_t n,
-                                                           double* __restrict__ partials) {
-    __shared__ double sh[4][3];
-    double acc[3] = {0.0, 0.0, 0.0};
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+__device__ __forceinline__ void pre_sum_scalar(const T* __restrict__ xyz, int64_t n, int lb, int nb, double (&acc)[3]) {
+    for (int64_t i = (int64_t)lb * 256 + threadIdx.x; i < n; i += (int64_t)nb * 256) {
         acc[0] += (double)xyz[3 * i];
         acc[1] += (double)xyz[3 * i + 1];
         acc[2] += (double)xyz[3 * i + 2];
     }
-    const double r = block_sum<3>(acc, sh);
-    if (threadIdx.x < 3) partials[(int64_t)blockIdx.x * 3 + threadIdx.x] = r;
 }
 
-// centroid = (sum over partial rows) / n: 256 lanes stride over the rows, then a fixed-order block sum
-__global__ __launch_bounds__(256) void preshape_centroid_kernel(const double* __restrict__ partials, int n_blocks,
-                                                                int64_t n, double* __restrict__ centroid) {
-    __shared__ double sh[4][3];
-    double acc[3] = {0.0, 0.0, 0.0};
-    for (int r = threadIdx.x; r < n_blocks; r += 256) {
-        acc[0] += partials[(int64_t)r * 3];
-        acc[1] += partials[(int64_t)r * 3 + 1];
-        acc[2] += partials[(int64_t)r * 3 + 2];
+// f32 fast path: the cloud is read as a flat array of float4 (16 B per lane, fully coalesced).  float4 j holds flat
+// floats 4j..4j+3; flat float f belongs to coordinate f % 3, and 4 == 1 (mod 3), so element e of float4 j is
+// coordinate (j + e) % 3: the sum pass needs no regrouping at all.
+__device__ __forceinline__ void pre_sum_f32v(const float* __restrict__ xyz, int64_t n, int lb, int nb, double (&acc)[3]) {
+    const float4* __restrict__ v = (const float4*)xyz;
+    const int64_t nfloats = 3 * n, nf4 = nfloats / 4;
+#pragma unroll 4
+    for (int64_t j = (int64_t)lb * 256 + threadIdx.x; j < nf4; j += (int64_t)nb * 256) {
+        const float4 q = v[j];
+        const int m = (int)(j % 3);
+        const double e0 = (double)q.x, e1 = (double)q.y, e2 = (double)q.z, e3 = (double)q.w;
+        if (m == 0) { acc[0] += e0; acc[1] += e1; acc[2] += e2; acc[0] += e3; }
+        else if (m == 1) { acc[1] += e0; acc[2] += e1; acc[0] += e2; acc[1] += e3; }
+        else { acc[2] += e0; acc[0] += e1; acc[1] += e2; acc[2] += e3; }
     }
-    const double v = block_sum<3>(acc, sh);
-    if (threadIdx.x < 3) centroid[threadIdx.x] = v / (double)n;
+    if (lb == 0 && threadIdx.x == 0)
+        for (int64_t f = nf4 * 4; f < nfloats; ++f) acc[f % 3] += (double)xyz[f];   // < 4 trailing floats
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void preshape_radius_kernel(const T* __restrict__ xyz, int64_t n,
-                                                              const double* __restrict__ centroid,
-                                                              double* __restrict__ partials) {
-    __shared__ double sh[4][1];
-    const double cx = centroid[0], cy = centroid[1], cz = centroid[2];
-    double acc[1] = {0.0};
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+__device__ __forceinline__ double pre_radius_scalar(const T* __restrict__ xyz, int64_t n, int lb, int nb, double cx, double cy, double cz) {
+    double acc = 0.0;
+    for (int64_t i = (int64_t)lb * 256 + threadIdx.x; i < n; i += (int64_t)nb * 256) {
         const double xl = (double)xyz[3 * i] - cx, yl = (double)xyz[3 * i + 1] - cy, zl = (double)xyz[3 * i + 2] - cz;
-        acc[0] += sqrt((xl * xl + yl * yl) + zl * zl);
+        acc += sqrt((xl * xl + yl * yl) + zl * zl);
     }
+    return acc;
+}
+
+// radius pass of the float4 stream: lane j reads float4 j and j+1 (32 contiguous bytes; the second is the neighbour's
+// first: an L1/TA hit, memory traffic unchanged) and finishes the points that START inside float4 j: two when
+// j % 3 == 0, else one.
+__device__ __forceinline__ double pre_radius_f32v(const float* __restrict__ xyz, int64_t n, int lb, int nb, double cx, double cy, double cz) {
+    const float4* __restrict__ v = (const float4*)xyz;
+    const int64_t nf4 = (3 * n) / 4;
+    double acc = 0.0;
+    auto add = [&](float x, float y, float z) {
+        const double xl = (double)x - cx, yl = (double)y - cy, zl = (double)z - cz;
+        acc += sqrt((xl * xl + yl * yl) + zl * zl);
+    };
+    const int64_t nv = nf4 > 0 ? nf4 - 1 : 0;   // lanes that may read j + 1
+#pragma unroll 2
+    for (int64_t j = (int64_t)lb * 256 + threadIdx.x; j < nv; j += (int64_t)nb * 256) {
+        const float4 a = v[j], b = v[j + 1];
+        const int m = (int)(j % 3);
+        if (m == 0) { add(a.x, a.y, a.z); add(a.w, b.x, b.y); }
+        else if (m == 1) add(a.z, a.w, b.x);
+        else add(a.y, a.z, a.w);
+    }
+    if (lb == 0 && threadIdx.x == 0)   // points that start at or after float 4 * nv: at most three, or all of a tiny cloud
+        for (int64_t k = (4 * nv + 2) / 3; k < n; ++k) add(xyz[3 * k], xyz[3 * k + 1], xyz[3 * k + 2]);
+    return acc;
+}
+
+// hand the workgroup's row over and tell whether this workgroup drew the cloud's last ticket (then every row is visible
+// to its sc1 loads)
+template <int NV>
+__device__ __forceinline__ bool pre_row_handoff(double r, double* __restrict__ row, int32_t* __restrict__ ticket, int nb, int* s_last) {
+    if (threadIdx.x < NV) {
+        __hip_atomic_store(&row[threadIdx.x], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *s_last = atomicAdd(ticket, 1) == nb - 1;
+    __syncthreads();
+    return *s_last != 0;
+}
+
+// launch A.  partials: 4 doubles per workgroup of the launch; tickets[0..1]; cent: 4 doubles per cloud.
+__global__ __launch_bounds__(256) void preshape_sum_kernel(PreArgs a, double* __restrict__ partials, int32_t* __restrict__ tickets,
+                                                           double* __restrict__ cent) {
+    __shared__ double sh[4][3];
+    __shared__ int s_last;
+    const int ci = (a.nclouds > 1 && (int)blockIdx.x >= a.c[1].first_block) ? 1 : 0;
+    const PreCloud cl = a.c[ci];
+    const int lb = (int)blockIdx.x - cl.first_block, nb = cl.n_blocks;
+    double acc[3] = {0.0, 0.0, 0.0};
+    if (cl.kind == 0) pre_sum_scalar((const double*)cl.xyz, cl.n, lb, nb, acc);
+    else if (cl.kind == 2) pre_sum_f32v((const float*)cl.xyz, cl.n, lb, nb, acc);
+    else pre_sum_scalar((const float*)cl.xyz, cl.n, lb, nb, acc);
+    const double r = block_sum<3>(acc, sh);
+    if (!pre_row_handoff<3>(r, partials + (int64_t)blockIdx.x * 4, tickets + ci, nb, &s_last)) return;
+    // centroid = (sum over the cloud's rows, lanes striding the rows, then a fixed-order block sum) / n
+    double t[3] = {0.0, 0.0, 0.0};
+    for (int rr = threadIdx.x; rr < nb; rr += 256)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            t[k] += __hip_atomic_load(&partials[(int64_t)(cl.first_block + rr) * 4 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double v = block_sum<3>(t, sh);
+    if (threadIdx.x < 3) cent[ci * 4 + threadIdx.x] = v / (double)cl.n;
+    if (threadIdx.x == 0) tickets[ci] = 0;   // re-armed for the next call (stream order)
+}
+
+// launch B.  tickets[2..3]; pub: host-mapped {bits, seq} pairs, slots ci * 4 + {0,1,2: centroid, 3: sum of radii}.
+__global__ __launch_bounds__(256) void preshape_radius_kernel(PreArgs a, double* __restrict__ partials, int32_t* __restrict__ tickets,
+                                                              const double* __restrict__ cent, unsigned long long* __restrict__ pub,
+                                                              unsigned long long seq) {
+    __shared__ double sh[4][1];
+    __shared__ int s_last;
+    const int ci = (a.nclouds > 1 && (int)blockIdx.x >= a.c[1].first_block) ? 1 : 0;
+    const PreCloud cl = a.c[ci];
+    const int lb = (int)blockIdx.x - cl.first_block, nb = cl.n_blocks;
+    const double cx = cent[ci * 4], cy = cent[ci * 4 + 1], cz = cent[ci * 4 + 2];
+    double acc[1];
+    if (cl.kind == 0) acc[0] = pre_radius_scalar((const double*)cl.xyz, cl.n, lb, nb, cx, cy, cz);
+    else if (cl.kind == 2) acc[0] = pre_radius_f32v((const float*)cl.xyz, cl.n, lb, nb, cx, cy, cz);
+    else acc[0] = pre_radius_scalar((const float*)cl.xyz, cl.n, lb, nb, cx, cy, cz);
     const double r = block_sum<1>(acc, sh);
-    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+    if (!pre_row_handoff<1>(r, partials + (int64_t)blockIdx.x * 4, tickets + 2 + ci, nb, &s_last)) return;
+    double t[1] = {0.0};
+    for (int rr = threadIdx.x; rr < nb; rr += 256)
+        t[0] += __hip_atomic_load(&partials[(int64_t)(cl.first_block + rr) * 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double v = block_sum<1>(t, sh);
+    if (threadIdx.x < 4) {
+        const double o = threadIdx.x == 0 ? v : (threadIdx.x == 1 ? cx : (threadIdx.x == 2 ? cy : cz));
+        const int slot = ci * 4 + (threadIdx.x == 0 ? 3 : (int)threadIdx.x - 1);
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const unsigned long long vb = (unsigned long long)__double_as_longlong(o);
+        u32x4 w;
+        w.x = (unsigned)vb; w.y = (unsigned)(vb >> 32); w.z = (unsigned)seq; w.w = (unsigned)(seq >> 32);
+        unsigned long long* dst = pub + 2 * slot;
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(w) : "memory");
+    }
+    if (threadIdx.x == 0) tickets[2 + ci] = 0;
+}
+
+static bool f32_vector_ok(const void* p, int64_t n) { return ((uintptr_t)p & 15u) == 0 && n >= 1024; }
+
+// d_partials: 4 doubles per workgroup (preshape_blocks(n0) + preshape_blocks(n1)); d_tickets: 4 zeroed ints;
+// d_cent: 8 doubles; d_pub: 8 host-mapped {bits, seq} slots.  d_xyz[1] == nullptr: one cloud.
+void launch_preshape_pair(hipStream_t st, const void* const d_xyz[2], const int64_t n[2], int dtype, double* d_partials,
+                          int32_t* d_tickets, double* d_cent, unsigned long long* d_pub, unsigned long long seq) {
+    PreArgs a;
+    a.nclouds = d_xyz[1] ? 2 : 1;
+    int first = 0;
+    for (int k = 0; k < 2; ++k) {
+        PreCloud& c = a.c[k];
+        c.xyz = k < a.nclouds ? d_xyz[k] : nullptr;
+        c.n = k < a.nclouds ? n[k] : 0;
+        c.n_blocks = k < a.nclouds ? preshape_blocks(n[k]) : 0;
+        c.first_block = first;
+        c.kind = dtype == KSS_F64 ? 0 : (k < a.nclouds && f32_vector_ok(d_xyz[k], n[k]) ? 2 : 1);
+        c.pad = 0;
+        first += c.n_blocks;
+    }
+    hipLaunchKernelGGL(preshape_sum_kernel, dim3(first), dim3(256), 0, st, a, d_partials, d_tickets, d_cent);
+    hipLaunchKernelGGL(preshape_radius_kernel, dim3(first), dim3(256), 0, st, a, d_partials, d_tickets, (const double*)d_cent, d_pub, seq);
 }
 
 // out[c] = sum over rows of partials[r][c], n_cols <= NSUMS: lanes stride over the rows (many loads in flight)
@@ -485,83 +621,6 @@ __global__ __launch_bounds__(256) void sum_columns_kernel(const double* __restri
             if (c < n_cols) acc[c] += partials[(int64_t)r * n_cols + c];
     const double v = block_sum<NSUMS>(acc, sh);
     if ((int)threadIdx.x < n_cols) out[threadIdx.x] = v;
-}
-
-// ---- f32 fast path: the cloud is read as a flat array of float4 (16 B per lane, fully coalesced) -------------
-// float4 j holds flat floats 4j..4j+3; flat float f belongs to coordinate f % 3, and 4 == 1 (mod 3), so element e
-// of float4 j is coordinate (j + e) % 3: the sum pass needs no regrouping at all.
-__global__ __launch_bounds__(256) void preshape_sum_f32v_kernel(const float4* __restrict__ v, int64_t nf4, const float* __restrict__ xyz,
-                                                                int64_t nfloats, double* __restrict__ partials) {
-    __shared__ double sh[4][3];
-    double acc[3] = {0.0, 0.0, 0.0};
-#pragma unroll 4
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nf4; j += (int64_t)gridDim.x * blockDim.x) {
-        const float4 q = v[j];
-        const int m = (int)(j % 3);
-        // rotate: element e goes to coordinate (m + e) % 3
-        const double e0 = (double)q.x, e1 = (double)q.y, e2 = (double)q.z, e3 = (double)q.w;
-        if (m == 0) { acc[0] += e0; acc[1] += e1; acc[2] += e2; acc[0] += e3; }
-        else if (m == 1) { acc[1] += e0; acc[2] += e1; acc[0] += e2; acc[1] += e3; }
-        else { acc[2] += e0; acc[0] += e1; acc[1] += e2; acc[2] += e3; }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        for (int64_t f = nf4 * 4; f < nfloats; ++f) acc[f % 3] += (double)xyz[f];   // < 4 trailing floats
-    const double r = block_sum<3>(acc, sh);
-    if (threadIdx.x < 3) partials[(int64_t)blockIdx.x * 3 + threadIdx.x] = r;
-}
-
-// radius pass: lane j reads float4 j and j+1 (32 contiguous bytes; the second is the neighbour's first: an L1/TA
-// hit, HBM traffic unchanged) and finishes the points that START inside float4 j: two when j % 3 == 0, else one.
-__global__ __launch_bounds__(256) void preshape_radius_f32v_kernel(const float4* __restrict__ v, int64_t nf4, const float* __restrict__ xyz,
-                                                                   int64_t n, const double* __restrict__ centroid,
-                                                                   double* __restrict__ partials) {
-    __shared__ double sh[4][1];
-    const double cx = centroid[0], cy = centroid[1], cz = centroid[2];
-    double acc[1] = {0.0};
-    auto add = [&](float x, float y, float z) {
-        const double xl = (double)x - cx, yl = (double)y - cy, zl = (double)z - cz;
-        acc[0] += sqrt((xl * xl + yl * yl) + zl * zl);
-    };
-    const int64_t nv = nf4 > 0 ? nf4 - 1 : 0;   // lanes that may read j + 1
-#pragma unroll 2
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nv; j += (int64_t)gridDim.x * blockDim.x) {
-        const float4 a = v[j], b = v[j + 1];
-        const int m = (int)(j % 3);
-        if (m == 0) { add(a.x, a.y, a.z); add(a.w, b.x, b.y); }
-        else if (m == 1) add(a.z, a.w, b.x);
-        else add(a.y, a.z, a.w);
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        // points that start at or after float 4 * nv: at most three, plus everything if the cloud is tiny
-        for (int64_t k = (4 * nv + 2) / 3; k < n; ++k) add(xyz[3 * k], xyz[3 * k + 1], xyz[3 * k + 2]);
-    }
-    const double r = block_sum<1>(acc, sh);
-    if (threadIdx.x == 0) partials[blockIdx.x] = r;
-}
-
-static bool f32_vector_ok(const void* p, int64_t n) { return ((uintptr_t)p & 15u) == 0 && n >= 1024; }
-
-void launch_preshape_sum(hipStream_t st, const void* d_xyz, int dtype, int64_t n, double* d_partials, int n_blocks) {
-    if (dtype == KSS_F64)
-        hipLaunchKernelGGL(preshape_sum_kernel<double>, dim3(n_blocks), dim3(256), 0, st, (const double*)d_xyz, n, d_partials);
-    else if (f32_vector_ok(d_xyz, n))
-        hipLaunchKernelGGL(preshape_sum_f32v_kernel, dim3(n_blocks), dim3(256), 0, st, (const float4*)d_xyz, (3 * n) / 4,
-                           (const float*)d_xyz, 3 * n, d_partials);
-    else
-        hipLaunchKernelGGL(preshape_sum_kernel<float>, dim3(n_blocks), dim3(256), 0, st, (const float*)d_xyz, n, d_partials);
-}
-void launch_preshape_centroid(hipStream_t st, const double* d_partials, int n_blocks, int64_t n, double* d_centroid) {
-    hipLaunchKernelGGL(preshape_centroid_kernel, dim3(1), dim3(256), 0, st, d_partials, n_blocks, n, d_centroid);
-}
-void launch_preshape_radius(hipStream_t st, const void* d_xyz, int dtype, int64_t n, const double* d_centroid,
-                            double* d_partials, int n_blocks) {
-    if (dtype == KSS_F64)
-        hipLaunchKernelGGL(preshape_radius_kernel<double>, dim3(n_blocks), dim3(256), 0, st, (const double*)d_xyz, n, d_centroid, d_partials);
-    else if (f32_vector_ok(d_xyz, n))
-        hipLaunchKernelGGL(preshape_radius_f32v_kernel, dim3(n_blocks), dim3(256), 0, st, (const float4*)d_xyz, (3 * n) / 4,
-                           (const float*)d_xyz, n, d_centroid, d_partials);
-    else
-        hipLaunchKernelGGL(preshape_radius_kernel<float>, dim3(n_blocks), dim3(256), 0, st, (const float*)d_xyz, n, d_centroid, d_partials);
 }
 void launch_sum_columns(hipStream_t st, const double* d_partials, int n_rows, int n_cols, double* d_out) {
     hipLaunchKernelGGL(sum_columns_kernel, dim3(1), dim3(256), 0, st, d_partials, n_rows, n_cols, d_out);
