@@ -6,6 +6,7 @@ No CPU fallback: a missing library or GPU raises KssError.
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -98,6 +99,14 @@ def load_library():
     p = lib_path()
     if not os.path.exists(p):
         raise KssError(-4, "load_library", "libkssicp.so not built: run __graft_entry__.build() (no CPU fallback exists)")
+    # One HIP runtime per process: PyTorch ships its own libamdhip64.so; if libkssicp.so pulled in /opt/rocm's copy
+    # first, torch would later load a second runtime and see no devices.  Importing torch first (when it is installed)
+    # makes both resolve to the same library.  KSS_NO_TORCH=1 skips this for hosts that never use torch.
+    if "torch" not in sys.modules and not os.environ.get("KSS_NO_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(p)
     vp, i64, dbl = C.c_void_p, C.c_int64, C.c_double
     L.kss_version.restype = C.c_int

@@ -37,42 +37,122 @@ def test_transfer_table_parses():
     assert t["Bunny"] == ("x", 1.1) and t["ant"] == ("x", 1.56) and t["Horse"] == ("y", 1.1)
 
 
+ALL_TEN = ["Angel", "Armadillo", "Bunny", "Cat", "Dog", "Girl", "Horse", "ant", "hand", "woodMan"]
+SCALE_13 = ["Angel", "Armadillo", "Buddha", "Bunny", "Cat", "Dog", "Dragon", "Girl", "ant", "centuar", "giraffe", "hand", "woodMan"]
+# PS_AIS_Simplification/data/registration/ICP.txt:1-13 ("Hand", "WoodMan" there; file names are hand, woodMan)
+ICP_TXT = {"Armadillo": True, "Bunny": True, "Cat": True, "Girl": True, "hand": True, "Horse": True, "woodMan": True,
+           "Angel": False, "ant": False, "Dog": False}
+
+
+def _ref_npz(sub):
+    return np.load(os.path.join(GOLDEN, "ref_data", sub + "_all.npz"))
+
+
+def _down(O, P, m):
+    return P[O.aivs(P, m)]
+
+
+def _kss_pipeline(O, S, T):
+    """KSSICP_init + KSSICP_Registration (KSS_ICP.hpp:53-131): pNumber = min(n)/2 capped at 2000, AIVS both clouds
+    (target first), registration on the samples, pointAlign at full resolution."""
+    m = min(min(len(S), len(T)) // 2, 2000)
+    Ts = _down(O, T, m); Ss = _down(O, S, m)
+    return O.kssicp_register(Ss, Ts, S, 8.0, 1000)
+
+
+def test_ref_fixtures_hold_all_pairs():
+    d = _ref_npz("registration"); e = _ref_npz("registration_scale")
+    assert list(d["names"]) == ALL_TEN and list(e["names"]) == SCALE_13
+    assert set(_transfer_table()) == set(ALL_TEN) == set(ICP_TXT)
+    for sub, name in (("registration", "Bunny"), ("registration", "Horse"), ("registration", "ant"), ("registration_scale", "Bunny")):
+        z = _ref_npz(sub)      # the text copies kept for the CLI tests are the same data
+        for ext in ("gird", "wlop"):
+            t = np.loadtxt(os.path.join(GOLDEN, "ref_data", sub, name + "." + ext), skiprows=1)
+            assert np.array_equal(t, z[name + "_" + ext])
+
+
+@pytest.mark.parametrize("name", ALL_TEN)
+def test_kssicp_recovers_reference_rotation(O, name):
+    """PIN (first-party path + down-sampler + ICP end to end), all ten pairs of data/registration: the .gird cloud is the
+    model rotated about the world origin by transfer.txt's angle (transferPC.hpp:66-98); the whole KSSICP pipeline
+    (AIVS x2, pre-shape, 729-candidate search, candidate ICPs) must undo it.  Source and target are different
+    resamplings of the surface (grid vs WLOP), so the tolerance is the sampling noise, not float rounding.
+    Observed max |dR| over the ten: 0.0007 (ant) ... 0.0095 (Bunny)."""
+    d = _ref_npz("registration")
+    S, T = d[name + "_gird"], d[name + "_wlop"]
+    axis, ang = _transfer_table()[name]
+    r = _kss_pipeline(O, S, T)
+    assert np.abs(r["R"] - _axis_R(axis, -ang)).max() < 1.2e-2
+    assert abs(r["scale"] - 1.0) < 7e-2          # different resamplings: mean radius differs by a few percent (Dog: 1.062)
+    assert np.abs(r["t"]).max() < 2e-2
+    assert r["final_fitness"] < 2e-3
+    qm = O.pcr_qm(r["pointAlign"], T)
+    assert qm[0] < 2e-3 and abs(qm[1] - np.sqrt(qm[0])) < 1e-15
+
+
 @pytest.mark.parametrize("name", ["Bunny", "Horse", "ant"])
-def test_kssicp_recovers_reference_rotation(O, ref_pairs, name):
-    """The .gird source is the model rotated about the world origin by transfer.txt's angle
-    (transferPC.hpp:66-98); KSS-ICP must undo it.  Source/target are different resamplings of the
-    surface, so the tolerance is the sampling noise (~5e-3), not float rounding."""
+def test_kssicp_on_presampled_pairs(O, ref_pairs, name):
+    """The round-1 form of the pin (registration on the clouds as they are, no AIVS) kept for the three text fixtures."""
     S, T = ref_pairs[("registration", name)]
     axis, ang = _transfer_table()[name]
     r = O.kssicp_register(S, T, S, 8.0, 1000)
-    Rexp = _axis_R(axis, -ang)
-    assert np.abs(r["R"] - Rexp).max() < 8e-3
-    assert abs(r["scale"] - 1.0) < 2e-2
-    assert np.abs(r["t"]).max() < 1e-2
-    assert r["final_fitness"] < 1e-3
+    assert np.abs(r["R"] - _axis_R(axis, -ang)).max() < 8e-3
+    assert abs(r["scale"] - 1.0) < 2e-2 and np.abs(r["t"]).max() < 1e-2 and r["final_fitness"] < 1e-3
+
+
+@pytest.mark.parametrize("name", SCALE_13)
+def test_scale_pairs_register_and_preshape_is_idempotent(O, name):
+    """All 13 pairs of data/registration_scale (source additionally scaled about its centroid and translated by
+    (dis, dis, dis): transferPC.hpp:100-138).  (i) pre-shape is idempotent on size and centroid; (ii) the pipeline
+    registers every pair: fitness and PCR_QM MSE of two resamplings of one surface, a proper rotation, a scale between
+    0.25 and 4 (observed 0.67 .. 3.48; the rates and angles the authors used are recorded nowhere in the reference, so
+    there is no ground-truth transform to compare with: the pin is "registers", not "recovers")."""
+    d = _ref_npz("registration_scale")
+    S, T = d[name + "_gird"], d[name + "_wlop"]
+    ps = O.preshape_stats(S, T)
+    sp = O.similarity_apply(S, ps)
+    ps2 = O.preshape_stats(sp, T)
+    assert abs(ps2.scale - 1.0) < 1e-12 and np.abs(np.array(ps2.shift)).max() < 1e-12 * max(1.0, np.abs(T).max())
+    r = _kss_pipeline(O, S, T)
+    assert r["final_fitness"] < 1.2e-3
+    assert 0.25 < r["scale"] < 4.0
+    R = r["R"]
+    assert np.abs(R @ R.T - np.eye(3)).max() < 1e-5 and abs(np.linalg.det(R) - 1.0) < 1e-5
     qm = O.pcr_qm(r["pointAlign"], T)
-    assert qm[0] < 1e-3 and abs(qm[1] - np.sqrt(qm[0])) < 1e-15
+    assert qm[0] < 1.2e-3
 
 
 def test_scale_pair_preshape(O, ref_pairs):
     """registration_scale/Bunny: source also scaled + translated (transferPC.hpp:100-138)."""
     S, T = ref_pairs[("registration_scale", "Bunny")]
     ps = O.preshape_stats(S, T)
-    sp = O.similarity_apply(S, ps)
-    ps2 = O.preshape_stats(sp, T)
-    assert abs(ps2.scale - 1.0) < 1e-12          # pre-shape is idempotent on size ...
-    assert np.abs(np.array(ps2.shift)).max() < 1e-12   # ... and on centroid
     assert 0.5 < ps.scale < 0.9                  # source was enlarged ~1.5x (survey: 1.21 vs 0.81)
 
 
-def test_plain_icp_success_cases(O, ref_pairs):
-    """ICP.txt lists Bunny and Horse among the models plain ICP registers."""
-    for name in ("Bunny", "Horse"):
-        S, T = ref_pairs[("registration", name)]
-        axis, ang = _transfer_table()[name]
-        r = O.icp(S, T)
-        assert r["converged"]
-        assert np.abs(r["T"][:3, :3] - _axis_R(axis, -ang)).max() < 8e-3
+def _plain_icp_ok(O, src, tgt, Rexp):
+    r = O.icp(src, tgt)                          # the reference's settings: KSS_ICP.hpp:155-162
+    return bool(np.abs(r["T"][:3, :3] - Rexp).max() < 0.05), r
+
+
+def test_plain_icp_reproduces_reference_icp_txt(O):
+    """PIN of the PCL-1.8.1 ICP restatement at the only evidence the reference holds for it: ICP.txt lists which of the
+    ten models plain ICP registers (7) and which it does not (3).  TransferPC_ReturnPoints returns {wlop, gird}
+    (transferPC.hpp:125-133), i.e. source = the WLOP cloud, target = the rotated grid cloud; run that way
+    (pcl::IterativeClosestPoint settings of KSS_ICP.hpp:155-162) the restatement reproduces the list 10 / 10.
+    Run the other way round (gird -> wlop, the direction KSS-ICP's own rotation recovery uses above) it agrees on 6:
+    Cat and hand fail, Angel and ant register -- recorded here and in DESIGN.md section 3, not tuned."""
+    d = _ref_npz("registration")
+    tr = _transfer_table()
+    fwd, rev = {}, {}
+    for name in ALL_TEN:
+        S, T = d[name + "_gird"], d[name + "_wlop"]
+        axis, ang = tr[name]
+        rev[name], _ = _plain_icp_ok(O, T, S, _axis_R(axis, ang))      # wlop -> gird: ICP must FIND the rotation
+        fwd[name], _ = _plain_icp_ok(O, S, T, _axis_R(axis, -ang))     # gird -> wlop: ICP must UNDO it
+    assert rev == ICP_TXT
+    assert fwd == {"Angel": True, "Armadillo": True, "Bunny": True, "Cat": False, "Dog": False, "Girl": True, "Horse": True,
+                   "ant": True, "hand": False, "woodMan": True}
+    assert sum(fwd[n] == ICP_TXT[n] for n in ALL_TEN) == 6
 
 
 def test_grid_trip_counts(O):
