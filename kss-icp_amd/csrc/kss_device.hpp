@@ -76,6 +76,68 @@ __device__ __forceinline__ double rows_column_sum(const double* __restrict__ row
     return v;
 }
 
+// ---- the canonical summation order of the fused cell-list pass (grid_pass_kernel) ------------------------------
+// One ROW = the sums over one CHUNK of 512 consecutive (cell-sorted) sources of a pair: lane t holds source
+// 512 * chunk + t.  Per f64 column the row value is a fixed binary tree over the 64 lanes of each wave -- partners at lane
+// distance 32, then 16, 8, 4, 2, 1 -- followed by the 8 wave totals added in wave order.  The pair total adds the rows
+// k = g, g + 25, g + 50, ... sequentially for each of 25 groups g, then the 25 group totals in group order.  Everything
+// is a function of the pair's source count only, so a pair gives the same bits alone or inside a batch, whatever the
+// grid size, and IEEE addition being commutative the tree can be evaluated with any exchange primitive.
+constexpr int PASS_BS = 512;                  // lanes per workgroup == sources per chunk / row
+constexpr int PASS_FG = PASS_BS / NSUMS;      // 25 row groups of the pair total
+
+template <typename F>
+__device__ __forceinline__ double dpp_f64(double x, F f) {
+    const int lo = f(__double2loint(x)), hi = f(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+// value of lane (l ^ d) for d = 8, 4, 2, 1 (inside a row of 16 lanes: DPP, no LDS)
+__device__ __forceinline__ double xor8(double x) { return dpp_f64(x, [](int v) { return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false); }); }   // row_ror:8
+__device__ __forceinline__ double xor4(double x) {
+    return dpp_f64(x, [](int v) {
+        int r = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xf, 0x5, false);   // row_shl:4 into banks 0, 2 (lanes with bit 2 clear)
+        return __builtin_amdgcn_update_dpp(r, v, 0x114, 0xf, 0xa, false);    // row_shr:4 into banks 1, 3
+    });
+}
+__device__ __forceinline__ double xor2(double x) { return dpp_f64(x, [](int v) { return __builtin_amdgcn_update_dpp(v, v, 0x4e, 0xf, 0xf, false); }); }    // quad_perm [2,3,0,1]
+__device__ __forceinline__ double xor1(double x) { return dpp_f64(x, [](int v) { return __builtin_amdgcn_update_dpp(v, v, 0xb1, 0xf, 0xf, false); }); }    // quad_perm [1,0,3,2]
+
+// a: lanes with the distance bit clear keep a (and receive the partner's a); b: lanes with the bit set keep b.
+// Returns a_own + a_partner in the "clear" lanes and b_partner + b_own in the "set" lanes: one tree level of TWO
+// columns for the price of one (v_permlane32_swap / v_permlane16_swap exchange half-waves / odd-even rows in place).
+__device__ __forceinline__ double level32(double a, double b) {
+    unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a), blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    const auto r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    return __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
+}
+__device__ __forceinline__ double level16(double a, double b) {
+    unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a), blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    const auto r0 = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    return __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
+}
+__device__ __forceinline__ double tree_low4(double x) {   // levels 8, 4, 2, 1: every lane of a 16-lane row ends with the row total
+    x += xor8(x); x += xor4(x); x += xor2(x); x += xor1(x);
+    return x;
+}
+
+// Wave totals of 16 columns: afterwards lane 16 * q (q = 0..3) holds columns 4q .. 4q+3 in v[0..3].
+__device__ __forceinline__ void wave_tree16(double (&v)[16]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = level32(v[j], v[j + 8]);     // lanes < 32: columns 0-7, lanes >= 32: columns 8-15
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = level16(v[j], v[j + 4]);     // bit 4 clear: first four of those, set: the other four
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = tree_low4(v[j]);
+}
+// Wave totals of 2 columns: lane 0 holds a, lane 32 holds b (same tree per column as above).
+__device__ __forceinline__ double wave_tree2(double a, double b) {
+    double x = level32(a, b);
+    x = level16(x, x);
+    return tree_low4(x);
+}
+
 // correspondence sums of one (source, matched target) pair; see KSS_NSUMS in include/kssicp.h
 __device__ __forceinline__ void accumulate_corr(double (&acc)[NSUMS], float px, float py, float pz,
                                                 float qx, float qy, float qz, float d2f, double max_d2) {

@@ -9,8 +9,8 @@
 
 namespace kss {
 
-constexpr int PUB_PAIRS = 32;   // batches up to this many pairs are awaited by spinning (more slots than that cost more to poll than a sync)
-static int ensure_pub(kss_ctx* c);   // host-mapped result slots (defined with wait_seq)
+constexpr int PUB_PAIRS = 32;   // brute-force batches up to this many pairs are awaited by spinning on the published sums
+static int ensure_pub(kss_ctx* c, int npairs = PUB_PAIRS);   // host-mapped result slots (defined with wait_seq)
 
 struct PairGeom {
     int64_t ns, nt;
@@ -35,7 +35,12 @@ struct IcpPlan {
     bool src_in_cell_order = false;   // sources were re-ordered by a cell-list setup: .w carries the original index
     GridParams gp;
     int total_cells = 0;
+    // fused cell-list pass: one row (= workgroup = chunk of PASS_BS sorted sources) table, pair by pair
+    std::vector<GridPairDev> gpairs;
+    std::vector<int32_t> row_pair;
+    int total_rows = 0;
 };
+constexpr int PASS_CHUNK = 512;   // == PASS_BS of kss_device.hpp (device-only header)
 
 static int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npairs, bool shared_target,
                int S_req, int split_req, int nn_mode, IcpPlan& pl) {
@@ -114,6 +119,20 @@ static int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npai
             return set_err(c, KSS_ERR_ARG, "problem too large for 32-bit indexing");
     }
     pl.total_src = sb; pl.total_tgt_pad = tb; pl.total_keys = kb;
+    pl.gpairs.clear(); pl.row_pair.clear(); pl.total_rows = 0;
+    if (any_grid) {
+        pl.gpairs.resize(npairs);
+        for (int p = 0; p < npairs; ++p) {
+            GridPairDev& gd = pl.gpairs[p];
+            std::memset(&gd, 0, sizeof gd);
+            gd.tgt_base = pl.g[p].tgt_base; gd.tgt_n = (int32_t)pl.g[p].nt; gd.tgt_pad = pl.g[p].tgt_pad;
+            gd.src_base = pl.g[p].src_base; gd.src_n = (int32_t)pl.g[p].ns;
+            gd.row_base = pl.total_rows;
+            gd.n_rows = (int32_t)((pl.g[p].ns + PASS_CHUNK - 1) / PASS_CHUNK);
+            for (int r = 0; r < gd.n_rows; ++r) pl.row_pair.push_back(p);
+            pl.total_rows += gd.n_rows;
+        }
+    }
 
     pl.nn.clear(); pl.red.clear(); pl.pred.resize(npairs);
     int32_t prow = 0;
@@ -142,16 +161,8 @@ static int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npai
         // it wants many workgroups; the 240-lane final reduction handles hundreds of rows in a few microseconds)
         int64_t R = (g.ns + 256 * 512 - 1) / (256 * 512);   // <= ~512 partial rows per pair
         R = std::max<int64_t>(1, std::min<int64_t>(R, 64));
-        if (pl.gridb) {
-            // fused batched pass: a workgroup's 20-value block reduction costs about as much as searching 256 queries,
-            // so every workgroup takes up to 8 rounds of 256 queries (sums stay in registers) as long as the batch
-            // still yields ~2000 workgroups (C3: 27.8 -> 19.1 ms).  KSS_GRIDB_ROUNDS: tuning hook.
-            static const int64_t forced = [] { const char* e = getenv("KSS_GRIDB_ROUNDS"); const int64_t v = e ? atoll(e) : 0; return v >= 1 && v <= 64 ? v : 0; }();
-            const int64_t rounds = forced ? forced : std::max<int64_t>(1, std::min<int64_t>(8, tot / (256 * 2048)));
-            R = std::max<int64_t>(R, std::min<int64_t>(rounds, (g.ns + 255) / 256));
-        }
         const int64_t rchunk = 256 * R;
-        const int nrb = (int)((g.ns + rchunk - 1) / rchunk);
+        const int nrb = pl.gridb ? 0 : (int)((g.ns + rchunk - 1) / rchunk);   // (the batched cell lists reduce inside the fused pass)
         for (int b = 0; b < nrb; ++b) {
             RedWork r;
             r.pair = p;
@@ -187,7 +198,7 @@ static int stage_plan(kss_ctx* c, const IcpPlan& pl) {
     KCHK(ensure(c, c->cur[0], (size_t)pl.total_src * sizeof(float4)));
     KCHK(ensure(c, c->cur[1], (size_t)pl.total_src * sizeof(float4)));
     KCHK(ensure(c, c->keys, (size_t)pl.total_keys * sizeof(unsigned long long)));
-    KCHK(ensure(c, c->partials, pl.red.size() * NSUMS * sizeof(double)));
+    KCHK(ensure(c, c->partials, std::max<size_t>(pl.red.size(), (size_t)pl.total_rows) * NSUMS * sizeof(double)));
     KCHK(ensure(c, c->sums, (size_t)pl.npairs * NSUMS * sizeof(double)));
     KCHK(ensure(c, c->nn_work, pl.nn.size() * sizeof(NNWork)));
     KCHK(ensure(c, c->red_work, pl.red.size() * sizeof(RedWork)));
@@ -197,7 +208,7 @@ static int stage_plan(kss_ctx* c, const IcpPlan& pl) {
     HIPCHK(c, hipMemsetAsync(c->pair_ticket.p, 0, (size_t)std::max(pl.npairs, PUB_PAIRS) * sizeof(int32_t), c->stream));
     KCHK(ensure_pinned(c, c->h_sums, c->h_sums_cap, (size_t)pl.npairs * NSUMS * sizeof(double)));
     KCHK(ensure_pinned(c, c->h_state, c->h_state_cap, (size_t)pl.npairs * sizeof(PairState)));
-    KCHK(ensure_pub(c));
+    KCHK(ensure_pub(c, pl.npairs));
     c->tables_staged = false;
     if (!pl.grid) KCHK(stage_tables(c, pl));   // the fused cell-list path needs them only if a query falls back
     return KSS_OK;
@@ -279,24 +290,24 @@ static int grid_setup(kss_ctx* c, IcpPlan& pl) {
     pl.gp = gp;
     const size_t ncells = (size_t)gp.gx * gp.gy * gp.gz;
     KCHK(ensure(c, c->g_counts, ncells * sizeof(int32_t)));
-    KCHK(ensure(c, c->g_start, (ncells + 1) * sizeof(int32_t)));
+    KCHK(ensure(c, c->g_start, (ncells + 8) * sizeof(int32_t)));   // [0] pad, starts at [1 .. ncells + 1], pads behind (block_walk reads 16 bytes per row)
     KCHK(ensure(c, c->g_cursor, ncells * sizeof(int32_t)));
     KCHK(ensure(c, c->g_bsums, ((ncells + 4095) / 4096 + 1) * sizeof(int32_t)));
     KCHK(ensure(c, c->g_sorted, (size_t)nt * sizeof(float4)));
     KCHK(ensure(c, c->g_list, (size_t)ns * sizeof(int32_t)));
     KCHK(ensure(c, c->g_pos, (size_t)ns * sizeof(int32_t)));   // previous winner of every source: -1 = none yet
     HIPCHK(c, hipMemsetAsync(c->g_pos.p, 0xff, (size_t)ns * sizeof(int32_t), c->stream));
-    KCHK(ensure_pub(c));
-    KCHK(ensure(c, c->g_count, 64));   // [0] unresolved-list length, [1] last-workgroup ticket
-    KCHK(ensure(c, c->g_partials, (size_t)grid_nn_blocks(ns) * NSUMS * sizeof(double)));
+    KCHK(ensure(c, c->g_count, 64));   // [0] unresolved-list length
     HIPCHK(c, hipMemsetAsync(c->g_count.p, 0, 64, c->stream));
+    pl.gpairs[0].gp = gp;
+    pl.gpairs[0].cell_base = 0;
     {   // device-side state of the pair (active, identity): read by the fallback kernels only; pinned source, no sync
         PairState* one = (PairState*)c->h_state;
         std::memset(one, 0, sizeof *one);
         one->active = 1;
         HIPCHK(c, hipMemcpyAsync(c->state.p, one, sizeof *one, hipMemcpyHostToDevice, c->stream));
     }
-    launch_grid_build(c->stream, tgt, nt, gp, (int32_t*)c->g_counts.p, (int32_t*)c->g_start.p, (int32_t*)c->g_cursor.p,
+    launch_grid_build(c->stream, tgt, nt, gp, (int32_t*)c->g_counts.p, (int32_t*)c->g_start.p + 1, (int32_t*)c->g_cursor.p,
                       (int32_t*)c->g_bsums.p, (float4*)c->g_sorted.p);
     // sources into the same cell order (original index in .w): cur[0] is the scratch of the scatter
     KCHK(ensure(c, c->g_start2, (ncells + 1) * sizeof(int32_t)));
@@ -311,7 +322,7 @@ static int grid_setup(kss_ctx* c, IcpPlan& pl) {
         c->stats_ns = ns; c->stats_nt = nt;
         KCHK(ensure(c, c->scratch_c, 64));
         HIPCHK(c, hipMemsetAsync(c->scratch_c.p, 0, 16, c->stream));
-        launch_grid_stats(c->stream, (const float4*)c->src0.p + g.src_base, ns, gp, (const int32_t*)c->g_start.p, (unsigned long long*)c->scratch_c.p);
+        launch_grid_stats(c->stream, (const float4*)c->src0.p + g.src_base, ns, gp, (const int32_t*)c->g_start.p + 1, (unsigned long long*)c->scratch_c.p);
         unsigned long long hst[2] = {0, 0};
         HIPCHK(c, hipMemcpyAsync(hst, c->scratch_c.p, 16, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -325,15 +336,9 @@ static int grid_setup(kss_ctx* c, IcpPlan& pl) {
 static int grid_setup_batch(kss_ctx* c, IcpPlan& pl) {
     if (!pl.gridb) return KSS_OK;
     const int np = pl.npairs;
-    std::vector<GridPairDev> hp(np);
+    std::vector<GridPairDev>& hp = pl.gpairs;   // segments and rows filled by build_plan; cell lists chosen below
     int64_t sum_nt = 0;
-    for (int p = 0; p < np; ++p) {
-        std::memset(&hp[p], 0, sizeof(GridPairDev));
-        hp[p].tgt_base = pl.g[p].tgt_base; hp[p].tgt_n = (int32_t)pl.g[p].nt;
-        hp[p].src_base = pl.g[p].src_base; hp[p].src_n = (int32_t)pl.g[p].ns;
-        hp[p].tgt_pad = pl.g[p].tgt_pad;
-        sum_nt += pl.g[p].nt;
-    }
+    for (int p = 0; p < np; ++p) sum_nt += pl.g[p].nt;
     ProfScope ps(c, KSS_K_GRID_BUILD);
     KCHK(ensure(c, c->g_pairs, (size_t)np * sizeof(GridPairDev)));
     KCHK(ensure(c, c->g_bbox, (size_t)np * 6 * sizeof(float)));
@@ -355,7 +360,7 @@ static int grid_setup_batch(kss_ctx* c, IcpPlan& pl) {
     pl.total_cells = (int)cells;
     HIPCHK(c, hipMemcpyAsync(c->g_pairs.p, hp.data(), (size_t)np * sizeof(GridPairDev), hipMemcpyHostToDevice, c->stream));
     KCHK(ensure(c, c->g_counts, (size_t)cells * sizeof(int32_t)));
-    KCHK(ensure(c, c->g_start, ((size_t)cells + 1) * sizeof(int32_t)));
+    KCHK(ensure(c, c->g_start, ((size_t)cells + 8) * sizeof(int32_t)));   // [0] pad, starts at [1 ..], pads behind
     KCHK(ensure(c, c->g_start2, ((size_t)cells + 1) * sizeof(int32_t)));
     KCHK(ensure(c, c->g_cursor, (size_t)cells * sizeof(int32_t)));
     KCHK(ensure(c, c->g_bsums, (((size_t)cells + 4095) / 4096 + 1) * sizeof(int32_t)));
@@ -364,14 +369,16 @@ static int grid_setup_batch(kss_ctx* c, IcpPlan& pl) {
     HIPCHK(c, hipMemsetAsync(c->g_pos.p, 0xff, (size_t)pl.total_src * sizeof(int32_t), c->stream));
     if ((cells + 4095) / 4096 > 1024 * 16) return set_err(c, KSS_ERR_ARG, "batch cell lists too large for the scan");
     launch_gridb_build_targets(c->stream, (const float4*)c->tgt4.p, (int)pl.total_tgt_pad, (const GridPairDev*)c->g_pairs.p, np,
-                               (int)cells, (int32_t*)c->g_counts.p, (int32_t*)c->g_start.p, (int32_t*)c->g_cursor.p,
+                               (int)cells, (int32_t*)c->g_counts.p, (int32_t*)c->g_start.p + 1, (int32_t*)c->g_cursor.p,
                                (int32_t*)c->g_bsums.p, (float4*)c->g_sorted.p);
+    KCHK(ensure(c, c->g_rowpair, pl.row_pair.size() * sizeof(int32_t)));
+    HIPCHK(c, hipMemcpyAsync(c->g_rowpair.p, pl.row_pair.data(), pl.row_pair.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     launch_gridb_sort_sources(c->stream, (const float4*)c->src0.p, (int)pl.total_src, (const GridPairDev*)c->g_pairs.p, np, (int)cells,
                               (int32_t*)c->g_counts.p, (int32_t*)c->g_start2.p, (int32_t*)c->g_cursor.p, (int32_t*)c->g_bsums.p,
                               (float4*)c->cur[0].p, (float4*)c->cur[1].p);
     HIPCHK(c, hipMemcpyAsync(c->src0.p, c->cur[1].p, (size_t)pl.total_src * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));   // hp/hb are about to go out of scope
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // hb is about to go out of scope (pageable)
     return KSS_OK;
 }
 
@@ -380,12 +387,19 @@ static int grid_setup_batch(kss_ctx* c, IcpPlan& pl) {
 // sequence number as one aligned 16-byte write: a slot whose sequence number matches holds this launch's value, so
 // there is no separate completion flag and no write-acknowledge round trip between "sums stored" and "flag stored"
 // on the device.
-static int ensure_pub(kss_ctx* c) {
-    if (c->h_seq) return KSS_OK;
+static int ensure_pub(kss_ctx* c, int npairs) {
+    const size_t want = (size_t)std::max(npairs, PUB_PAIRS) * NSUMS * 16;
+    if (c->h_seq && want <= c->h_seq_bytes) return KSS_OK;
+    if (c->h_seq) {   // grow: nothing may still be writing the old slots
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipHostFree(c->h_seq));
+        c->h_seq = nullptr; c->h_seq_dev = nullptr; c->h_seq_bytes = 0;
+    }
     void* p = nullptr;
-    const size_t bytes = (size_t)PUB_PAIRS * NSUMS * 16;
+    const size_t bytes = want + want / 4;
     if (hipHostMalloc(&p, bytes, hipHostMallocMapped) != hipSuccess) return set_err(c, KSS_ERR_NOMEM, "hipHostMalloc(result slots)");
     c->h_seq = (unsigned long long*)p;
+    c->h_seq_bytes = bytes;
     std::memset(p, 0, bytes);
     void* d = nullptr;
     HIPCHK(c, hipHostGetDevicePointer(&d, p, 0));
@@ -398,25 +412,41 @@ static int ensure_pub(kss_ctx* c) {
 // without progress it falls back to the stream sync, which also surfaces a faulted kernel instead of spinning forever.
 static void gated_cancel(kss_ctx* c);
 
-static int wait_seq(kss_ctx* c, int npairs = 1, unsigned long long want = 0) {
-    if (!want) want = c->seq;
-    double* out = (double*)c->h_sums;
-    const int nslots = npairs * NSUMS;
-    auto collect = [&]() -> bool {
-        for (int k = nslots - 1; k >= 0; --k) {   // the highest slot is usually the last to land
-            if (__atomic_load_n(&c->h_seq[2 * k + 1], __ATOMIC_ACQUIRE) != want) return false;
-            const unsigned long long bits = __atomic_load_n(&c->h_seq[2 * k], __ATOMIC_RELAXED);
-            std::memcpy(&out[k], &bits, sizeof(double));
-        }
-        return true;
-    };
+// the 20 sums of pair p of launch `want`, if they have all landed
+static inline bool collect_pair(kss_ctx* c, int p, unsigned long long want) {
+    const unsigned long long* sl = c->h_seq + (size_t)2 * NSUMS * p;
+    if (__atomic_load_n(&sl[2 * (NSUMS - 1) + 1], __ATOMIC_ACQUIRE) != want) return false;   // the highest slot is usually the last to land
+    double* out = (double*)c->h_sums + (size_t)NSUMS * p;
+    for (int k = NSUMS - 1; k >= 0; --k) {
+        if (__atomic_load_n(&sl[2 * k + 1], __ATOMIC_ACQUIRE) != want) return false;
+        const unsigned long long bits = __atomic_load_n(&sl[2 * k], __ATOMIC_RELAXED);
+        std::memcpy(&out[k], &bits, sizeof(double));
+    }
+    return true;
+}
+
+// wait for pair p's sums (spin; after ~2 ms without them: open any gate, synchronize the stream, look once more)
+static int wait_pair(kss_ctx* c, int p, unsigned long long want) {
     for (long spin = 0; spin < 2000000; ++spin) {
-        if (collect()) return KSS_OK;
+        if (collect_pair(c, p, want)) return KSS_OK;
         __builtin_ia32_pause();
     }
-    gated_cancel(c);   // a pre-enqueued launch behind a closed gate would make the synchronize below wait forever
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (!collect()) return set_err(c, KSS_ERR_HIP, "kernel finished without publishing its result");
+    return KSS_ERR_HIP;   // the caller synchronizes (only one thread may) and retries
+}
+
+static int wait_seq(kss_ctx* c, int npairs = 1, unsigned long long want = 0, const int* active = nullptr) {
+    if (!want) want = c->seq;
+    bool slow = false;
+    for (int p = npairs - 1; p >= 0; --p) {
+        if (active && !active[p]) continue;
+        if (!slow && wait_pair(c, p, want) == KSS_OK) continue;
+        if (!slow) {
+            gated_cancel(c);   // a pre-enqueued launch behind a closed gate would make the synchronize below wait forever
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            slow = true;
+        }
+        if (!collect_pair(c, p, want)) return set_err(c, KSS_ERR_HIP, "kernel finished without publishing its result");
+    }
     return KSS_OK;
 }
 
@@ -504,34 +534,54 @@ struct GatedGuard {   // no exit from the ICP loop leaves a gate closed
     ~GatedGuard() { gated_cancel(c); c->gated.want_next = false; }
 };
 
-// One NN sweep + correspondence reduce over every active pair.  h_sums receives npairs*NSUMS.
+// arguments of the fused cell-list pass for this plan (single pair or batch)
+static PassArgs pass_args(kss_ctx* c, const IcpPlan& pl, const float4* d_in, float4* d_out, double max_d2,
+                          int32_t* d_idx_out, float* d_d2_out) {
+    PassArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.src_in = d_in; a.src_out = d_out;
+    a.cell_start = (const int32_t*)c->g_start.p + 1;
+    a.sorted = (const float4*)c->g_sorted.p;
+    a.tgt4 = (const float4*)c->tgt4.p;
+    a.pos_prev = (int32_t*)c->g_pos.p;
+    a.keys = (unsigned long long*)c->keys.p;
+    a.list = (int32_t*)c->g_list.p; a.list_count = (int32_t*)c->g_count.p;
+    a.total_rows = pl.total_rows;
+    static const bool noprev = getenv("KSS_GRID_NOPREV") != nullptr;   // A/B switch: the previous winner is stored but not used as a bound
+    a.use_prev = noprev ? 0 : 1;
+    a.max_d2 = max_d2;
+    a.rows = (double*)c->partials.p; a.tickets = (int32_t*)c->pair_ticket.p;
+    a.pub = c->h_seq_dev;
+    a.idx_out = d_idx_out; a.d2_out = d_d2_out;
+    if (pl.gridb) {
+        a.pairs = (const GridPairDev*)c->g_pairs.p;
+        a.row_pair = (const int32_t*)c->g_rowpair.p;
+    } else {
+        a.pair0 = pl.gpairs[0];
+    }
+    return a;
+}
+
+// One NN pass (search + correspondence sums) over every active pair.  h_sums receives npairs*NSUMS.
+// full: all 20 sums (the fitness / PCR_QM pass, traced runs); otherwise slots 17 and 18 stay 0 (an ICP iteration never
+// reads them: one f64 sqrt per source and two reduction columns less).  active: which pairs take part (null: all).
 static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, float4* d_out, double max_d2,
-            int32_t* d_idx_out, float* d_d2_out) {
+            int32_t* d_idx_out, float* d_d2_out, bool full, const int* active = nullptr) {
     PairState* hs = (PairState*)c->h_state;
-    auto reduce = [&](const int32_t* unresolved, int32_t* reset) {
-        ProfScope ps(c, KSS_K_CORR_REDUCE);
-        launch_corr_reduce(c->stream, (const RedWork*)c->red_work.p, (int)pl.red.size(), (const PairState*)c->state.p,
-                           d_out, (const float4*)c->tgt4.p, (const unsigned long long*)c->keys.p, max_d2,
-                           (double*)c->partials.p, d_idx_out, d_d2_out, pl.src_in_cell_order ? 1 : 0);
-        // the last kernel of the pass writes the sums straight into host-mapped pinned memory
-        launch_finalize_sums(c->stream, (const PairRed*)c->pair_red.p, pl.npairs, (const double*)c->partials.p,
-                             (double*)c->h_sums_dev, unresolved, reset);
-    };
     if (pl.grid) {
-        // single pair: the transform rides in the kernel arguments, the device-side state (active = 1) was
-        // uploaded once by grid_setup
-        unsigned long long* stamps = nullptr;
-        const int nblk = grid_nn_blocks((int)pl.g[0].ns);
+        // single pair: the transform rides in the kernel arguments
+        PassArgs a = pass_args(c, pl, d_in, d_out, max_d2, d_idx_out, d_d2_out);
+        const int nblk = grid_pass_blocks(pl.total_rows);
         if (getenv("KSS_GRID_STAMPS")) {   // diagnostic build of the timeline (tools/grid_stamps.py)
             KCHK(ensure(c, c->g_stamps, (size_t)nblk * 16 * sizeof(unsigned long long)));
             HIPCHK(c, hipMemsetAsync(c->g_stamps.p, 0, (size_t)nblk * 16 * sizeof(unsigned long long), c->stream));
-            stamps = (unsigned long long*)c->g_stamps.p;
+            a.stamps = (unsigned long long*)c->g_stamps.p;
         }
         const auto tl0 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-        int32_t* d_pos = getenv("KSS_GRID_NOPREV") ? nullptr : (int32_t*)c->g_pos.p;
         unsigned long long want_seq = 0;
         kss_ctx::Gated& G = c->gated;
-        if (G.pending && G.d_in == (const void*)d_in && G.d_out == (void*)d_out && G.fma == fma && G.max_d2 == max_d2 && !stamps && !d_idx_out && !d_d2_out) {
+        const bool plain_args = !a.stamps && !d_idx_out && !d_d2_out;
+        if (G.pending && G.d_in == (const void*)d_in && G.d_out == (void*)d_out && G.fma == fma && G.full == full && G.max_d2 == max_d2 && plain_args) {
             // this pass was enqueued while the previous one ran: hand it its transform and open the gate
             want_seq = G.seq;
             gated_release(c, hs[0], 0);
@@ -539,30 +589,28 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
             gated_cancel(c);   // (a pre-enqueued kernel that does not fit this pass, e.g. before the fitness pass)
             ProfScope ps(c, KSS_K_GRID_NN);
             // search + correspondence sums + final reduction in ONE launch; sums land in host-mapped memory
-            launch_grid_nn(c->stream, fma, hs[0], d_in, d_out, (int)pl.g[0].ns, pl.gp, (const int32_t*)c->g_start.p,
-                           (const float4*)c->g_sorted.p, (unsigned long long*)c->keys.p, (int32_t*)c->g_list.p, (int32_t*)c->g_count.p, max_d2,
-                           (double*)c->g_partials.p, (int32_t*)c->g_count.p + 1, d_idx_out, d_d2_out,
-                           ++c->seq, c->h_seq_dev, stamps, d_pos);
+            a.ps0 = hs[0];
+            a.seq = ++c->seq;
+            launch_grid_pass(c->stream, fma, full, false, true, a);
             want_seq = c->seq;
         }
         HIPCHK(c, hipGetLastError());
         // HIP-event timing: a bracket behind the gate would also time the dispatch that follows the wait, so the launches
         // the profiler samples (every n-th) are plain launches; the others advance its tick here
         const bool next_sampled = c->prof == 1 || (c->prof > 1 && c->prof_tick[KSS_K_GRID_NN] % (unsigned)c->prof == 0);
-        if (G.want_next && !next_sampled && !stamps && !d_idx_out && !d_d2_out && gated_available(c)) {
+        if (G.want_next && !next_sampled && plain_args && gated_available(c)) {
             if (c->prof > 1) ++c->prof_tick[KSS_K_GRID_NN];
             // enqueue the NEXT iteration behind the gate while this one runs: it reads what this pass writes (d_out) and
             // writes the other ping-pong buffer
             float4* nxt_out = d_out == (float4*)c->cur[0].p ? (float4*)c->cur[1].p : (float4*)c->cur[0].p;
             G.slot ^= 1;
             if (hipStreamWaitValue64(c->stream, c->h_gate_dev, G.gate_val + 1, hipStreamWaitValueGte, 0xffffffffffffffffull) == hipSuccess) {
-                {
-                    launch_grid_nn(c->stream, fma, hs[0], d_out, nxt_out, (int)pl.g[0].ns, pl.gp, (const int32_t*)c->g_start.p,
-                                   (const float4*)c->g_sorted.p, (unsigned long long*)c->keys.p, (int32_t*)c->g_list.p, (int32_t*)c->g_count.p, max_d2,
-                                   (double*)c->g_partials.p, (int32_t*)c->g_count.p + 1, nullptr, nullptr,
-                                   ++c->seq, c->h_seq_dev, nullptr, d_pos, c->h_xf_dev + G.slot);
-                }
-                G.pending = true; G.seq = c->seq; G.d_in = d_out; G.d_out = nxt_out; G.fma = fma; G.max_d2 = max_d2;
+                PassArgs n = pass_args(c, pl, d_out, nxt_out, max_d2, nullptr, nullptr);
+                n.ps0 = hs[0];
+                n.state = c->h_xf_dev + G.slot;
+                n.seq = ++c->seq;
+                launch_grid_pass(c->stream, fma, G.want_full, false, true, n);
+                G.pending = true; G.seq = c->seq; G.d_in = d_out; G.d_out = nxt_out; G.fma = fma; G.full = G.want_full; G.max_d2 = max_d2;
                 if (hipGetLastError() != hipSuccess) { gated_cancel(c); G.supported = 0; }   // the wait is queued: open it, give gating up
             } else {
                 (void)hipGetLastError();
@@ -576,15 +624,16 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
             c->t_launch_us += std::chrono::duration<double, std::micro>(tl1 - tl0).count();
             c->t_wait_us += std::chrono::duration<double, std::micro>(tl2 - tl1).count();
         }
-        if (stamps) {
+        if (a.stamps) {
             c->last_stamps.resize((size_t)nblk * 16);
-            HIPCHK(c, hipMemcpy(c->last_stamps.data(), stamps, c->last_stamps.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(c->last_stamps.data(), a.stamps, c->last_stamps.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             for (int b = 0; b < nblk; ++b) c->evals_sum += (double)c->last_stamps[(size_t)b * 16 + 10];
             c->evals_launches += 1.0;
         }
         if (((const double*)c->h_sums)[NSUMS - 1] > 0.0) {
-            // queries the cell search gave up on (far from the target): brute-force sweep over the list,
-            // then the reduce again over every source
+            // sources the cell search gave up on (far from the target): brute-force sweep over the list, then the sums
+            // again by a SEARCH = false launch of the fused pass -- same rows, same order, so the result does not depend
+            // on WHICH sources needed the list
             gated_cancel(c);              // the list pass must not queue up behind a closed gate
             c->gated.want_next = false;   // (clouds this far apart: plain launches until the loop says otherwise)
             KCHK(stage_tables(c, pl));
@@ -594,16 +643,43 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
                                      d_out, (const float4*)c->tgt4.p, (unsigned long long*)c->keys.p, (const int32_t*)c->g_list.p,
                                      (const int32_t*)c->g_count.p);
             }
-            reduce((const int32_t*)c->g_count.p, (int32_t*)c->g_count.p);
+            HIPCHK(c, hipMemsetAsync(c->g_count.p, 0, sizeof(int32_t), c->stream));   // the list is consumed
+            {
+                ProfScope ps(c, KSS_K_CORR_REDUCE);
+                PassArgs r = pass_args(c, pl, d_in, d_out, max_d2, d_idx_out, d_d2_out);
+                r.ps0 = hs[0];
+                r.seq = ++c->seq;
+                launch_grid_pass(c->stream, fma, true, false, false, r);
+            }
             HIPCHK(c, hipGetLastError());
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            KCHK(wait_seq(c, 1, c->seq));
         }
         ((double*)c->h_sums)[NSUMS - 1] = 0.0;
         return KSS_OK;
     }
-    // The per-pair states (transform to apply, active flag): a small batch lets the kernels read them straight from the
-    // pinned, host-mapped table (64 B per workgroup over PCIe, no copy operation on the stream: ~5 us per pass); a large
-    // one (thousands of workgroups) gets the table copied to device memory once per pass.
+    if (pl.gridb) {
+        // batch: one launch searches every active pair and publishes each pair's sums as its last workgroup finishes.
+        // The per-pair states (transform to apply, active flag) are read by every workgroup: a small batch reads them
+        // straight from the pinned host-mapped table (no copy operation on the stream), a large one (thousands of
+        // workgroups) gets the table copied to device memory once per pass.
+        PassArgs a = pass_args(c, pl, d_in, d_out, max_d2, d_idx_out, d_d2_out);
+        a.state = (const PairState*)c->state.p;
+        if (pl.total_rows <= 512) {
+            void* dev = nullptr;
+            if (hipHostGetDevicePointer(&dev, c->h_state, 0) == hipSuccess && dev) a.state = (const PairState*)dev;
+        }
+        if (a.state == (const PairState*)c->state.p)
+            HIPCHK(c, hipMemcpyAsync(c->state.p, hs, (size_t)pl.npairs * sizeof(PairState), hipMemcpyHostToDevice, c->stream));
+        {
+            ProfScope ps(c, KSS_K_GRID_NN);
+            a.seq = ++c->seq;
+            launch_grid_pass(c->stream, fma, full, true, true, a);
+        }
+        HIPCHK(c, hipGetLastError());
+        if (!c->defer_wait) KCHK(wait_seq(c, pl.npairs, c->seq, active));
+        return KSS_OK;
+    }
+    // brute-force engine.  Per-pair states as above.
     const PairState* d_state = (const PairState*)c->state.p;
     if (pl.npairs <= PUB_PAIRS) {
         void* dev = nullptr;
@@ -611,25 +687,6 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
     }
     if (d_state == (const PairState*)c->state.p)
         HIPCHK(c, hipMemcpyAsync(c->state.p, hs, (size_t)pl.npairs * sizeof(PairState), hipMemcpyHostToDevice, c->stream));
-    if (pl.gridb) {
-        // search + correspondence sums in one launch (one partial row per workgroup), then the per-pair row sums
-        {
-            ProfScope ps(c, KSS_K_GRID_NN);
-            launch_gridb_nn(c->stream, fma, (const RedWork*)c->red_work.p, (int)pl.red.size(), d_state,
-                            (const GridPairDev*)c->g_pairs.p, d_in, d_out, (const int32_t*)c->g_start.p, (const float4*)c->g_sorted.p,
-                            (const float4*)c->tgt4.p, getenv("KSS_GRID_NOPREV") ? nullptr : (int32_t*)c->g_pos.p, max_d2, (double*)c->partials.p, d_idx_out, d_d2_out);
-        }
-        const bool spin = pl.npairs <= PUB_PAIRS;
-        {
-            ProfScope ps(c, KSS_K_CORR_REDUCE);
-            launch_finalize_sums(c->stream, (const PairRed*)c->pair_red.p, pl.npairs, (const double*)c->partials.p,
-                                 (double*)c->h_sums_dev, nullptr, nullptr, spin ? c->h_seq_dev : nullptr, spin ? ++c->seq : 0);
-        }
-        HIPCHK(c, hipGetLastError());
-        if (spin) KCHK(wait_seq(c, pl.npairs));
-        else HIPCHK(c, hipStreamSynchronize(c->stream));
-        return KSS_OK;
-    }
     {
         ProfScope ps(c, KSS_K_NN_SWEEP);
         launch_nn_sweep(c->stream, pl.S, fma, (const NNWork*)c->nn_work.p, (int)pl.nn.size(), d_state,
@@ -669,8 +726,9 @@ static int icp_loop(kss_ctx* c, const IcpPlan& pl_in, const kss_icp_params& P, k
     const int np = pl_in.npairs;
     std::vector<Convergence> conv(np);
     std::vector<float> fin((size_t)np * 16), Tk((size_t)np * 16);
-    std::vector<int> iters(np, 0), active(np, 1), converged(np, 0), state(np, 0);
+    std::vector<int> iters(np, 0), active(np, 1), converged(np, 0), state(np, 0), solved(np, 0), was_active;
     std::vector<double> last_mse(np, 0.0);
+    const bool full = P.trace_sums != nullptr;   // traced runs report all 20 sums of every pass
     PairState* hs = (PairState*)c->h_state;
     float I[16];
     mat4_identity(I);
@@ -699,37 +757,31 @@ static int icp_loop(kss_ctx* c, const IcpPlan& pl_in, const kss_icp_params& P, k
         // (cancelled if this iteration converges; never with an all-reduce callback: its collective would queue up on
         // this stream BEHIND the closed gate and the host would wait for it forever)
         c->gated.want_next = plan->grid && !P.allreduce && it + 1 < P.max_iterations;
-        KCHK(nn_pass(c, *plan, P.nn_fma != 0, d_in, d_out, max_d2, nullptr, nullptr));
-        if (plan->gridb) {
-            // Batched cell lists: slot 19 counts the lanes that ended in the in-wave brute-force fallback.  When more
-            // than 10 % of the active sources did (badly posed pairs), the rest of this call runs on the brute-force
-            // engine, whose tiled sweep is several times faster at that job; the engines agree bit for bit on every
-            // correspondence, so the switch only changes speed.  The packed clouds stay where they are.
-            double fallback = 0.0, act = 0.0;
-            for (int p = 0; p < np; ++p)
-                if (active[p]) { fallback += hsum[(size_t)p * NSUMS + NSUMS - 1]; act += (double)plan->g[p].ns; }
-            if (fallback > 0.10 * act && !getenv("KSS_GRID_NOSWITCH")) {
-                std::vector<int64_t> ns(np), nt(np);
-                for (int p = 0; p < np; ++p) { ns[p] = plan->g[p].ns; nt[p] = plan->g[p].nt; }
-                KCHK(build_plan(c, ns.data(), nt.data(), np, false, P.nn_sources_per_thread, P.nn_target_splits, KSS_NN_BRUTE, brute_plan));
-                brute_plan.src_in_cell_order = true;
-                KCHK(stage_plan(c, brute_plan));
-                plan = &brute_plan;
-            }
-        }
+        c->gated.want_full = full;
+        // batched cell lists: every pair's sums are published as its last workgroup finishes, and the solve loop below
+        // picks the pairs up in that order while the rest of the launch is still running
+        c->defer_wait = plan->gridb;
+        const int rc_pass = nn_pass(c, *plan, P.nn_fma != 0, d_in, d_out, max_d2, nullptr, nullptr, full, active.data());
+        const bool deferred = c->defer_wait;
+        c->defer_wait = false;
+        KCHK(rc_pass);
+        const unsigned long long pass_seq = c->seq;
         // source rows split over ranks: the sums of all ranks, identical on every rank from here on
         if (P.allreduce && P.allreduce(P.allreduce_user, (double*)c->h_sums, NSUMS) != 0)
             return set_err(c, KSS_ERR_RCCL, "icp: the allreduce callback failed");
         // per-pair solve + convergence test: pairs are independent (a large batch is split over a few host threads;
         // each pair is handled by exactly one thread, so the results do not depend on the split)
-        std::atomic<int> finished{0};
+        std::atomic<int> finished{0}, stuck{0};
+        bool poll = deferred;
+        std::fill(solved.begin(), solved.end(), 0);
         auto solve = [&](int pb, int pe) {
             int fin_here = 0;
             for (int p = pb; p < pe; ++p) {
-                if (!active[p]) continue;
+                if (!active[p] || solved[p]) continue;
+                if (poll && wait_pair(c, p, pass_seq) != KSS_OK) { stuck.fetch_add(1); continue; }   // (retried below after a stream sync)
                 const double* s = hsum + (size_t)p * NSUMS;
                 if ((int)s[0] < P.min_correspondences) {   // PCL: "Not enough correspondences found"
-                    state[p] = KSS_STATE_NO_CORRESPONDENCES; converged[p] = 0; active[p] = 0; ++fin_here;
+                    state[p] = KSS_STATE_NO_CORRESPONDENCES; converged[p] = 0; active[p] = 0; ++fin_here; solved[p] = 1;
                     set_state(hs[p], I, 0, 0);
                     continue;
                 }
@@ -746,6 +798,7 @@ static int icp_loop(kss_ctx* c, const IcpPlan& pl_in, const kss_icp_params& P, k
                 }
                 const bool done = conv[p].has_converged(iters[p], tk, mse);
                 state[p] = conv[p].state;
+                solved[p] = 1;
                 if (done) {
                     converged[p] = 1; active[p] = 0; ++fin_here;
                     set_state(hs[p], tk, 0, 1);
@@ -755,8 +808,47 @@ static int icp_loop(kss_ctx* c, const IcpPlan& pl_in, const kss_icp_params& P, k
             }
             finished.fetch_add(fin_here, std::memory_order_relaxed);
         };
-        if (np >= 64) c->pool.parallel_for(np, solve);
-        else solve(0, np);
+        // the fallback statistics of this pass need the pairs that were active when it ran
+        if (plan->gridb) was_active = active;
+        if (np >= 64) {
+            std::atomic<int> next{0};
+            constexpr int kBlock = 16;   // pairs claimed at a time, in launch order: the first threads start while the GPU is still on later pairs
+            c->pool.parallel_for(np, [&](int, int) {
+                for (;;) {
+                    const int pb = next.fetch_add(1) * kBlock;
+                    if (pb >= np) break;
+                    solve(pb, std::min(np, pb + kBlock));
+                }
+            });
+        } else {
+            solve(0, np);
+        }
+        if (stuck.load() > 0) {   // a pair did not publish in time: synchronize (surfaces a faulted kernel), then finish the stragglers
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            for (int p = 0; p < np; ++p) {
+                if (!active[p] || solved[p]) continue;
+                if (!collect_pair(c, p, pass_seq)) return set_err(c, KSS_ERR_HIP, "kernel finished without publishing its result");
+            }
+            poll = false;        // their sums are in h_sums now
+            solve(0, np);        // (pairs already solved in this pass are skipped)
+        }
+        if (plan->gridb) {
+            // Batched cell lists: slot 19 counts the lanes that ended in the in-wave brute-force fallback.  When more
+            // than 10 % of the active sources did (badly posed pairs), the rest of this call runs on the brute-force
+            // engine, whose tiled sweep is several times faster at that job; the engines agree bit for bit on every
+            // correspondence, so the switch only changes speed.  The packed clouds stay where they are.
+            double fallback = 0.0, act = 0.0;
+            for (int p = 0; p < np; ++p)
+                if (was_active[p]) { fallback += hsum[(size_t)p * NSUMS + NSUMS - 1]; act += (double)plan->g[p].ns; }
+            if (fallback > 0.10 * act && !getenv("KSS_GRID_NOSWITCH")) {
+                std::vector<int64_t> ns(np), nt(np);
+                for (int p = 0; p < np; ++p) { ns[p] = plan->g[p].ns; nt[p] = plan->g[p].nt; }
+                KCHK(build_plan(c, ns.data(), nt.data(), np, false, P.nn_sources_per_thread, P.nn_target_splits, KSS_NN_BRUTE, brute_plan));
+                brute_plan.src_in_cell_order = true;
+                KCHK(stage_plan(c, brute_plan));
+                plan = &brute_plan;
+            }
+        }
         n_active -= finished.load(std::memory_order_relaxed);
         ++it;
     }
@@ -777,7 +869,7 @@ static int icp_loop(kss_ctx* c, const IcpPlan& pl_in, const kss_icp_params& P, k
             KCHK(ensure(c, c->stage_d2, (size_t)plan->total_src * sizeof(float)));
             d_idx = (int32_t*)c->stage_idx.p; d_d2 = (float*)c->stage_d2.p;
         }
-        KCHK(nn_pass(c, *plan, P.nn_fma != 0, (const float4*)c->src0.p, (float4*)c->cur[0].p, max_d2, d_idx, d_d2));
+        KCHK(nn_pass(c, *plan, P.nn_fma != 0, (const float4*)c->src0.p, (float4*)c->cur[0].p, max_d2, d_idx, d_d2, true));
         if (P.allreduce) {   // mean over ALL source rows of the job
             double v[2] = {hsum[17], (double)plan->g[0].ns};
             if (P.allreduce(P.allreduce_user, v, 2) != 0) return set_err(c, KSS_ERR_RCCL, "icp: the allreduce callback failed");
@@ -842,7 +934,7 @@ int nn_generic_dev(kss_ctx* c, const void* d_src, int64_t ns, const void* d_tgt,
     float I[16];
     mat4_identity(I);
     set_state(((PairState*)c->h_state)[0], I, 1, 0);
-    KCHK(nn_pass(c, pl, false, (const float4*)c->src0.p, (float4*)c->cur[0].p, 1e300, d_idx, d_d2));
+    KCHK(nn_pass(c, pl, false, (const float4*)c->src0.p, (float4*)c->cur[0].p, 1e300, d_idx, d_d2, true));
     if (sums_out) std::memcpy(sums_out, c->h_sums, NSUMS * sizeof(double));
     return KSS_OK;
 }

@@ -212,7 +212,6 @@ void launch_grid_build(hipStream_t st, const float4* d_tgt, int n, const GridPar
 // unsigned order == smaller distance first, then lower index; d2 >= +0 so its bit pattern is monotone).
 // (2-16 cooperating lanes per query were measured as well: once sources are cell-sorted and the block's ranges
 // are fetched up front, one lane wins at every size tried.)
-constexpr int GRID_BS_DEFAULT = 512;  // workgroup size
 #ifndef KSS_GRID_WALK
 #define KSS_GRID_WALK 8
 #endif
@@ -260,11 +259,14 @@ __device__ __forceinline__ void scan_range(const float4* __restrict__ sorted, in
 // and are walked as ONE flattened list, GRID_WALK points in flight per step: the loads issued are the loads
 // needed (the vector memory pipe bounds this kernel: 36 unconditional float4 gathers per lane used to cost more
 // than the whole remaining search).  Returns the number of distance evaluations.
+typedef int32_t int4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at 4-byte alignment (one global_load_dwordx4)
+
 template <bool FMA, int BS>
 __device__ __forceinline__ int block_walk(const GridParams& gp, const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
                                           float qx, float qy, float qz, int cx, int cy, int cz, int pp, int2 (*rowq)[BS],
                                           unsigned long long& key, int& kpos, float4& win) {
-    const int xl = max(cx - 1, 0), xr = min(cx + 1, gp.gx - 1);
+    // the four bounds of a row -- starts of cells cx-1, cx, cx+1, cx+2 -- are ONE unaligned 16-byte load (cell_start has a
+    // readable element in front of cell 0 and two behind the last start): 9 loads per query instead of 36
     int s0[9], s1[9], s2[9], s3[9];
     bool ok[9];
 #pragma unroll
@@ -272,10 +274,11 @@ __device__ __forceinline__ int block_walk(const GridParams& gp, const int32_t* _
         const int z = cz + t / 3 - 1, y = cy + t % 3 - 1;
         ok[t] = z >= 0 && z < gp.gz && y >= 0 && y < gp.gy;
         const int row = ok[t] ? (z * gp.gy + y) * gp.gx : 0;
-        s0[t] = cell_start[row + xl];       // [s0, s1) = cell cx-1 (empty when it does not exist: xl == cx)
-        s1[t] = cell_start[row + cx];       // [s1, s2) = cell cx
-        s2[t] = cell_start[row + cx + 1];   // [s2, s3) = cell cx+1 (empty when it does not exist: xr == cx)
-        s3[t] = cell_start[row + xr + 1];
+        const int4u v = *(const int4u*)(cell_start + row + cx - 1);
+        s0[t] = cx > 0 ? v.x : v.y;               // [s0, s1) = cell cx-1 (empty when it does not exist)
+        s1[t] = v.y;                              // [s1, s2) = cell cx
+        s2[t] = v.z;                              // [s2, s3) = cell cx+1 (empty when it does not exist)
+        s3[t] = cx + 1 < gp.gx ? v.w : v.z;
     }
     float d0 = __builtin_inff();
     if (pp >= 0) {
@@ -355,221 +358,262 @@ void launch_grid_sort_sources(hipStream_t st, const float4* d_src, int n, const 
     hipLaunchKernelGGL(grid_rank_fix_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_tmp, n, gp, d_start, d_out);
 }
 
-// One launch per ICP iteration: cell search + correspondence sums + the final reduction.
-//   - persistent workgroups stride over the query groups and keep the 20 f64 sums in registers;
-//   - each workgroup publishes one partial row, then takes a ticket on a device counter; the workgroup that
-//     draws the last ticket adds the rows up IN ROW ORDER (bitwise reproducible) and writes the result --
-//     normally straight into host-mapped pinned memory -- and re-arms the counter;
-//   - cross-workgroup visibility follows cdna_hip_programming.md Guideline 16: storing lanes release at agent
-//     scope (+ explicit s_waitcnt vmcnt(0), the ROCm 7.2 compiler hazard), one lane takes the ticket, acquires
-//     at agent scope, and the workgroup barrier publishes that to the other lanes before they load.
-//   Sources the search gives up on are excluded from the sums and counted in slot 19: the host then runs the
-//   brute-force list pass + the stand-alone reduce (rare: only for sources far from the target).
-template <bool FMA, int BS>
-__global__ __launch_bounds__(BS) void grid_nn_kernel(const PairState ps_arg, const float4* __restrict__ src_in,
-                                                      float4* __restrict__ src_out, int ns, GridParams gp,
-                                                      const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
-                                                      unsigned long long* __restrict__ keys,
-                                                      int32_t* __restrict__ list, int32_t* __restrict__ list_count,
-                                                      double max_d2, double* __restrict__ partials, int32_t* __restrict__ ticket,
-                                                      int32_t* __restrict__ idx_out,
-                                                      float* __restrict__ d2_out, unsigned long long seq,
-                                                      unsigned long long* __restrict__ pub,
-                                                      unsigned long long* __restrict__ stamps, int32_t* __restrict__ pos_prev,
-                                                      const PairState* __restrict__ ps_host) {
-    // diagnostic stamps (100 MHz s_memrealtime; null in production): [block*16 + {0 start, 1 searched, 2 reduced,
-    // 3 ticketed}], last workgroup also [4 result stored]; search phase: 6 source loaded,
-    // 8 block scanned, 9 shells done; 10 = distance evaluations of the workgroup (a count)
-#define KSS_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-    // search-phase stamps drain the wave's loads first, so they time the dependent round trips (diagnostic runs only)
-#define KSS_STAMPW(k) do { if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); KSS_STAMP(k); } } while (0)
+// =============================================================================================
+// The fused cell-list pass: ONE kernel for a single pair (C2 / C4) and for a batch of pairs (C3 / C5).
+//   - one workgroup = one CHUNK of 512 consecutive cell-sorted sources of one pair, one lane per source; workgroups
+//     are laid out pair by pair and handed to XCDs in contiguous runs (blockIdx % 8 remap), so the workgroups of a
+//     pair -- and with them that pair's cell list -- stay in one XCD's L2;
+//   - search: previous winner first (its distance bounds the answer), the 3x3x3 block pruned by that bound
+//     (block_walk), further shells up to GridParams::rcap, then the fallback: BATCH -> the wave sweeps the pair's
+//     targets by brute force for its unresolved lanes (uniform addresses, no LDS, no barrier); single pair -> the
+//     source goes to a device list that nn_sweep_kernel<LIST> resolves, after which a SEARCH = false launch of this
+//     kernel (same rows, same order) redoes the sums from the stored winners;
+//   - sums: every lane contributes its correspondence to 16 f64 columns (+ 2 in FULL mode: sum of all d2 and of
+//     sqrt(d2) for getFitnessScore / PCR_QM; counts are ballots), reduced in the canonical order of kss_device.hpp:
+//     in-wave tree by permlane swaps + DPP (no LDS, no barrier), 8 wave totals through LDS, one row per workgroup;
+//   - rows are handed over with write-through sc1 stores + vmcnt(0) + workgroup barrier + ONE agent-scope ticket on the
+//     pair's counter (MI355X_MICROARCH.md, "Valid forms", table row 1); the workgroup drawing the pair's last ticket
+//     adds the rows in the canonical order and publishes the 20 sums of the pair as {bits(sum), seq} 16-byte stores into
+//     host-mapped memory, where the host spins on the sequence numbers (no completion flag, no stream sync);
+//   - a pair of a single chunk skips the hand-over (0.0 + row: the same bits as the general path).
+// The result of a pair is a function of its own clouds only: alone or in a batch of any size, bit for bit.
+// =============================================================================================
+template <bool FMA, bool FULL, bool BATCH, bool SEARCH>
+__global__ __launch_bounds__(PASS_BS) void grid_pass_kernel(const PassArgs a) {
+    // diagnostic stamps (100 MHz s_memrealtime): [block*16 + {0 start, 1 searched, 2 row ready, 3 ticketed, 4 result stored
+    // (last workgroup)}], 10 = distance evaluations of the r = 1 block (a count)
+#define KSS_STAMP(k) do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     KSS_STAMP(0);
-    // The transform normally rides in the kernel arguments.  A launch that was enqueued BEFORE its transform existed
-    // (behind a hipStreamWaitValue64 gate, see kss_engine.hip) fetches it from host-mapped memory instead -- uniform
-    // address: scalar loads, one PCIe read per CU, overlapped with the source loads below -- and leaves at once when the
-    // host cancelled it (pad[0] != 0).
-    PairState ps = ps_arg;
-    if (ps_host) {
-        ps = *ps_host;
-        if (ps.pad[0] != 0) return;   // uniform
+    constexpr int BS = PASS_BS;
+    const int per_xcd = (int)gridDim.x / 8;                                   // the launcher makes gridDim.x a multiple of 8
+    const int w = ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8;      // bijection on [0, gridDim.x): XCD-contiguous runs
+    if (w >= a.total_rows) return;
+    int pi = 0;
+    if constexpr (BATCH) pi = a.row_pair[w];
+    const GridPairDev pr = BATCH ? a.pairs[pi] : a.pair0;
+    PairState ps = a.ps0;
+    if constexpr (BATCH) {
+        ps = a.state[pi];
+        if (!ps.active) return;            // uniform: a converged pair costs one table read per workgroup
+    } else if (a.state) {
+        // a launch enqueued BEFORE its transform existed (behind a hipStreamWaitValue64 gate, kss_engine.hip) fetches it
+        // from host-mapped memory -- uniform address: scalar loads -- and leaves at once when the host cancelled it
+        ps = *a.state;
+        if (ps.pad[0] != 0) return;
     }
-    constexpr int FG = BS / NSUMS;           // lane groups of the two column-sum stages below
-    __shared__ double shf[FG][NSUMS];
+    const GridParams& gp = pr.gp;
+    const int32_t* __restrict__ cs = a.cell_start + pr.cell_base;
+    const float4* __restrict__ sorted = a.sorted;
+    __shared__ int2 rowq[9][BS];           // block_walk's per-lane queue of point ranges
+    __shared__ double shw[BS / 64][NSUMS];
     __shared__ int s_last;
-    __shared__ int2 rowq[9][BS];   // block_walk's per-lane queue of point ranges
-    // the 20 correspondence sums of this lane's queries (KSS_NSUMS in include/kssicp.h); ps travels as a kernel
-    // argument: no per-iteration upload
-    double acc[NSUMS];
-#pragma unroll
-    for (int j = 0; j < NSUMS; ++j) acc[j] = 0.0;
+    double (*shf)[NSUMS] = reinterpret_cast<double (*)[NSUMS]>(&rowq[0][0]);   // the last workgroup's group totals: rowq is dead by then (two barriers later)
+    static_assert(sizeof(double) * PASS_FG * NSUMS <= sizeof(int2) * 9 * BS, "shf must fit inside rowq");
 
-    // XCD-aware, contiguous chunks: workgroups b and b+8 share an XCD (round-robin dispatch), so the virtual
-    // index below hands every XCD one contiguous eighth of the (spatially sorted) sources and its L2 then
-    // holds one eighth of the cell list; a different placement only changes speed, never results.
-    const int per_xcd = (int)gridDim.x / 8;                     // the launcher makes gridDim.x a multiple of 8
-    const int vb = ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8;   // bijection on [0, gridDim.x)
-    const int nrounds_total = (ns + BS - 1) / BS;               // one "round" = BS queries of one workgroup
-    const int base = nrounds_total / (int)gridDim.x, rem = nrounds_total % (int)gridDim.x;
-    const int rounds = base + (vb < rem ? 1 : 0);               // balanced: the first `rem` chunks are one longer
-    const int first = vb * base + min(vb, rem);
-    for (int rr = 0; rr < rounds; ++rr) {
-        const int i = (first + rr) * BS + (int)threadIdx.x;
-        if (i >= ns) break;
-        float4 p = src_in[i];
-        const int pp = pos_prev ? pos_prev[i] : -1;
-        if (ps.apply) {   // pcl transformCloud with the previous iteration's Matrix4f, as nn_sweep_kernel does
-            const float x = p.x, y = p.y, z = p.z;
-            p.x = ((ps.m[0] * x + ps.m[1] * y) + ps.m[2] * z) + ps.m[3];
-            p.y = ((ps.m[4] * x + ps.m[5] * y) + ps.m[6] * z) + ps.m[7];
-            p.z = ((ps.m[8] * x + ps.m[9] * y) + ps.m[10] * z) + ps.m[11];
+    const int local = (w - pr.row_base) * BS + (int)threadIdx.x;
+    const bool valid = local < pr.src_n;
+    const int i = pr.src_base + local;
+    // this lane's correspondence
+    bool have = false, fell_back = false;
+    int ev_lane = 0;                       // diagnostic runs: distance evaluations of the r = 1 block
+    float qx = 0.f, qy = 0.f, qz = 0.f, d2 = 0.f;
+    float4 win = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) {
+        float4 p = SEARCH ? a.src_in[i] : a.src_out[i];
+        int pp = a.pos_prev[i];
+        if constexpr (SEARCH) {
+            if (ps.apply) {   // pcl transformCloud with the previous iteration's Matrix4f, Eigen order, float, no fma
+                const float x = p.x, y = p.y, z = p.z;
+                p.x = ((ps.m[0] * x + ps.m[1] * y) + ps.m[2] * z) + ps.m[3];
+                p.y = ((ps.m[4] * x + ps.m[5] * y) + ps.m[6] * z) + ps.m[7];
+                p.z = ((ps.m[8] * x + ps.m[9] * y) + ps.m[10] * z) + ps.m[11];
+            }
+            a.src_out[i] = p;
         }
-        KSS_STAMPW(6);
-        src_out[i] = p;
-        const float qx = p.x, qy = p.y, qz = p.z;
-        const int cx = cell_coord(qx, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(qy, gp.oy, gp.inv_h, gp.gy),
-                  cz = cell_coord(qz, gp.oz, gp.inv_h, gp.gz);
+        qx = p.x; qy = p.y; qz = p.z;
         unsigned long long key = ~0ull;
-        int kpos = 0;
-        float4 win = make_float4(0.f, 0.f, 0.f, 0.f);   // the best point so far
-        bool done = false;
-        // ---- r = 1: the 3x3x3 block, pruned by the previous winner's distance ----
-        const int ev = block_walk<FMA, BS>(gp, cell_start, sorted, qx, qy, qz, cx, cy, cz, pp, rowq, key, kpos, win);
-        if (stamps) {   // diagnostic runs: distance evaluations of the r = 1 block, summed per workgroup into slot 10
-            int evs = ev;
-#pragma unroll
-            for (int m = 32; m > 0; m >>= 1) evs += __shfl_xor(evs, m, 64);
-            if ((threadIdx.x & 63) == 0) atomicAdd(&stamps[(size_t)blockIdx.x * 16 + 10], (unsigned long long)evs);
-        }
-        KSS_STAMPW(8);
-        for (int r = 1; r <= gp.rcap; ++r) {
-            if (r > 1) {   // shell r: (2r+1)^2 rows
-                const int w = 2 * r + 1;
-                const int x0 = max(cx - r, 0), x1 = min(cx + r, gp.gx - 1);
-                for (int t = 0; t < w * w; ++t) {
-                    const int dz = t / w - r, dy = t % w - r;
-                    const int z = cz + dz, y = cy + dy;
-                    if (z < 0 || z >= gp.gz || y < 0 || y >= gp.gy) continue;
-                    const int row = (z * gp.gy + y) * gp.gx;
-                    if (dz == -r || dz == r || dy == -r || dy == r) {
-                        // a row on the shell's y/z faces: the whole x extent is new
-                        scan_range<FMA>(sorted, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, key, kpos, win);
-                    } else {
-                        // interior row of shell r: only its two x end cells are new
-                        if (cx - r >= 0) scan_range<FMA>(sorted, cell_start[row + cx - r], cell_start[row + cx - r + 1], qx, qy, qz, key, kpos, win);
-                        if (cx + r < gp.gx) scan_range<FMA>(sorted, cell_start[row + cx + r], cell_start[row + cx + r + 1], qx, qy, qz, key, kpos, win);
+        int kpos = -1;
+        // a non-finite query matches nothing (its distances are NaN; as an integer key NaN bits would beat every real one)
+        const bool qok = (qx - qx) == 0.f && (qy - qy) == 0.f && (qz - qz) == 0.f;
+        if constexpr (SEARCH) {
+            bool done = !qok;
+            if (qok) {
+                const int cx = cell_coord(qx, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(qy, gp.oy, gp.inv_h, gp.gy),
+                          cz = cell_coord(qz, gp.oz, gp.inv_h, gp.gz);
+                // ---- r = 1: the 3x3x3 block, pruned by the previous winner's distance ----
+                ev_lane = block_walk<FMA, BS>(gp, cs, sorted, qx, qy, qz, cx, cy, cz, a.use_prev ? pp : -1, rowq, key, kpos, win);
+                for (int r = 1; r <= gp.rcap; ++r) {
+                    if (r > 1) {   // shell r: (2r+1)^2 rows
+                        const int wd = 2 * r + 1;
+                        const int x0 = max(cx - r, 0), x1 = min(cx + r, gp.gx - 1);
+                        for (int t = 0; t < wd * wd; ++t) {
+                            const int dz = t / wd - r, dy = t % wd - r;
+                            const int z = cz + dz, y = cy + dy;
+                            if (z < 0 || z >= gp.gz || y < 0 || y >= gp.gy) continue;
+                            const int row = (z * gp.gy + y) * gp.gx;
+                            if (dz == -r || dz == r || dy == -r || dy == r) {
+                                // a row on the shell's y/z faces: the whole x extent is new
+                                scan_range<FMA>(sorted, cs[row + x0], cs[row + x1 + 1], qx, qy, qz, key, kpos, win);
+                            } else {
+                                // interior row of shell r: only its two x end cells are new
+                                if (cx - r >= 0) scan_range<FMA>(sorted, cs[row + cx - r], cs[row + cx - r + 1], qx, qy, qz, key, kpos, win);
+                                if (cx + r < gp.gx) scan_range<FMA>(sorted, cs[row + cx + r], cs[row + cx + r + 1], qx, qy, qz, key, kpos, win);
+                            }
+                        }
                     }
+                    const float best = __uint_as_float((unsigned)(key >> 32));
+                    // distance from the query to the faces of the visited block; faces on the grid border are open
+                    float b = __builtin_inff();
+                    if (cx - r > 0) b = fminf(b, qx - (gp.ox + (float)(cx - r) * gp.h));
+                    if (cx + r < gp.gx - 1) b = fminf(b, (gp.ox + (float)(cx + r + 1) * gp.h) - qx);
+                    if (cy - r > 0) b = fminf(b, qy - (gp.oy + (float)(cy - r) * gp.h));
+                    if (cy + r < gp.gy - 1) b = fminf(b, (gp.oy + (float)(cy + r + 1) * gp.h) - qy);
+                    if (cz - r > 0) b = fminf(b, qz - (gp.oz + (float)(cz - r) * gp.h));
+                    if (cz + r < gp.gz - 1) b = fminf(b, (gp.oz + (float)(cz + r + 1) * gp.h) - qz);
+                    const float bs = b - gp.eps;
+                    if (b == __builtin_inff()) done = true;                              // the whole grid has been visited
+                    else if (bs > 0.f && best < bs * bs * 0.999999f) done = true;        // every unvisited point is strictly farther
+                    if (done) break;
                 }
             }
-            const float best = __uint_as_float((unsigned)(key >> 32));
-            // distance from the query to the faces of the visited block; faces on the grid border are open
-            float b = __builtin_inff();
-            if (cx - r > 0) b = fminf(b, qx - (gp.ox + (float)(cx - r) * gp.h));
-            if (cx + r < gp.gx - 1) b = fminf(b, (gp.ox + (float)(cx + r + 1) * gp.h) - qx);
-            if (cy - r > 0) b = fminf(b, qy - (gp.oy + (float)(cy - r) * gp.h));
-            if (cy + r < gp.gy - 1) b = fminf(b, (gp.oy + (float)(cy + r + 1) * gp.h) - qy);
-            if (cz - r > 0) b = fminf(b, qz - (gp.oz + (float)(cz - r) * gp.h));
-            if (cz + r < gp.gz - 1) b = fminf(b, (gp.oz + (float)(cz + r + 1) * gp.h) - qz);
-            const float bs = b - gp.eps;
-            if (b == __builtin_inff()) done = key != ~0ull;                 // the whole grid has been visited
-            else if (bs > 0.f && best < bs * bs * 0.999999f) done = true;   // every unvisited point is strictly farther
-            if (done) break;
-        }
-        KSS_STAMPW(9);
-        if (done) {
-            const float d2 = __uint_as_float((unsigned)(key >> 32));
-            accumulate_corr(acc, qx, qy, qz, win.x, win.y, win.z, d2, max_d2);
-            keys[i] = key;
-            if (pos_prev) pos_prev[i] = kpos;
-            const int oi = __float_as_int(p.w);   // original source index (sources are in cell order)
-            if (idx_out) idx_out[oi] = (int)(unsigned)(key & 0xffffffffull);
-            if (d2_out) d2_out[oi] = d2;
+            if constexpr (BATCH) {
+                // bounded fallback: brute force over the pair's targets for the lanes the shells did not resolve
+                if (__builtin_amdgcn_ballot_w64(!done) != 0ull) {              // wave-uniform
+                    const float4* __restrict__ tp = a.tgt4 + pr.tgt_base;      // original order; uniform addresses below
+                    for (int j = 0; j < pr.tgt_n; ++j) {
+                        const float4 q = tp[j];
+                        const float dx = qx - q.x, dy = qy - q.y, dz = qz - q.z;
+                        float d;
+                        if constexpr (FMA) d = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+                        else d = (dx * dx + dy * dy) + dz * dz;
+                        const unsigned long long kk = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(unsigned)j;
+                        if (!done && kk < key) { key = kk; win = q; kpos = -1; }   // (no position in `sorted` known: no warm start next time)
+                    }
+                    fell_back = !done;
+                    done = true;
+                }
+            }
+            if (done) {
+                have = key != ~0ull;
+                a.pos_prev[i] = kpos;
+            } else {   // single pair: resolved by the brute-force list pass through atomicMin, sums by the SEARCH = false launch
+                a.keys[i] = ~0ull;
+                a.pos_prev[i] = -1;
+                const int slot = atomicAdd(a.list_count, 1);
+                a.list[slot] = i;
+            }
         } else {
-            keys[i] = ~0ull;   // resolved by the brute-force list pass through atomicMin
-            if (pos_prev) pos_prev[i] = -1;
-            const int slot = atomicAdd(list_count, 1);
-            list[slot] = i;
+            // sums only: the winner is where the search left it, or what the list pass found
+            if (pp >= 0) {
+                win = sorted[pp];
+                key = point_key<FMA>(win, qx, qy, qz);
+            } else if (qok) {
+                key = a.keys[i];
+                if (key != ~0ull) win = a.tgt4[pr.tgt_base + (int)(unsigned)(key & 0xffffffffull)];
+            }
+            have = key != ~0ull;
         }
+        if (have) {
+            d2 = __uint_as_float((unsigned)(key >> 32));
+            const int oi = __float_as_int(p.w);   // original source index (sources are in cell order)
+            if (a.idx_out) a.idx_out[oi] = (int)(unsigned)(key & 0xffffffffull);
+            if (a.d2_out) a.d2_out[oi] = d2;
+        }
+    }
+    KSS_STAMP(1);
+    if (a.stamps) {   // evaluations summed per workgroup into slot 10
+        int evs = ev_lane;
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) evs += __shfl_xor(evs, m, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&a.stamps[(size_t)blockIdx.x * 16 + 10], (unsigned long long)evs);
     }
 
-    KSS_STAMP(1);
-    // ---- workgroup partial row, then the last workgroup finishes the job ----
-    // 20 f64 per lane: a shuffle tree costs 240 ds_bpermute + dependent adds per wave (measured ~3 us of a 20 us
-    // kernel).  Transpose through LDS instead: lane t stores column-major (conflict free), FG * 20 lanes each add one
-    // column's rows g, g + FG, ... and the FG group totals are added in group order.
+    // ---- the row of this chunk, canonical order (kss_device.hpp) ----
+    const double d2d = have ? (double)d2 : 0.0;
+    const bool kept = have && !(d2d > a.max_d2);   // PCL: `if (distance[0] > max_dist_sqr) continue;`
+    double col[16];
+    {
+        const double px = kept ? (double)qx : 0.0, py = kept ? (double)qy : 0.0, pz = kept ? (double)qz : 0.0;
+        const double tx = kept ? (double)win.x : 0.0, ty = kept ? (double)win.y : 0.0, tz = kept ? (double)win.z : 0.0;
+        col[0] = px; col[1] = py; col[2] = pz; col[3] = tx; col[4] = ty; col[5] = tz;
+        col[6] = px * tx; col[7] = px * ty; col[8] = px * tz;
+        col[9] = py * tx; col[10] = py * ty; col[11] = py * tz;
+        col[12] = pz * tx; col[13] = pz * ty; col[14] = pz * tz;
+        col[15] = kept ? d2d : 0.0;
+    }
+    wave_tree16(col);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long mk = __builtin_amdgcn_ballot_w64(kept), mf = __builtin_amdgcn_ballot_w64(fell_back);
+    double extra = 0.0;
+    if constexpr (FULL) extra = wave_tree2(d2d, have ? sqrt(d2d) : 0.0);   // lane 0: sum of all d2, lane 32: sum of sqrt(d2)
+    if ((lane & 15) == 0) {
+        const int q = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) shw[wave][1 + 4 * q + j] = col[j];
+        if (lane == 0) {
+            shw[wave][0] = (double)__builtin_popcountll(mk);
+            shw[wave][NSUMS - 1] = (double)__builtin_popcountll(mf);
+            shw[wave][17] = extra;
+        }
+        if (lane == 32) shw[wave][18] = extra;
+    }
+    __syncthreads();
     double r = 0.0;
-    {
-        __shared__ double shT[NSUMS][BS + 2];
-#pragma unroll
-        for (int c = 0; c < NSUMS; ++c) shT[c][threadIdx.x] = acc[c];
-        __syncthreads();
-        const int c = threadIdx.x / FG, g = threadIdx.x % FG;
-        if (c < NSUMS) {
-            double a0 = 0.0, a1 = 0.0;
-            int k = g;
-            for (; k + FG < BS; k += 2 * FG) { a0 += shT[c][k]; a1 += shT[c][k + FG]; }
-            if (k < BS) a0 += shT[c][k];
-            shf[g][c] = a0 + a1;
-        }
-        __syncthreads();
-        if (threadIdx.x < NSUMS)
-            for (int gg = 0; gg < FG; ++gg) r += shf[gg][threadIdx.x];
-        __syncthreads();   // shf is reused by the last workgroup below
-    }
-    if (threadIdx.x < NSUMS) {
-        // hand-off without an L2 write-back (MI355X_MICROARCH.md, "Valid forms", table row 1): EVERY store of the
-        // handed-off row is a write-through `sc1` store (relaxed agent-scope atomic store), the storing wave drains
-        // them (vmcnt(0)), the workgroup barrier orders that before ONE lane's agent-scope atomic add, and the
-        // workgroup whose add returns the last ticket reads every row with `sc1` loads after its own barrier.
-        // A release fence here would write back all the source / key lines this XCD just dirtied (several us).
-        __hip_atomic_store(&partials[(int64_t)blockIdx.x * NSUMS + threadIdx.x], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    KSS_STAMP(2);
-    if (threadIdx.x == 0) {
-        const int tk = atomicAdd(ticket, 1);
-        s_last = tk == (int)gridDim.x - 1;
-    }
-    __syncthreads();
-    KSS_STAMP(3);
-    if (!s_last) return;
-    // Column sums of the gridDim.x published rows, fixed order (bitwise reproducible): lane (g, c) adds rows g, g + FG,
-    // g + 2 FG, ... of column c -- eight sc1 loads in flight per batch, i.e. ONE cross-XCD round trip for <= 8 * FG rows
-    // (200 rows at C2) -- and the FG group totals are then added in group order.
-    {
-        const int g = threadIdx.x / NSUMS, c = threadIdx.x % NSUMS, nrows = (int)gridDim.x;
-        if (g < FG) {
-            double a = 0.0;
-            for (int k = g; k < nrows; k += 8 * FG) {
-                double t[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    t[j] = k + j * FG < nrows ? __hip_atomic_load(&partials[(int64_t)(k + j * FG) * NSUMS + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) a += t[j];
-            }
-            shf[g][c] = a;
-        }
-    }
-    __syncthreads();
-    double v = 0.0;
     if (threadIdx.x < NSUMS)
-        for (int gg = 0; gg < FG; ++gg) v += shf[gg][threadIdx.x];
+#pragma unroll
+        for (int ww = 0; ww < BS / 64; ++ww) r += shw[ww][threadIdx.x];
+    KSS_STAMP(2);
+
+    double v = 0.0 + r;                    // a single-chunk pair: exactly what the general path below computes
+    if (pr.n_rows > 1) {
+        if (threadIdx.x < NSUMS) {
+            __hip_atomic_store(&a.rows[(int64_t)w * NSUMS + threadIdx.x], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = atomicAdd(&a.tickets[pi], 1) == pr.n_rows - 1;
+        __syncthreads();
+        KSS_STAMP(3);
+        if (!s_last) return;
+        // pair total: lane (g, c) adds rows g, g + 25, ... of column c -- eight sc1 loads in flight per batch -- and the 25
+        // group totals are then added in group order
+        {
+            const int g = threadIdx.x / NSUMS, c = threadIdx.x % NSUMS;
+            const double* __restrict__ rows = a.rows + (int64_t)pr.row_base * NSUMS;
+            if (g < PASS_FG) {
+                double acc = 0.0;
+                for (int k = g; k < pr.n_rows; k += 8 * PASS_FG) {
+                    double t[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        t[j] = k + j * PASS_FG < pr.n_rows ? __hip_atomic_load(&rows[(int64_t)(k + j * PASS_FG) * NSUMS + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc += t[j];
+                }
+                shf[g][c] = acc;
+            }
+        }
+        __syncthreads();
+        v = 0.0;
+        if (threadIdx.x < NSUMS)
+            for (int gg = 0; gg < PASS_FG; ++gg) v += shf[gg][threadIdx.x];
+        if (threadIdx.x == 0) a.tickets[pi] = 0;   // re-armed for the next launch (stream order makes it visible)
+    }
     if (threadIdx.x < NSUMS) {
-        if (threadIdx.x == NSUMS - 1) v = (double)__hip_atomic_load(list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // publish {bits(sum), seq} as ONE aligned 16-byte system-scope store per sum into host-mapped memory: the host
-        // accepts a slot when its sequence number matches, so no flag has to be ordered after the data (that ordering
-        // would cost a write-acknowledge round trip over PCIe) and no L2 write-back fence is needed
+        if (!FULL && (threadIdx.x == 17 || threadIdx.x == 18)) v = 0.0;
+        if (!BATCH && threadIdx.x == NSUMS - 1)   // single pair: slot 19 = sources left to the list pass
+            v = SEARCH ? (double)__hip_atomic_load(a.list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        // {bits(sum), seq} as ONE aligned 16-byte system-scope store per sum into host-mapped memory: the host accepts a
+        // slot when its sequence number matches, so no flag has to be ordered after the data (that ordering would cost a
+        // write-acknowledge round trip over PCIe) and no L2 write-back fence is needed
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
         const unsigned long long vb = (unsigned long long)__double_as_longlong(v);
-        u32x4 w;
-        w.x = (unsigned)vb; w.y = (unsigned)(vb >> 32); w.z = (unsigned)seq; w.w = (unsigned)(seq >> 32);
-        unsigned long long* dst = pub + 2 * threadIdx.x;
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(w) : "memory");
+        u32x4 o;
+        o.x = (unsigned)vb; o.y = (unsigned)(vb >> 32); o.z = (unsigned)a.seq; o.w = (unsigned)(a.seq >> 32);
+        unsigned long long* dst = a.pub + 2 * ((int64_t)pi * NSUMS + threadIdx.x);
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(o) : "memory");
         KSS_STAMP(4);
     }
-    if (threadIdx.x == 0) *ticket = 0;   // re-arm for the next launch (stream order makes it visible)
-#undef KSS_STAMPW
 #undef KSS_STAMP
 }
 
@@ -689,123 +733,6 @@ void launch_gridb_sort_sources(hipStream_t st, const float4* d_src, int total_sr
     hipLaunchKernelGGL(gridb_rank_fix_kernel, grid, block, 0, st, d_tmp, total_src, d_pairs, npairs, d_start, d_out);
 }
 
-// query + correspondence sums: one workgroup per RedWork item (consecutive sorted sources of ONE pair, 256 per
-// round), one lane per source.  Writes the transformed source, the previous-winner position and one partial row of
-// the 20 sums (the matched target's coordinates are still in registers: no gather pass); finalize_sums_kernel then
-// adds each pair's rows in row order.
-// Fallback: a lane still unresolved after GridParams::rcap shells (a source far from its target: badly posed pairs)
-// stops adding shells; its WAVE then sweeps the pair's whole target, brute force, for exactly those lanes (every lane
-// reads the same target: uniform addresses, scalar-cache loads, no LDS and no barrier, so the common path stays
-// barrier free).  A pass therefore never costs more than the shells plus one brute-force sweep of the pair -- without
-// it the shell loop is cubic in the distance.
-template <bool FMA>
-__global__ __launch_bounds__(256) void gridb_nn_kernel(const RedWork* __restrict__ work, const PairState* __restrict__ state,
-                                                       const GridPairDev* __restrict__ pairs, const float4* __restrict__ src_in,
-                                                       float4* __restrict__ src_out, const int32_t* __restrict__ cell_start,
-                                                       const float4* __restrict__ sorted, const float4* __restrict__ tgt4,
-                                                       int32_t* __restrict__ pos_prev, double max_d2, double* __restrict__ partials,
-                                                       int32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
-    __shared__ int2 rowq[9][256];   // block_walk's per-lane range queue
-    __shared__ double sh[4][NSUMS];
-    const RedWork w = work[blockIdx.x];
-    const PairState ps = state[w.pair];
-    double acc[NSUMS];
-#pragma unroll
-    for (int c = 0; c < NSUMS; ++c) acc[c] = 0.0;
-    if (ps.active) {   // uniform: one pair per workgroup
-        const GridPairDev pr = pairs[w.pair];
-        const GridParams& gp = pr.gp;
-        const int32_t* __restrict__ cs = cell_start + pr.cell_base;
-        for (int t = threadIdx.x; t < w.src_count; t += 256) {
-            const int i = w.src_begin + t;
-            float4 p = src_in[i];
-            if (ps.apply) {
-                const float x = p.x, y = p.y, z = p.z;
-                p.x = ((ps.m[0] * x + ps.m[1] * y) + ps.m[2] * z) + ps.m[3];
-                p.y = ((ps.m[4] * x + ps.m[5] * y) + ps.m[6] * z) + ps.m[7];
-                p.z = ((ps.m[8] * x + ps.m[9] * y) + ps.m[10] * z) + ps.m[11];
-            }
-            src_out[i] = p;
-            const float qx = p.x, qy = p.y, qz = p.z;
-            const int cx = cell_coord(qx, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(qy, gp.oy, gp.inv_h, gp.gy),
-                      cz = cell_coord(qz, gp.oz, gp.inv_h, gp.gz);
-            unsigned long long key = ~0ull;
-            int kpos = -1;
-            float4 win = make_float4(0.f, 0.f, 0.f, 0.f);
-            bool done = false;
-            for (int r = 1; r <= gp.rcap && !done; ++r) {
-                const int wd = 2 * r + 1;
-                const int x0 = max(cx - r, 0), x1 = min(cx + r, gp.gx - 1);
-                if (r == 1) {
-                    block_walk<FMA, 256>(gp, cs, sorted, qx, qy, qz, cx, cy, cz, pos_prev ? pos_prev[i] : -1, rowq, key, kpos, win);
-                } else {
-                    for (int u = 0; u < wd * wd; ++u) {
-                        const int dz = u / wd - r, dy = u % wd - r;
-                        const int z = cz + dz, y = cy + dy;
-                        if (z < 0 || z >= gp.gz || y < 0 || y >= gp.gy) continue;
-                        const int row = (z * gp.gy + y) * gp.gx;
-                        if (dz == -r || dz == r || dy == -r || dy == r) {
-                            scan_range<FMA>(sorted, cs[row + x0], cs[row + x1 + 1], qx, qy, qz, key, kpos, win);
-                        } else {
-                            if (cx - r >= 0) scan_range<FMA>(sorted, cs[row + cx - r], cs[row + cx - r + 1], qx, qy, qz, key, kpos, win);
-                            if (cx + r < gp.gx) scan_range<FMA>(sorted, cs[row + cx + r], cs[row + cx + r + 1], qx, qy, qz, key, kpos, win);
-                        }
-                    }
-                }
-                const float best = __uint_as_float((unsigned)(key >> 32));
-                float b = __builtin_inff();
-                if (cx - r > 0) b = fminf(b, qx - (gp.ox + (float)(cx - r) * gp.h));
-                if (cx + r < gp.gx - 1) b = fminf(b, (gp.ox + (float)(cx + r + 1) * gp.h) - qx);
-                if (cy - r > 0) b = fminf(b, qy - (gp.oy + (float)(cy - r) * gp.h));
-                if (cy + r < gp.gy - 1) b = fminf(b, (gp.oy + (float)(cy + r + 1) * gp.h) - qy);
-                if (cz - r > 0) b = fminf(b, qz - (gp.oz + (float)(cz - r) * gp.h));
-                if (cz + r < gp.gz - 1) b = fminf(b, (gp.oz + (float)(cz + r + 1) * gp.h) - qz);
-                const float bs = b - gp.eps;
-                if (b == __builtin_inff()) done = key != ~0ull;                  // the pair's whole grid has been visited
-                else if (bs > 0.f && best < bs * bs * 0.999999f) done = true;    // every unvisited point is strictly farther
-            }
-            // ---- bounded fallback: brute force over the pair's targets for the lanes the shells did not resolve ----
-            if (__builtin_amdgcn_ballot_w64(!done) != 0ull) {             // wave-uniform
-                const float4* __restrict__ tp = tgt4 + pr.tgt_base;      // original order; uniform addresses below
-                for (int j = 0; j < pr.tgt_n; ++j) {
-                    const float4 q = tp[j];
-                    const float dx = qx - q.x, dy = qy - q.y, dz = qz - q.z;
-                    float d;
-                    if constexpr (FMA) d = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
-                    else d = (dx * dx + dy * dy) + dz * dz;
-                    const unsigned long long kk = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(unsigned)j;
-                    if (!done && kk < key) { key = kk; win = q; kpos = -1; }   // (no position in `sorted` known: no warm start next time)
-                }
-                if (!done) acc[NSUMS - 1] += 1.0;   // slot 19: lanes that needed the fallback (the host may change engine)
-            }
-            if (key != ~0ull) {   // (an empty target cannot happen: the plan rejects it)
-                const float d2 = __uint_as_float((unsigned)(key >> 32));
-                accumulate_corr(acc, qx, qy, qz, win.x, win.y, win.z, d2, max_d2);
-                if (pos_prev) pos_prev[i] = kpos;   // positions are global in the pair-by-pair `sorted`
-                const int oi = __float_as_int(p.w);
-                if (idx_out) idx_out[oi] = (int)(unsigned)(key & 0xffffffffull);
-                if (d2_out) d2_out[oi] = d2;
-            }
-        }
-    }
-    const double r = block_sum<NSUMS>(acc, sh);
-    if (threadIdx.x < NSUMS) partials[(int64_t)w.partial_index * NSUMS + threadIdx.x] = r;
-}
-
-void launch_gridb_nn(hipStream_t st, bool fma, const RedWork* d_work, int n_work, const PairState* d_state,
-                     const GridPairDev* d_pairs, const float4* d_src_in, float4* d_src_out, const int32_t* d_cell_start,
-                     const float4* d_sorted, const float4* d_tgt4, int32_t* d_pos, double max_d2, double* d_partials,
-                     int32_t* d_idx_out, float* d_d2_out) {
-    if (n_work <= 0) return;
-    const dim3 grid(n_work), block(256);
-    if (fma)
-        hipLaunchKernelGGL(gridb_nn_kernel<true>, grid, block, 0, st, d_work, d_state, d_pairs, d_src_in, d_src_out, d_cell_start,
-                           d_sorted, d_tgt4, d_pos, max_d2, d_partials, d_idx_out, d_d2_out);
-    else
-        hipLaunchKernelGGL(gridb_nn_kernel<false>, grid, block, 0, st, d_work, d_state, d_pairs, d_src_in, d_src_out, d_cell_start,
-                           d_sorted, d_tgt4, d_pos, max_d2, d_partials, d_idx_out, d_d2_out);
-}
-
 // statistics for the roofline statement: evaluations of one r = 1 pass and occupied cells (profiling only)
 __global__ __launch_bounds__(256) void grid_stats_kernel(const float4* __restrict__ src, int ns, GridParams gp,
                                                          const int32_t* __restrict__ cell_start, unsigned long long* __restrict__ out) {
@@ -835,47 +762,22 @@ void launch_grid_stats(hipStream_t st, const float4* d_src, int ns, const GridPa
     hipLaunchKernelGGL(grid_stats_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, d_src, ns, gp, d_cell_start, d_out);
 }
 
-static int env_int(const char* name, int dflt) {
-    if (const char* e = getenv(name)) {
-        const int v = atoi(e);
-        if (v > 0) return v;
+int grid_pass_blocks(int total_rows) { return (total_rows + 7) / 8 * 8; }   // multiple of 8: the XCD remap is then a bijection
+
+void launch_grid_pass(hipStream_t st, bool fma, bool full, bool batch, bool search, const PassArgs& a) {
+    if (a.total_rows <= 0) return;
+    const dim3 grid(grid_pass_blocks(a.total_rows)), block(PASS_BS);
+#define KSS_PASS(F, U, B, S) hipLaunchKernelGGL((grid_pass_kernel<F, U, B, S>), grid, block, 0, st, a)
+    if (!search) {   // sums-only relaunch after the list pass: single pair, all 20 sums
+        if (fma) KSS_PASS(true, true, false, false); else KSS_PASS(false, true, false, false);
+    } else if (batch) {
+        if (fma) { if (full) KSS_PASS(true, true, true, true); else KSS_PASS(true, false, true, true); }
+        else     { if (full) KSS_PASS(false, true, true, true); else KSS_PASS(false, false, true, true); }
+    } else {
+        if (fma) { if (full) KSS_PASS(true, true, false, true); else KSS_PASS(true, false, false, true); }
+        else     { if (full) KSS_PASS(false, true, false, true); else KSS_PASS(false, false, false, true); }
     }
-    return dflt;
-}
-// tuning hooks (defaults measured on C2, 100k x 100k; profiles/): workgroup size, workgroup cap
-static int grid_bs() { const int v = env_int("KSS_GRID_BS", GRID_BS_DEFAULT); return (v == 256 || v == 512) ? v : GRID_BS_DEFAULT; }
-
-int grid_nn_blocks(int ns) {
-    const int bs = grid_bs();
-    const int need = (ns + bs - 1) / bs;
-    const int cap = env_int("KSS_GRID_BLOCKS", 131072 / bs);   // one 512-lane workgroup per CU
-    const int nb = need < cap ? need : cap;
-    return (nb + 7) / 8 * 8;   // multiple of 8: the XCD-aware block remap in the kernel is then a bijection
-}
-
-template <bool FMA, int BS>
-static void grid_launch(hipStream_t st, dim3 grid, const PairState& state, const float4* d_src_in, float4* d_src_out, int ns,
-                        const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted, unsigned long long* d_keys,
-                        int32_t* d_list, int32_t* d_list_count, double max_d2, double* d_partials, int32_t* d_ticket,
-                        int32_t* d_idx_out, float* d_d2_out, unsigned long long seq,
-                        unsigned long long* d_pub, unsigned long long* d_stamps, int32_t* d_pos, const PairState* d_ps_host) {
-    hipLaunchKernelGGL((grid_nn_kernel<FMA, BS>), grid, dim3(BS), 0, st, state, d_src_in, d_src_out, ns, gp, d_cell_start,
-                       d_sorted, d_keys, d_list, d_list_count, max_d2, d_partials, d_ticket, d_idx_out, d_d2_out, seq,
-                       d_pub, d_stamps, d_pos, d_ps_host);
-}
-
-void launch_grid_nn(hipStream_t st, bool fma, const PairState& state, const float4* d_src_in, float4* d_src_out, int ns,
-                    const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted,
-                    unsigned long long* d_keys, int32_t* d_list, int32_t* d_list_count, double max_d2, double* d_partials,
-                    int32_t* d_ticket, int32_t* d_idx_out, float* d_d2_out, unsigned long long seq,
-                    unsigned long long* d_pub, unsigned long long* d_stamps, int32_t* d_pos, const PairState* d_ps_host) {
-    const dim3 grid(grid_nn_blocks(ns));
-    const int bs = grid_bs();
-#define KSS_GRID_ARGS st, grid, state, d_src_in, d_src_out, ns, gp, d_cell_start, d_sorted, d_keys, d_list, d_list_count, max_d2, \
-                      d_partials, d_ticket, d_idx_out, d_d2_out, seq, d_pub, d_stamps, d_pos, d_ps_host
-    if (fma) { if (bs == 256) grid_launch<true, 256>(KSS_GRID_ARGS); else grid_launch<true, 512>(KSS_GRID_ARGS); }
-    else     { if (bs == 256) grid_launch<false, 256>(KSS_GRID_ARGS); else grid_launch<false, 512>(KSS_GRID_ARGS); }
-#undef KSS_GRID_ARGS
+#undef KSS_PASS
 }
 
 }  // namespace kss

@@ -71,6 +71,7 @@ struct alignas(16) GridPairDev {
     int32_t tgt_base, tgt_n;    // target segment in tgt4 (padded layout) and its real point count
     int32_t src_base, src_n;    // source segment
     int32_t tgt_pad;            // slots of the target segment in tgt4 (multiple of NN_TILE, +inf sentinels behind tgt_n)
+    int32_t row_base, n_rows;   // this pair's chunks of 512 sources = workgroups of the fused pass = partial rows
 };
 
 // one pair's target segment for the batched pack kernel
@@ -79,6 +80,28 @@ struct PackSeg {
     int64_t out_base;   // first slot in tgt4
     int64_t n;          // real points; slots [n, next segment) are sentinel padding
 };
+
+// arguments of the fused cell-list pass (kss_grid.hip: grid_pass_kernel), by value
+struct PassArgs {
+    const float4* src_in; float4* src_out;      // cell-sorted sources (.w = original index): read, transformed copy written
+    const int32_t* cell_start;                  // exclusive prefix of the cell counts; [-1] and [cells + 1] are readable
+    const float4* sorted;                       // targets in cell order, .w = index within the pair's target
+    const float4* tgt4;                         // targets in original order (fallback sweep, SEARCH = false gathers)
+    int32_t* pos_prev;                          // per source: position of its last winner in `sorted`, -1 = none
+    unsigned long long* keys;                   // single pair: key of the sources left to the list pass
+    int32_t* list; int32_t* list_count;         // single pair: those sources
+    const GridPairDev* pairs;                   // BATCH: per-pair table
+    const int32_t* row_pair;                    // BATCH: pair of every row (= workgroup)
+    const PairState* state;                     // BATCH: per-pair transforms; single pair: host-mapped transform of a gated launch or null
+    GridPairDev pair0; PairState ps0;           // single pair: by value (no upload per iteration)
+    int32_t total_rows, use_prev;
+    double max_d2;
+    double* rows; int32_t* tickets;
+    unsigned long long* pub; unsigned long long seq;
+    int32_t* idx_out; float* d2_out;
+    unsigned long long* stamps;                 // diagnostics (null in production): see KSS_STAMP below
+};
+
 
 // PCL's octree bounding cube (kss_octree.hip; replayed on the host by oct_first_point / oct_adopt)
 struct OctBox {
@@ -139,13 +162,8 @@ void launch_nn_sweep_list(hipStream_t st, int S, bool fma, const NNWork* d_work,
 void launch_grid_bbox(hipStream_t st, const float4* d_tgt, int n, float* d_partial, int n_blocks);
 void launch_grid_build(hipStream_t st, const float4* d_tgt, int n, const GridParams& gp, int32_t* d_counts,
                        int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums, float4* d_sorted);
-void launch_grid_nn(hipStream_t st, bool fma, const PairState& state, const float4* d_src_in, float4* d_src_out, int ns,
-                    const GridParams& gp, const int32_t* d_cell_start, const float4* d_sorted,
-                    unsigned long long* d_keys, int32_t* d_list, int32_t* d_list_count, double max_d2, double* d_partials,
-                    int32_t* d_ticket, int32_t* d_idx_out, float* d_d2_out, unsigned long long seq,
-                    unsigned long long* d_pub /* host-mapped: NSUMS x {bits(sum), seq} */, unsigned long long* d_stamps, int32_t* d_pos,
-                    const PairState* d_ps_host = nullptr /* host-mapped transform of a gated launch, else the by-value state */);
-int grid_nn_blocks(int ns);
+int grid_pass_blocks(int total_rows);
+void launch_grid_pass(hipStream_t st, bool fma, bool full, bool batch, bool search, const PassArgs& a);
 void launch_gridb_bbox(hipStream_t st, const float4* d_tgt, const GridPairDev* d_pairs, int npairs, float* d_bbox);
 void launch_gridb_build_targets(hipStream_t st, const float4* d_tgt, int total_tgt_pad, const GridPairDev* d_pairs, int npairs,
                                 int total_cells, int32_t* d_counts, int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums,
@@ -153,10 +171,6 @@ void launch_gridb_build_targets(hipStream_t st, const float4* d_tgt, int total_t
 void launch_gridb_sort_sources(hipStream_t st, const float4* d_src, int total_src, const GridPairDev* d_pairs, int npairs,
                                int total_cells, int32_t* d_counts, int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums,
                                float4* d_tmp, float4* d_out);
-void launch_gridb_nn(hipStream_t st, bool fma, const RedWork* d_work, int n_work, const PairState* d_state,
-                     const GridPairDev* d_pairs, const float4* d_src_in, float4* d_src_out, const int32_t* d_cell_start,
-                     const float4* d_sorted, const float4* d_tgt4, int32_t* d_pos, double max_d2, double* d_partials,
-                     int32_t* d_idx_out, float* d_d2_out);
 void launch_grid_stats(hipStream_t st, const float4* d_src, int ns, const GridParams& gp, const int32_t* d_cell_start,
                        unsigned long long* d_out /* [0] evaluations of the 3x3x3 block, [1] occupied cells */);
 void launch_grid_sort_sources(hipStream_t st, const float4* d_src, int n, const GridParams& gp, int32_t* d_counts,
