@@ -46,7 +46,7 @@ struct kss_ctx {
     // grow-only device workspace
     DevBuf tgt4, src0, cur[2], keys, partials, sums, nn_work, red_work, pair_red, state, cs, scratch_a,
         scratch_b, scratch_c, stage_src, stage_tgt, stage_idx, stage_d2, stage_out, g_counts, g_start, g_cursor,
-        g_bsums, g_sorted, g_list, g_count, g_bbox, g_partials, g_start2, g_pairs, g_stamps, g_pos, pack_seg, reg_s, reg_t, reg_p, reg_all, reg_f, reg_g, oct_pts, oct_cen, oct_a, oct_b, oct_tmp, pair_ticket, pre_partials, pre_state, g_rowpair;
+        g_bsums, g_sorted, g_list, g_count, g_bbox, g_partials, g_start2, g_pairs, g_stamps, g_pos, pack_seg, reg_s, reg_t, reg_p, reg_all, reg_f, reg_g, oct_pts, oct_cen, oct_a, oct_b, oct_tmp, pair_ticket, pre_partials, pre_state, g_rowpair, g_gate;
     HostPool pool;   // per-pair host work of batched iterations
     std::vector<kss_ctx*> workers;   // contexts of kss_register_batch's worker threads (same device, own streams)
     std::vector<unsigned long long> last_stamps;
@@ -57,19 +57,19 @@ struct kss_ctx {
     unsigned long long* h_seq = nullptr;       // host-mapped result of the fused grid kernel: NSUMS x {bits(sum), sequence number}
     unsigned long long* h_seq_dev = nullptr;
     size_t h_seq_bytes = 0;
-    // gated launches (kss_engine.hip): the next iteration's fused kernel is enqueued behind a hipStreamWaitValue64 on
-    // h_gate while the current one runs; the host releases it by writing the transform to h_xf[slot] and then the gate
+    // gated launches (kss_engine.hip): the next iteration's fused kernel is enqueued while the current one runs and polls
+    // the host-mapped record h_xf[slot]; the host answers it with the transform and the launch's stamp
     struct Gated {
         int supported = -1;                 // -1 unknown, 0 no, 1 yes
         bool want_next = false;             // set by the ICP loop: another regular iteration may follow this pass
         bool pending = false;
         int slot = 0;
-        unsigned long long gate_val = 0, seq = 0;
+        unsigned long long seq = 0;
+        int32_t stamp = 0;
         const void* d_in = nullptr; void* d_out = nullptr;
         bool fma = false, full = false, want_full = false; double max_d2 = 0.0;
     } gated;
     bool defer_wait = false;   // batched fused pass: the ICP loop polls the pairs' result slots itself
-    unsigned long long* h_gate = nullptr; unsigned long long* h_gate_dev = nullptr;
     PairState* h_xf = nullptr; PairState* h_xf_dev = nullptr;
     unsigned long long seq = 0;
     void* h_state = nullptr; size_t h_state_cap = 0;

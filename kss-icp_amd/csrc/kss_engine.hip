@@ -472,40 +472,33 @@ int wait_slots(kss_ctx* c, int nslots, double* out) {
 }
 
 // ---- gated launches of the fused single-pair pass -------------------------------------------------------------
-// Per ICP iteration the host has to see the sums, solve, and only then can the next launch carry the new transform:
-// hipLaunchKernel (~3 us on the host) and the dispatch that follows sit on the critical path.  With gating the NEXT
-// iteration's kernel is enqueued -- behind a hipStreamWaitValue64 on a host-mapped word -- while the current one runs;
-// when the transform is known the host writes it to host-mapped memory and opens the gate (one store), and the kernel,
-// already at the head of the queue, fetches it from there.  tools/waitvalue_probe.hip: host -> kernel -> host 6.0 us by
-// launch, 3.4 us through a gate.  A pre-enqueued kernel the loop does not need (convergence, the brute-force fallback,
-// an error) is CANCELLED: released with pad[0] = 1, it leaves at once.  Nothing ever waits on a cancelled kernel, and
-// no path returns with the gate closed (GatedGuard), so the stream cannot be left blocked.
-// A closed gate blocks the hardware queue its stream is mapped to, and HIP multiplexes many streams onto a few hardware
-// queues -- work of ANOTHER stream or thread can sit behind it.  That is harmless as long as no host waits for such work
-// before the gate opens.  This loop never does, and the hazards it cannot see are excluded up front: gating is used
-// only on a stream the context owns, only while the context is the only one in the process (two gated loops could each
-// wait for a kernel parked behind the other's gate), never with an all-reduce callback (its collective would queue up
-// behind the gate), and the slow path of the wait (stream synchronize) cancels the gate first.  KSS_GATED=0 turns it off.
-// Measured at C2: +3 to +7 % iterations/s.
+// Per ICP iteration the host has to see the sums, solve, and only then does the next transform exist: hipLaunchKernel
+// (~3 us on the host), the dispatch after it and the new workgroups' first loads all sat on the critical path.  With
+// gating the NEXT iteration's kernel is enqueued while the current one runs; it starts as soon as the current one ends,
+// fetches its sources and previous winners, and polls a host-mapped 64-byte record for its transform (kss_grid.hip,
+// grid_pass_kernel).  When the sums are in, the host solves, writes the transform into the record and stamps it with the
+// launch's number (one release store): the kernel goes on from there -- no stream operation, no second PCIe round trip
+// for the transform.  (Round 1 parked the kernel behind a hipStreamWaitValue64 and let it fetch the transform afterwards:
+// wait-kernel -> dispatch -> fetch were three dependent steps where this has one.)  A pre-enqueued kernel the loop does not
+// need (convergence, the brute-force fallback, an error) is CANCELLED: stamped with pad[0] = 1, it leaves at once.
+// Nothing ever waits on a cancelled kernel, no path returns with a kernel unanswered (GatedGuard), and the kernel's poll
+// is bounded, so neither side can wait forever.  A polling kernel keeps its workgroups resident (200 of ~770 slots at
+// C2): other streams still run.  Exclusions: only on a stream the context owns and only while it is the only context
+// of the process (several loops polling at once could crowd each other's real work out of the CUs), never with an
+// all-reduce callback (its collective would queue up on this stream BEHIND the polling kernel, whose transform depends
+// on it).  KSS_GATED=0 turns it off.
 static bool gated_available(kss_ctx* c) {
     static const bool want = getenv("KSS_GATED") == nullptr || atoi(getenv("KSS_GATED")) != 0;   // KSS_GATED=0 switches it off
-    // only on a stream this context owns, and only while it is the ONLY context of the process: two gated loops whose
-    // kernels share a hardware queue would each wait for a kernel parked behind the other's closed gate
     if (!want || !c->own_stream || kss_live_contexts().load() != 1) return false;
     if (c->gated.supported < 0) {
-        int can = 0;
-        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device) != hipSuccess) can = 0;
-        void *g = nullptr, *x = nullptr, *gd = nullptr, *xd = nullptr;
-        if (can && hipHostMalloc(&g, 64, hipHostMallocMapped) == hipSuccess && hipHostMalloc(&x, 2 * sizeof(PairState), hipHostMallocMapped) == hipSuccess &&
-            hipHostGetDevicePointer(&gd, g, 0) == hipSuccess && hipHostGetDevicePointer(&xd, x, 0) == hipSuccess) {
-            std::memset(g, 0, 64);
+        void *x = nullptr, *xd = nullptr;
+        if (ensure(c, c->g_gate, 256) == KSS_OK && hipMemsetAsync(c->g_gate.p, 0, 256, c->stream) == hipSuccess &&
+            hipHostMalloc(&x, 2 * sizeof(PairState), hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&xd, x, 0) == hipSuccess) {
             std::memset(x, 0, 2 * sizeof(PairState));
-            c->h_gate = (unsigned long long*)g; c->h_gate_dev = (unsigned long long*)gd;
             c->h_xf = (PairState*)x; c->h_xf_dev = (PairState*)xd;
             c->gated.supported = 1;
         } else {
             (void)hipGetLastError();
-            if (g) hipHostFree(g);
             if (x) hipHostFree(x);
             c->gated.supported = 0;
         }
@@ -513,11 +506,11 @@ static bool gated_available(kss_ctx* c) {
     return c->gated.supported == 1;
 }
 
-static void gated_release(kss_ctx* c, const PairState& st, int skip) {   // transform (or the cancel mark), then the gate
-    PairState v = st;
-    v.pad[0] = skip;
-    c->h_xf[c->gated.slot] = v;
-    __atomic_store_n(c->h_gate, ++c->gated.gate_val, __ATOMIC_RELEASE);
+static void gated_release(kss_ctx* c, const PairState& st, int skip) {   // transform (or the cancel mark), then the stamp
+    PairState* rec = &c->h_xf[c->gated.slot];
+    for (int k = 0; k < 12; ++k) rec->m[k] = st.m[k];
+    rec->active = st.active; rec->apply = st.apply; rec->pad[0] = skip;
+    __atomic_store_n(&rec->pad[1], c->gated.stamp, __ATOMIC_RELEASE);   // the kernel accepts the record when it reads this stamp
     c->gated.pending = false;
 }
 
@@ -604,18 +597,17 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
             // writes the other ping-pong buffer
             float4* nxt_out = d_out == (float4*)c->cur[0].p ? (float4*)c->cur[1].p : (float4*)c->cur[0].p;
             G.slot ^= 1;
-            if (hipStreamWaitValue64(c->stream, c->h_gate_dev, G.gate_val + 1, hipStreamWaitValueGte, 0xffffffffffffffffull) == hipSuccess) {
-                PassArgs n = pass_args(c, pl, d_out, nxt_out, max_d2, nullptr, nullptr);
-                n.ps0 = hs[0];
-                n.state = c->h_xf_dev + G.slot;
-                n.seq = ++c->seq;
-                launch_grid_pass(c->stream, fma, G.want_full, false, true, n);
-                G.pending = true; G.seq = c->seq; G.d_in = d_out; G.d_out = nxt_out; G.fma = fma; G.full = G.want_full; G.max_d2 = max_d2;
-                if (hipGetLastError() != hipSuccess) { gated_cancel(c); G.supported = 0; }   // the wait is queued: open it, give gating up
-            } else {
-                (void)hipGetLastError();
-                G.supported = 0;
-            }
+            G.stamp = (G.stamp + 1) & 0x7fffffff;
+            if (G.stamp == 0) G.stamp = 1;   // (0 is what a fresh record holds)
+            PassArgs n = pass_args(c, pl, d_out, nxt_out, max_d2, nullptr, nullptr);
+            n.ps0 = hs[0];
+            n.state = c->h_xf_dev + G.slot;
+            n.gate_seq = G.stamp;
+            n.gate_dev = (unsigned int*)c->g_gate.p;
+            n.seq = ++c->seq;
+            launch_grid_pass(c->stream, fma, G.want_full, false, true, n);
+            G.pending = true; G.seq = c->seq; G.d_in = d_out; G.d_out = nxt_out; G.fma = fma; G.full = G.want_full; G.max_d2 = max_d2;
+            if (hipGetLastError() != hipSuccess) { gated_cancel(c); G.supported = 0; }   // (if it did get queued it is answered; gating is given up)
         }
         const auto tl1 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
         KCHK(wait_seq(c, 1, want_seq));

@@ -263,8 +263,8 @@ typedef int32_t int4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-b
 
 template <bool FMA, int BS>
 __device__ __forceinline__ int block_walk(const GridParams& gp, const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
-                                          float qx, float qy, float qz, int cx, int cy, int cz, int pp, int2 (*rowq)[BS],
-                                          unsigned long long& key, int& kpos, float4& win) {
+                                          float qx, float qy, float qz, int cx, int cy, int cz, int pp, const float4 prevp,
+                                          int2 (*rowq)[BS], unsigned long long& key, int& kpos, float4& win) {
     // the four bounds of a row -- starts of cells cx-1, cx, cx+1, cx+2 -- are ONE unaligned 16-byte load (cell_start has a
     // readable element in front of cell 0 and two behind the last start): 9 loads per query instead of 36
     int s0[9], s1[9], s2[9], s3[9];
@@ -282,7 +282,7 @@ __device__ __forceinline__ int block_walk(const GridParams& gp, const int32_t* _
     }
     float d0 = __builtin_inff();
     if (pp >= 0) {
-        win = sorted[pp];
+        win = prevp;   // == sorted[pp], loaded by the caller ahead of time
         key = point_key<FMA>(win, qx, qy, qz);
         kpos = pp;
         d0 = __uint_as_float((unsigned)(key >> 32));
@@ -310,6 +310,8 @@ __device__ __forceinline__ int block_walk(const GridParams& gp, const int32_t* _
     }
     int cur = 0, end = 0, nxt = 0;
     if (nrow > 0) { const int2 v = rowq[0][threadIdx.x]; cur = v.x; end = v.y; nxt = 1; }
+    // U points in flight per step.  (Measured: predicating the loads of a lane past the end of its list -- instead of letting
+    // it repeat its last point -- turns the step into a chain of exec-masked blocks and costs 25 % of the search phase.)
     constexpr int U = GRID_WALK;
     for (int e = 0; e < total; e += U) {
         int at[U];
@@ -395,11 +397,6 @@ __global__ __launch_bounds__(PASS_BS) void grid_pass_kernel(const PassArgs a) {
     if constexpr (BATCH) {
         ps = a.state[pi];
         if (!ps.active) return;            // uniform: a converged pair costs one table read per workgroup
-    } else if (a.state) {
-        // a launch enqueued BEFORE its transform existed (behind a hipStreamWaitValue64 gate, kss_engine.hip) fetches it
-        // from host-mapped memory -- uniform address: scalar loads -- and leaves at once when the host cancelled it
-        ps = *a.state;
-        if (ps.pad[0] != 0) return;
     }
     const GridParams& gp = pr.gp;
     const int32_t* __restrict__ cs = a.cell_start + pr.cell_base;
@@ -407,6 +404,8 @@ __global__ __launch_bounds__(PASS_BS) void grid_pass_kernel(const PassArgs a) {
     __shared__ int2 rowq[9][BS];           // block_walk's per-lane queue of point ranges
     __shared__ double shw[BS / 64][NSUMS];
     __shared__ int s_last;
+    __shared__ int sh_ps[16];
+    static_assert(sizeof(PairState) == 64, "the gated launch reads the transform record as 16 dwords");
     double (*shf)[NSUMS] = reinterpret_cast<double (*)[NSUMS]>(&rowq[0][0]);   // the last workgroup's group totals: rowq is dead by then (two barriers later)
     static_assert(sizeof(double) * PASS_FG * NSUMS <= sizeof(int2) * 9 * BS, "shf must fit inside rowq");
 
@@ -418,9 +417,73 @@ __global__ __launch_bounds__(PASS_BS) void grid_pass_kernel(const PassArgs a) {
     int ev_lane = 0;                       // diagnostic runs: distance evaluations of the r = 1 block
     float qx = 0.f, qy = 0.f, qz = 0.f, d2 = 0.f;
     float4 win = make_float4(0.f, 0.f, 0.f, 0.f);
+    // what does not depend on the transform is fetched first: the source, where its last winner sits, and that point
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), prevp = p;
+    int pp = -1;
     if (valid) {
-        float4 p = SEARCH ? a.src_in[i] : a.src_out[i];
-        int pp = a.pos_prev[i];
+        p = SEARCH ? a.src_in[i] : a.src_out[i];
+        pp = a.pos_prev[i];
+        if (SEARCH && a.use_prev && pp >= 0) prevp = sorted[pp];
+    }
+    if constexpr (!BATCH && SEARCH) {
+        if (a.state) {
+            // GATED launch (kss_engine.hip): this kernel was enqueued while the previous iteration was still running, before
+            // its transform existed.  Workgroup 0 polls the host-mapped 64-byte record (one cache line, one PCIe read per poll)
+            // until the host has stamped it with this launch's number -- the host writes the stamp last and a line is read
+            // as a whole, so a matching stamp comes with its transform -- and re-publishes it in device memory, where every
+            // workgroup polls for it (200 workgroups polling HOST memory at once were measured: 45 us per iteration).  Both
+            // polls are bounded: a host that never answers makes the kernel leave without publishing, which the host's own
+            // wait reports.  pad[0] != 0: cancelled.  (The loads above are already in flight while this waits.)
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            if (w == 0 && threadIdx.x < 16) {
+                // the ONE workgroup that asks the host: lanes 0-15 read the 64-byte record as one request per poll
+                const int* w32 = reinterpret_cast<const int*>(a.state);
+                int v = 0, n = 0;
+                bool ok = true;
+                for (;;) {
+                    v = __hip_atomic_load(w32 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (__shfl(v, 15, 64) == a.gate_seq) break;      // word 15 = pad[1], written last by the host
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++n > (1 << 21)) { ok = false; break; }
+                }
+                if (ok) {
+                    // hand it to the other workgroups through device memory as five self-validating 16-byte granules
+                    // {word 3g, 3g+1, 3g+2, stamp} (one sc1 store each: a granule is never seen torn, so no flag and no
+                    // ordering between the stores is needed)
+                    const int g = threadIdx.x;
+                    const int w0 = __shfl(v, min(3 * g, 15), 64), w1 = __shfl(v, min(3 * g + 1, 15), 64), w2 = __shfl(v, min(3 * g + 2, 15), 64);
+                    if (g < 5) {
+                        u32x4 o;
+                        o.x = (unsigned)w0; o.y = (unsigned)w1; o.z = (unsigned)w2; o.w = (unsigned)a.gate_seq;
+                        unsigned int* dst = a.gate_dev + 4 * g;
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(o) : "memory");
+                    }
+                }
+            }
+            if (threadIdx.x < 8) {         // every workgroup: lanes 0-4 poll the five granules (one 80-byte request per poll)
+                const unsigned int* src = a.gate_dev + 4 * min((int)threadIdx.x, 4);
+                u32x4 v;
+                int n = 0;
+                bool ok = true;
+                for (;;) {
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(src) : "memory");
+                    if (__builtin_amdgcn_ballot_w64((int)v.w == a.gate_seq) == 0xffull) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++n > (1 << 22)) { ok = false; break; }
+                }
+                if (threadIdx.x < 5) { sh_ps[3 * threadIdx.x] = (int)v.x; sh_ps[3 * threadIdx.x + 1] = (int)v.y; sh_ps[3 * threadIdx.x + 2] = (int)v.z; }
+                if (threadIdx.x == 0) { sh_ps[15] = a.gate_seq; s_last = ok ? 1 : 0; }
+            }
+            __syncthreads();
+            if (!s_last) return;
+            int* d32 = reinterpret_cast<int*>(&ps);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) d32[k] = sh_ps[k];
+            if (ps.pad[0] != 0) return;
+            __syncthreads();               // s_last is reused by the ticket below
+        }
+    }
+    if (valid) {
         if constexpr (SEARCH) {
             if (ps.apply) {   // pcl transformCloud with the previous iteration's Matrix4f, Eigen order, float, no fma
                 const float x = p.x, y = p.y, z = p.z;
@@ -441,7 +504,7 @@ __global__ __launch_bounds__(PASS_BS) void grid_pass_kernel(const PassArgs a) {
                 const int cx = cell_coord(qx, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(qy, gp.oy, gp.inv_h, gp.gy),
                           cz = cell_coord(qz, gp.oz, gp.inv_h, gp.gz);
                 // ---- r = 1: the 3x3x3 block, pruned by the previous winner's distance ----
-                ev_lane = block_walk<FMA, BS>(gp, cs, sorted, qx, qy, qz, cx, cy, cz, a.use_prev ? pp : -1, rowq, key, kpos, win);
+                ev_lane = block_walk<FMA, BS>(gp, cs, sorted, qx, qy, qz, cx, cy, cz, a.use_prev ? pp : -1, prevp, rowq, key, kpos, win);
                 for (int r = 1; r <= gp.rcap; ++r) {
                     if (r > 1) {   // shell r: (2r+1)^2 rows
                         const int wd = 2 * r + 1;

@@ -23,7 +23,7 @@ st = buf[:k].reshape(-1, 16).astype(np.int64)
 st = st[st[:, 0] > 0]
 t0 = st[:, 0].min()
 us = lambda a: (a - t0) / 100.0
-names = [(0, "start"), (6, "src"), (8, "block"), (9, "shells"), (1, "searched"), (2, "reduced"), (3, "ticketed")]
+names = [(0, "start"), (1, "searched"), (2, "row ready"), (3, "ticketed")]
 print("workgroups:", len(st))
 for i, nm in names:
     v = us(st[:, i])
