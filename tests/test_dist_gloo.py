@@ -129,3 +129,38 @@ def test_shard_range_partitions():
                 seen += list(range(lo, hi))
             assert seen == list(range(n))
     assert C.sizeof(pkg.IcpResult) == pkg.shard.RECORD_BYTES
+
+
+def _run_bench(args, env_extra=None, timeout=300):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_bench_gpus_n_starts_n_ranks():
+    """`python bench.py --gpus 2` with no rank environment must RUN two ranks (the launcher spawns them before anything
+    touches torch / HIP) and print ONE JSON line with n_gpus = 2.  --dry-run-dist swaps the registration for a stand-in
+    so that the protocol (gloo group, barriers, MAX over ranks, padded record gather) runs on CPU."""
+    import json
+    r = _run_bench(["--gpus", "2", "--dry-run-dist", "--steps", "3", "--warmup", "1"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["dry_run"] is True
+    assert d["records_gathered_ok"] is True and d["scaling"] == "weak" and d["metric"] == "icp_iterations_per_sec"
+    # the time is the slowest rank's: rank 1 sleeps 4 ms per step
+    assert d["ms_per_step"] >= 4.0
+    assert abs(d["value"] - 3 * 50 * 2 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_rejects_a_rank_count_that_disagrees_with_the_environment():
+    """Under an existing rank environment (torch.distributed.run) --gpus must match WORLD_SIZE: a mismatch is an error,
+    never a silently smaller job."""
+    r = _run_bench(["--gpus", "4", "--dry-run-dist", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr and not r.stdout.strip()
+    r = _run_bench(["--gpus", "1", "--dry-run-dist", "--steps", "2", "--warmup", "0"])
+    assert r.returncode == 0 and '"n_gpus": 1' in r.stdout

@@ -67,6 +67,8 @@ def main():
         wa = sum(wv) / len(wv) if wv else 0.0
         rb, wb = fa * 1024 * 2, wa * 1024
         key = k.split("<")[0].replace("_kernel", "")
+        if key in summary and summary[key].get("launches", 0) > len(fv):
+            continue   # template variants share a key: keep the one launched most (the ICP-iteration form)
         summary[key] = {"kernel": k, "launches": len(fv), "fetch_size_kib_raw": fa, "read_bytes_corrected": rb,
                         "write_size_kib": wa, "write_bytes": wb, "hbm_bytes_per_launch": rb + wb}
         if k in stats:
@@ -82,7 +84,8 @@ def main():
                 lines.append("- %s = %.4g" % (c, sum(v) / len(v)))
             d = {c: sum(v) / len(v) for c, v in sq[k].items()}
             key = k.split("<")[0].replace("_kernel", "")
-            summary.setdefault(key, {})["sq"] = d
+            if summary.get(key, {}).get("kernel", k) == k:
+                summary.setdefault(key, {})["sq"] = d
     open(os.path.join(dst, "%s_rocprof_summary.md" % tag), "w").write("\n".join(lines) + "\n")
     json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
     for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
