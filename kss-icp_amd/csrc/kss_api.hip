@@ -366,7 +366,7 @@ int kss_cov_dev(kss_ctx* c, const float* d_src, const float* d_tgt, const int32_
     if (!c || !d_src || !d_tgt || !d_idx || !sums) return set_err(c, KSS_ERR_ARG, "cov: null argument");
     if (n <= 0 || nt <= 0) return set_err(c, KSS_ERR_ARG, "cov: empty input");
     HIPCHK(c, hipSetDevice(c->device));
-    const int nb = preshape_blocks(n);
+    const int nb = stream_blocks(n);
     KCHK(ensure(c, c->partials, (size_t)nb * NSUMS * sizeof(double)));
     KCHK(ensure(c, c->sums, NSUMS * sizeof(double)));
     KCHK(ensure_pinned(c, c->h_sums, c->h_sums_cap, NSUMS * sizeof(double)));

@@ -291,7 +291,6 @@ static int grid_setup(kss_ctx* c, IcpPlan& pl) {
     const size_t ncells = (size_t)gp.gx * gp.gy * gp.gz;
     KCHK(ensure(c, c->g_counts, ncells * sizeof(int32_t)));
     KCHK(ensure(c, c->g_start, (ncells + 8) * sizeof(int32_t)));   // [0] pad, starts at [1 .. ncells + 1], pads behind (block_walk reads 16 bytes per row)
-    KCHK(ensure(c, c->g_cursor, ncells * sizeof(int32_t)));
     KCHK(ensure(c, c->g_bsums, ((ncells + 4095) / 4096 + 1) * sizeof(int32_t)));
     KCHK(ensure(c, c->g_sorted, (size_t)nt * sizeof(float4)));
     KCHK(ensure(c, c->g_list, (size_t)ns * sizeof(int32_t)));
@@ -307,12 +306,12 @@ static int grid_setup(kss_ctx* c, IcpPlan& pl) {
         one->active = 1;
         HIPCHK(c, hipMemcpyAsync(c->state.p, one, sizeof *one, hipMemcpyHostToDevice, c->stream));
     }
-    launch_grid_build(c->stream, tgt, nt, gp, (int32_t*)c->g_counts.p, (int32_t*)c->g_start.p + 1, (int32_t*)c->g_cursor.p,
-                      (int32_t*)c->g_bsums.p, (float4*)c->g_sorted.p);
+    launch_grid_build(c->stream, tgt, nt, gp, (int32_t*)c->g_counts.p, (int32_t*)c->g_start.p + 1,
+                      (int32_t*)c->g_bsums.p, (float4*)c->g_sorted.p, false);
     // sources into the same cell order (original index in .w): cur[0] is the scratch of the scatter
     KCHK(ensure(c, c->g_start2, (ncells + 1) * sizeof(int32_t)));
     launch_grid_sort_sources(c->stream, (const float4*)c->src0.p + g.src_base, ns, gp, (int32_t*)c->g_counts.p,
-                             (int32_t*)c->g_start2.p, (int32_t*)c->g_cursor.p, (int32_t*)c->g_bsums.p,
+                             (int32_t*)c->g_start2.p, (int32_t*)c->g_bsums.p,
                              (float4*)c->cur[0].p, (float4*)c->src0.p + g.src_base);   // (scatter: src0 -> cur[0]; rank fix: cur[0] -> src0)
     HIPCHK(c, hipGetLastError());
     c->grid_stats[0] = gp.h; c->grid_stats[1] = gp.gx; c->grid_stats[2] = gp.gy; c->grid_stats[3] = gp.gz;
@@ -362,21 +361,19 @@ static int grid_setup_batch(kss_ctx* c, IcpPlan& pl) {
     KCHK(ensure(c, c->g_counts, (size_t)cells * sizeof(int32_t)));
     KCHK(ensure(c, c->g_start, ((size_t)cells + 8) * sizeof(int32_t)));   // [0] pad, starts at [1 ..], pads behind
     KCHK(ensure(c, c->g_start2, ((size_t)cells + 1) * sizeof(int32_t)));
-    KCHK(ensure(c, c->g_cursor, (size_t)cells * sizeof(int32_t)));
     KCHK(ensure(c, c->g_bsums, (((size_t)cells + 4095) / 4096 + 1) * sizeof(int32_t)));
     KCHK(ensure(c, c->g_sorted, (size_t)sum_nt * sizeof(float4)));
     KCHK(ensure(c, c->g_pos, (size_t)pl.total_src * sizeof(int32_t)));   // previous winners: -1 = none yet
     HIPCHK(c, hipMemsetAsync(c->g_pos.p, 0xff, (size_t)pl.total_src * sizeof(int32_t), c->stream));
     if ((cells + 4095) / 4096 > 1024 * 16) return set_err(c, KSS_ERR_ARG, "batch cell lists too large for the scan");
     launch_gridb_build_targets(c->stream, (const float4*)c->tgt4.p, (int)pl.total_tgt_pad, (const GridPairDev*)c->g_pairs.p, np,
-                               (int)cells, (int32_t*)c->g_counts.p, (int32_t*)c->g_start.p + 1, (int32_t*)c->g_cursor.p,
+                               (int)cells, (int32_t*)c->g_counts.p, (int32_t*)c->g_start.p + 1,
                                (int32_t*)c->g_bsums.p, (float4*)c->g_sorted.p);
     KCHK(ensure(c, c->g_rowpair, pl.row_pair.size() * sizeof(int32_t)));
     HIPCHK(c, hipMemcpyAsync(c->g_rowpair.p, pl.row_pair.data(), pl.row_pair.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     launch_gridb_sort_sources(c->stream, (const float4*)c->src0.p, (int)pl.total_src, (const GridPairDev*)c->g_pairs.p, np, (int)cells,
-                              (int32_t*)c->g_counts.p, (int32_t*)c->g_start2.p, (int32_t*)c->g_cursor.p, (int32_t*)c->g_bsums.p,
-                              (float4*)c->cur[0].p, (float4*)c->cur[1].p);
-    HIPCHK(c, hipMemcpyAsync(c->src0.p, c->cur[1].p, (size_t)pl.total_src * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+                              (int32_t*)c->g_counts.p, (int32_t*)c->g_start2.p, (int32_t*)c->g_bsums.p,
+                              (float4*)c->cur[0].p, (float4*)c->src0.p);   // (scatter: src0 -> cur[0]; rank fix: cur[0] -> src0)
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));   // hb is about to go out of scope (pageable)
     return KSS_OK;

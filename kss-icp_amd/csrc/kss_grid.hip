@@ -126,7 +126,7 @@ __global__ __launch_bounds__(1024) void scan_of_block_sums_kernel(int32_t* __res
 // build is ~20 launches of a few microseconds each.
 template <bool SELF>
 __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restrict__ in, int n, const int32_t* __restrict__ block_sums,
-                                                         int32_t* __restrict__ out_start, int32_t* __restrict__ cursor) {
+                                                         int32_t* __restrict__ out_start) {
     // each lane scans 16 consecutive elements, wave/LDS scan of the lane totals, plus the workgroup offset
     __shared__ int sh[256];
     __shared__ int sh_off[4];
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restri
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int i = base + k;
-        if (i < n) { out_start[i] = run; cursor[i] = run; }
+        if (i < n) out_start[i] = run;
         run += v[k];
         if (SELF && i == n - 1) out_start[n] = run;   // the total
     }
@@ -174,37 +174,42 @@ __global__ void scan_tail_kernel(const int32_t* __restrict__ counts, int32_t* __
     if (threadIdx.x == 0 && blockIdx.x == 0) start[n] = start[n - 1] + counts[n - 1];
 }
 
-static void launch_scan(hipStream_t st, const int32_t* d_counts, int ncells, int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums) {
+static void launch_scan(hipStream_t st, const int32_t* d_counts, int ncells, int32_t* d_start, int32_t* d_block_sums) {
     const int nb = (ncells + SCAN_CHUNK - 1) / SCAN_CHUNK;
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(256), 0, st, d_counts, ncells, d_block_sums);
     if (nb <= 1024) {
-        hipLaunchKernelGGL(scan_apply_kernel<true>, dim3(nb), dim3(256), 0, st, d_counts, ncells, d_block_sums, d_start, d_cursor);
+        hipLaunchKernelGGL(scan_apply_kernel<true>, dim3(nb), dim3(256), 0, st, d_counts, ncells, d_block_sums, d_start);
     } else {
         hipLaunchKernelGGL(scan_of_block_sums_kernel, dim3(1), dim3(1024), 0, st, d_block_sums, nb);
-        hipLaunchKernelGGL(scan_apply_kernel<false>, dim3(nb), dim3(256), 0, st, d_counts, ncells, d_block_sums, d_start, d_cursor);
+        hipLaunchKernelGGL(scan_apply_kernel<false>, dim3(nb), dim3(256), 0, st, d_counts, ncells, d_block_sums, d_start);
         hipLaunchKernelGGL(scan_tail_kernel, dim3(1), dim3(64), 0, st, d_counts, d_start, ncells);
     }
 }
 
 __global__ __launch_bounds__(256) void grid_scatter_kernel(const float4* __restrict__ tgt, int n, GridParams gp,
-                                                           int32_t* __restrict__ cursor, float4* __restrict__ sorted) {
+                                                           int32_t* __restrict__ counts, const int32_t* __restrict__ start,
+                                                           float4* __restrict__ sorted) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float4 p = tgt[i];
     const int cx = cell_coord(p.x, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(p.y, gp.oy, gp.inv_h, gp.gy),
               cz = cell_coord(p.z, gp.oz, gp.inv_h, gp.gz);
-    const int pos = atomicAdd(&cursor[(cz * gp.gy + cy) * gp.gx + cx], 1);
+    // the cell's count doubles as its cursor: counting DOWN hands out the slots start + count-1 .. start and leaves the
+    // array zeroed for the next build (no separate cursor array for the scan to write, no memset in between)
+    const int cell = (cz * gp.gy + cy) * gp.gx + cx;
+    const int pos = start[cell] + atomicSub(&counts[cell], 1) - 1;
     p.w = __int_as_float(i);   // original index rides in .w
     sorted[pos] = p;
 }
 
+// counts_are_zero: the previous build over the same cells left them so (its scatter counts every cell back down)
 void launch_grid_build(hipStream_t st, const float4* d_tgt, int n, const GridParams& gp, int32_t* d_counts,
-                       int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums, float4* d_sorted) {
+                       int32_t* d_start, int32_t* d_block_sums, float4* d_sorted, bool counts_are_zero) {
     const int ncells = gp.gx * gp.gy * gp.gz;
-    hipMemsetAsync(d_counts, 0, (size_t)ncells * sizeof(int32_t), st);
+    if (!counts_are_zero) hipMemsetAsync(d_counts, 0, (size_t)ncells * sizeof(int32_t), st);
     hipLaunchKernelGGL(grid_count_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_tgt, n, gp, d_counts);
-    launch_scan(st, d_counts, ncells, d_start, d_cursor, d_block_sums);
-    hipLaunchKernelGGL(grid_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_tgt, n, gp, d_cursor, d_sorted);
+    launch_scan(st, d_counts, ncells, d_start, d_block_sums);
+    hipLaunchKernelGGL(grid_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_tgt, n, gp, d_counts, (const int32_t*)d_start, d_sorted);
 }
 
 // ---- query -----------------------------------------------------------------------------------------------
@@ -355,8 +360,8 @@ __global__ __launch_bounds__(256) void grid_rank_fix_kernel(const float4* __rest
 }
 
 void launch_grid_sort_sources(hipStream_t st, const float4* d_src, int n, const GridParams& gp, int32_t* d_counts,
-                              int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums, float4* d_tmp, float4* d_out) {
-    launch_grid_build(st, d_src, n, gp, d_counts, d_start, d_cursor, d_block_sums, d_tmp);
+                              int32_t* d_start, int32_t* d_block_sums, float4* d_tmp, float4* d_out) {
+    launch_grid_build(st, d_src, n, gp, d_counts, d_start, d_block_sums, d_tmp, true);   // (right after the target build over the same cells)
     hipLaunchKernelGGL(grid_rank_fix_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_tmp, n, gp, d_start, d_out);
 }
 
@@ -726,13 +731,19 @@ __global__ __launch_bounds__(256) void gridb_bbox_kernel(const float4* __restric
 }
 
 // counts (SCATTER = false) or scatter into cell order (SCATTER = true) of targets (BY_SRC = false: positions of
-// tgt4, padding skipped, .w = pair-relative index) or sources (BY_SRC = true: .w = global source index)
+// tgt4, padding skipped, .w = pair-relative index) or sources (BY_SRC = true: .w = global source index).
+// The pair of a slot: ONE binary search per workgroup for its first slot (uniform: scalar loads), then a short walk per
+// lane (a per-lane search over 1024 pairs was ten dependent loads per point: 0.4 of the 0.5 ms this kernel took at C3).
+// The scatter counts each cell back DOWN (slots start + count-1 .. start): no cursor array, counts end zeroed.
 template <bool SCATTER, bool BY_SRC>
 __global__ __launch_bounds__(256) void gridb_bin_kernel(const float4* __restrict__ pts, int total, const GridPairDev* __restrict__ pairs,
-                                                        int npairs, int32_t* __restrict__ counts_or_cursor, float4* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+                                                        int npairs, int32_t* __restrict__ counts, const int32_t* __restrict__ start,
+                                                        float4* __restrict__ out) {
+    const int i0 = blockIdx.x * blockDim.x;
+    int pi = pair_of(i0, pairs, npairs, BY_SRC);
+    const int i = i0 + threadIdx.x;
     if (i >= total) return;
-    const int pi = pair_of(i, pairs, npairs, BY_SRC);
+    while (pi + 1 < npairs && (BY_SRC ? pairs[pi + 1].src_base : pairs[pi + 1].tgt_base) <= i) ++pi;
     const GridPairDev pr = pairs[pi];
     const int local = i - (BY_SRC ? pr.src_base : pr.tgt_base);
     if (local >= (BY_SRC ? pr.src_n : pr.tgt_n)) return;   // sentinel padding of the target layout
@@ -742,21 +753,22 @@ __global__ __launch_bounds__(256) void gridb_bin_kernel(const float4* __restrict
               cz = cell_coord(p.z, gp.oz, gp.inv_h, gp.gz);
     const int cell = pr.cell_base + (cz * gp.gy + cy) * gp.gx + cx;
     if constexpr (SCATTER) {
-        const int pos = atomicAdd(&counts_or_cursor[cell], 1);
+        const int pos = start[cell] + atomicSub(&counts[cell], 1) - 1;
         p.w = __int_as_float(BY_SRC ? i : local);
         out[pos] = p;
     } else {
-        atomicAdd(&counts_or_cursor[cell], 1);
+        atomicAdd(&counts[cell], 1);
     }
 }
 
 // deterministic in-cell order for the sources (see grid_rank_fix_kernel)
 __global__ __launch_bounds__(256) void gridb_rank_fix_kernel(const float4* __restrict__ tmp, int total, const GridPairDev* __restrict__ pairs,
                                                              int npairs, const int32_t* __restrict__ start, float4* __restrict__ out) {
+    int pi = pair_of((int)(blockIdx.x * blockDim.x), pairs, npairs, true);   // uniform; sorted positions stay inside the pair's source segment
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= total) return;
+    while (pi + 1 < npairs && pairs[pi + 1].src_base <= j) ++pi;
     const float4 p = tmp[j];
-    const int pi = pair_of(j, pairs, npairs, true);   // sorted positions stay inside the pair's source segment
     const GridPairDev pr = pairs[pi];
     const GridParams& gp = pr.gp;
     const int cx = cell_coord(p.x, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(p.y, gp.oy, gp.inv_h, gp.gy),
@@ -775,24 +787,22 @@ void launch_gridb_bbox(hipStream_t st, const float4* d_tgt, const GridPairDev* d
 
 // targets: tgt4 (padded layout, total_tgt_pad slots) -> d_sorted (pair by pair, sum of nt entries), d_start
 void launch_gridb_build_targets(hipStream_t st, const float4* d_tgt, int total_tgt_pad, const GridPairDev* d_pairs, int npairs,
-                                int total_cells, int32_t* d_counts, int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums,
-                                float4* d_sorted) {
+                                int total_cells, int32_t* d_counts, int32_t* d_start, int32_t* d_block_sums, float4* d_sorted) {
     hipMemsetAsync(d_counts, 0, (size_t)total_cells * sizeof(int32_t), st);
     const dim3 grid((total_tgt_pad + 255) / 256), block(256);
-    hipLaunchKernelGGL((gridb_bin_kernel<false, false>), grid, block, 0, st, d_tgt, total_tgt_pad, d_pairs, npairs, d_counts, (float4*)nullptr);
-    launch_scan(st, d_counts, total_cells, d_start, d_cursor, d_block_sums);
-    hipLaunchKernelGGL((gridb_bin_kernel<true, false>), grid, block, 0, st, d_tgt, total_tgt_pad, d_pairs, npairs, d_cursor, d_sorted);
+    hipLaunchKernelGGL((gridb_bin_kernel<false, false>), grid, block, 0, st, d_tgt, total_tgt_pad, d_pairs, npairs, d_counts, (const int32_t*)nullptr, (float4*)nullptr);
+    launch_scan(st, d_counts, total_cells, d_start, d_block_sums);
+    hipLaunchKernelGGL((gridb_bin_kernel<true, false>), grid, block, 0, st, d_tgt, total_tgt_pad, d_pairs, npairs, d_counts, (const int32_t*)d_start, d_sorted);
 }
 
-// sources: d_src (total_src float4) -> d_out in (pair, cell, original index) order; d_tmp is scratch
+// sources: d_src (total_src float4) -> d_out in (pair, cell, original index) order; d_tmp is scratch (d_out may be d_src).
+// Runs right after the target build over the same cells: the counts are zero again.
 void launch_gridb_sort_sources(hipStream_t st, const float4* d_src, int total_src, const GridPairDev* d_pairs, int npairs,
-                               int total_cells, int32_t* d_counts, int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums,
-                               float4* d_tmp, float4* d_out) {
-    hipMemsetAsync(d_counts, 0, (size_t)total_cells * sizeof(int32_t), st);
+                               int total_cells, int32_t* d_counts, int32_t* d_start, int32_t* d_block_sums, float4* d_tmp, float4* d_out) {
     const dim3 grid((total_src + 255) / 256), block(256);
-    hipLaunchKernelGGL((gridb_bin_kernel<false, true>), grid, block, 0, st, d_src, total_src, d_pairs, npairs, d_counts, (float4*)nullptr);
-    launch_scan(st, d_counts, total_cells, d_start, d_cursor, d_block_sums);
-    hipLaunchKernelGGL((gridb_bin_kernel<true, true>), grid, block, 0, st, d_src, total_src, d_pairs, npairs, d_cursor, d_tmp);
+    hipLaunchKernelGGL((gridb_bin_kernel<false, true>), grid, block, 0, st, d_src, total_src, d_pairs, npairs, d_counts, (const int32_t*)nullptr, (float4*)nullptr);
+    launch_scan(st, d_counts, total_cells, d_start, d_block_sums);
+    hipLaunchKernelGGL((gridb_bin_kernel<true, true>), grid, block, 0, st, d_src, total_src, d_pairs, npairs, d_counts, (const int32_t*)d_start, d_tmp);
     hipLaunchKernelGGL(gridb_rank_fix_kernel, grid, block, 0, st, d_tmp, total_src, d_pairs, npairs, d_start, d_out);
 }
 

@@ -163,20 +163,18 @@ void launch_nn_sweep_list(hipStream_t st, int S, bool fma, const NNWork* d_work,
                           unsigned long long* d_keys, const int32_t* d_list, const int32_t* d_count);
 void launch_grid_bbox(hipStream_t st, const float4* d_tgt, int n, float* d_partial, int n_blocks);
 void launch_grid_build(hipStream_t st, const float4* d_tgt, int n, const GridParams& gp, int32_t* d_counts,
-                       int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums, float4* d_sorted);
+                       int32_t* d_start, int32_t* d_block_sums, float4* d_sorted, bool counts_are_zero);
 int grid_pass_blocks(int total_rows);
 void launch_grid_pass(hipStream_t st, bool fma, bool full, bool batch, bool search, const PassArgs& a);
 void launch_gridb_bbox(hipStream_t st, const float4* d_tgt, const GridPairDev* d_pairs, int npairs, float* d_bbox);
 void launch_gridb_build_targets(hipStream_t st, const float4* d_tgt, int total_tgt_pad, const GridPairDev* d_pairs, int npairs,
-                                int total_cells, int32_t* d_counts, int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums,
-                                float4* d_sorted);
+                                int total_cells, int32_t* d_counts, int32_t* d_start, int32_t* d_block_sums, float4* d_sorted);
 void launch_gridb_sort_sources(hipStream_t st, const float4* d_src, int total_src, const GridPairDev* d_pairs, int npairs,
-                               int total_cells, int32_t* d_counts, int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums,
-                               float4* d_tmp, float4* d_out);
+                               int total_cells, int32_t* d_counts, int32_t* d_start, int32_t* d_block_sums, float4* d_tmp, float4* d_out);
 void launch_grid_stats(hipStream_t st, const float4* d_src, int ns, const GridParams& gp, const int32_t* d_cell_start,
                        unsigned long long* d_out /* [0] evaluations of the 3x3x3 block, [1] occupied cells */);
 void launch_grid_sort_sources(hipStream_t st, const float4* d_src, int n, const GridParams& gp, int32_t* d_counts,
-                              int32_t* d_start, int32_t* d_cursor, int32_t* d_block_sums, float4* d_tmp, float4* d_out);
+                              int32_t* d_start, int32_t* d_block_sums, float4* d_tmp, float4* d_out);
 
 void launch_corr_reduce(hipStream_t st, const RedWork* d_work, int n_work, const PairState* d_state,
                         const float4* d_src, const float4* d_tgt4, const unsigned long long* d_keys,
@@ -219,6 +217,7 @@ void launch_knn_sweep(hipStream_t st, const float4* d_qry, int nq, const float4*
 void launch_normals(hipStream_t st, const float4* d_pts, int n, const int32_t* d_knn, int k, double* d_normals);
 
 int preshape_blocks(int64_t n);
+int stream_blocks(int64_t n);
 
 // AIVS down-sampler (kss_aivs.hip): indices of the selected points in the reference's output order
 int aivs_device(hipStream_t st, const double* d_xyz, int n, int point_num, std::vector<int32_t>& out_idx, std::string& err,

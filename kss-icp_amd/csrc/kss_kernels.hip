@@ -62,13 +62,15 @@ void launch_empty(hipStream_t st) { hipLaunchKernelGGL(empty_kernel, dim3(1), di
 template <typename T>
 __global__ __launch_bounds__(256) void pack_batch_kernel(const T* __restrict__ in, const PackSeg* __restrict__ seg, int nseg,
                                                          int64_t total_out, float4* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total_out) return;
-    int lo = 0, hi = nseg - 1;
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x;
+    int lo = 0, hi = nseg - 1;             // ONE search per workgroup (uniform: scalar loads), then a short walk per lane
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (seg[mid].out_base <= i) lo = mid; else hi = mid - 1;
+        if (seg[mid].out_base <= i0) lo = mid; else hi = mid - 1;
     }
+    const int64_t i = i0 + threadIdx.x;
+    if (i >= total_out) return;
+    while (lo + 1 < nseg && seg[lo + 1].out_base <= i) ++lo;
     const PackSeg sg = seg[lo];
     const int64_t k = i - sg.out_base;
     float4 v;
@@ -434,9 +436,19 @@ void launch_finalize_sums(hipStream_t st, const PairRed* d_pairs, int n_pairs, c
 // The block decomposition of a cloud depends on its size only, so "both clouds in one call" and "one call per cloud"
 // give the same bits.
 // ---------------------------------------------------------------------------------------------
-int preshape_blocks(int64_t n) {
+int stream_blocks(int64_t n) {   // streaming kernels without a hand-over: 256 CUs x 8 workgroups, grid-stride beyond
     int64_t b = (n + 255) / 256;
-    if (b > 2048) b = 2048;   // 256 CUs x 8 workgroups, grid-stride beyond
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+int preshape_blocks(int64_t n) {
+    // >= 8 points per lane before another workgroup is added: every workgroup costs a row hand-over and a ticket on the
+    // cloud's counter (one counter takes ~12 ns per ticket: 2048 workgroups on a 1M-point cloud spent 25 us per launch
+    // queueing there).  Capped at 256 CUs x 8 workgroups, grid-stride beyond (64M points: 2048 workgroups, as before).
+    int64_t b = (n + 2047) / 2048;
+    if (b > 2048) b = 2048;
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -679,7 +691,7 @@ void launch_pose_apply(hipStream_t st, const double* d_in, int64_t n, const kss_
     for (int k = 0; k < 3; ++k) { a.shift[k] = pose.shift[k]; a.center[k] = pose.center[k]; }
     a.scale = pose.scale;
     for (int k = 0; k < 6; ++k) a.cs[k] = cs[k];
-    hipLaunchKernelGGL(pose_apply_kernel, dim3(preshape_blocks(n)), dim3(256), 0, st, d_in, n, a, d_out);
+    hipLaunchKernelGGL(pose_apply_kernel, dim3(stream_blocks(n)), dim3(256), 0, st, d_in, n, a, d_out);
 }
 
 struct M34 { float m[12]; };
@@ -699,7 +711,7 @@ void launch_transform_apply_f64(hipStream_t st, const float T[16], const double*
     if (n <= 0) return;
     M34 m;
     for (int k = 0; k < 12; ++k) m.m[k] = T[k];
-    hipLaunchKernelGGL(transform_apply_f64_kernel, dim3(preshape_blocks(n)), dim3(256), 0, st, d_in, n, m, d_out);
+    hipLaunchKernelGGL(transform_apply_f64_kernel, dim3(stream_blocks(n)), dim3(256), 0, st, d_in, n, m, d_out);
 }
 
 __global__ __launch_bounds__(256) void transform_apply_f32_kernel(const float* __restrict__ in, int64_t n, M34 T,
@@ -716,7 +728,7 @@ void launch_transform_apply_f32(hipStream_t st, const float T[16], const float* 
     if (n <= 0) return;
     M34 m;
     for (int k = 0; k < 12; ++k) m.m[k] = T[k];
-    hipLaunchKernelGGL(transform_apply_f32_kernel, dim3(preshape_blocks(n)), dim3(256), 0, st, d_in, n, m, d_out);
+    hipLaunchKernelGGL(transform_apply_f32_kernel, dim3(stream_blocks(n)), dim3(256), 0, st, d_in, n, m, d_out);
 }
 
 // ---------------------------------------------------------------------------------------------
