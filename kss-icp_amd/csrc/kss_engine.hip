@@ -346,34 +346,46 @@ static int grid_setup_batch(kss_ctx* c, IcpPlan& pl) {
     std::vector<float> hb((size_t)np * 6);
     HIPCHK(c, hipMemcpyAsync(hb.data(), c->g_bbox.p, hb.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    int64_t cells = 0;
+    int64_t cells = 0, sorted_base = 0;
+    int most_cells = 0;
     for (int p = 0; p < np; ++p) {
         const float* b = &hb[(size_t)p * 6];
         for (int k = 0; k < 6; ++k)
             if (!std::isfinite(b[k])) return set_err(c, KSS_ERR_ARG, "non-finite target coordinates");
         choose_cells(b, b + 3, pl.g[p].nt, hp[p].gp);
         hp[p].cell_base = (int32_t)cells;
-        cells += (int64_t)hp[p].gp.gx * hp[p].gp.gy * hp[p].gp.gz;
+        hp[p].sorted_base = (int32_t)sorted_base;
+        const int64_t nc = (int64_t)hp[p].gp.gx * hp[p].gp.gy * hp[p].gp.gz;
+        most_cells = (int)std::max<int64_t>(most_cells, nc);
+        cells += nc;
+        sorted_base += pl.g[p].nt;
         if (cells > 0x7fff0000ll) return set_err(c, KSS_ERR_ARG, "batch cell lists exceed 32-bit indexing");
     }
     pl.total_cells = (int)cells;
     HIPCHK(c, hipMemcpyAsync(c->g_pairs.p, hp.data(), (size_t)np * sizeof(GridPairDev), hipMemcpyHostToDevice, c->stream));
-    KCHK(ensure(c, c->g_counts, (size_t)cells * sizeof(int32_t)));
     KCHK(ensure(c, c->g_start, ((size_t)cells + 8) * sizeof(int32_t)));   // [0] pad, starts at [1 ..], pads behind
-    KCHK(ensure(c, c->g_start2, ((size_t)cells + 1) * sizeof(int32_t)));
-    KCHK(ensure(c, c->g_bsums, (((size_t)cells + 4095) / 4096 + 1) * sizeof(int32_t)));
     KCHK(ensure(c, c->g_sorted, (size_t)sum_nt * sizeof(float4)));
     KCHK(ensure(c, c->g_pos, (size_t)pl.total_src * sizeof(int32_t)));   // previous winners: -1 = none yet
     HIPCHK(c, hipMemsetAsync(c->g_pos.p, 0xff, (size_t)pl.total_src * sizeof(int32_t), c->stream));
-    if ((cells + 4095) / 4096 > 1024 * 16) return set_err(c, KSS_ERR_ARG, "batch cell lists too large for the scan");
-    launch_gridb_build_targets(c->stream, (const float4*)c->tgt4.p, (int)pl.total_tgt_pad, (const GridPairDev*)c->g_pairs.p, np,
-                               (int)cells, (int32_t*)c->g_counts.p, (int32_t*)c->g_start.p + 1,
-                               (int32_t*)c->g_bsums.p, (float4*)c->g_sorted.p);
     KCHK(ensure(c, c->g_rowpair, pl.row_pair.size() * sizeof(int32_t)));
     HIPCHK(c, hipMemcpyAsync(c->g_rowpair.p, pl.row_pair.data(), pl.row_pair.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    launch_gridb_sort_sources(c->stream, (const float4*)c->src0.p, (int)pl.total_src, (const GridPairDev*)c->g_pairs.p, np, (int)cells,
-                              (int32_t*)c->g_counts.p, (int32_t*)c->g_start2.p, (int32_t*)c->g_bsums.p,
-                              (float4*)c->cur[0].p, (float4*)c->src0.p);   // (scatter: src0 -> cur[0]; rank fix: cur[0] -> src0)
+    static const bool no_lds = getenv("KSS_GRIDB_NOLDS") != nullptr;   // A/B switch: always the global-atomic build
+    if (most_cells <= gridb_lds_max_cells() && !no_lds) {
+        // every pair's counters fit a CU's LDS: one workgroup per pair builds both of its lists (kss_grid.hip)
+        launch_gridb_build_lds(c->stream, (const float4*)c->tgt4.p, (float4*)c->src0.p, (float4*)c->cur[0].p, (const GridPairDev*)c->g_pairs.p, np,
+                               (int32_t*)c->g_start.p + 1, (float4*)c->g_sorted.p);
+    } else {
+        KCHK(ensure(c, c->g_counts, (size_t)cells * sizeof(int32_t)));
+        KCHK(ensure(c, c->g_start2, ((size_t)cells + 1) * sizeof(int32_t)));
+        KCHK(ensure(c, c->g_bsums, (((size_t)cells + 4095) / 4096 + 1) * sizeof(int32_t)));
+        if ((cells + 4095) / 4096 > 1024 * 16) return set_err(c, KSS_ERR_ARG, "batch cell lists too large for the scan");
+        launch_gridb_build_targets(c->stream, (const float4*)c->tgt4.p, (int)pl.total_tgt_pad, (const GridPairDev*)c->g_pairs.p, np,
+                                   (int)cells, (int32_t*)c->g_counts.p, (int32_t*)c->g_start.p + 1,
+                                   (int32_t*)c->g_bsums.p, (float4*)c->g_sorted.p);
+        launch_gridb_sort_sources(c->stream, (const float4*)c->src0.p, (int)pl.total_src, (const GridPairDev*)c->g_pairs.p, np, (int)cells,
+                                  (int32_t*)c->g_counts.p, (int32_t*)c->g_start2.p, (int32_t*)c->g_bsums.p,
+                                  (float4*)c->cur[0].p, (float4*)c->src0.p);   // (scatter: src0 -> cur[0]; rank fix: cur[0] -> src0)
+    }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));   // hb is about to go out of scope (pageable)
     return KSS_OK;
@@ -653,7 +665,8 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
         // workgroups) gets the table copied to device memory once per pass.
         PassArgs a = pass_args(c, pl, d_in, d_out, max_d2, d_idx_out, d_d2_out);
         a.state = (const PairState*)c->state.p;
-        if (pl.total_rows <= 512) {
+        static const int host_state_rows = [] { const char* e = getenv("KSS_BATCH_HOST_STATE_ROWS"); return e ? atoi(e) : 512; }();   // tuning hook
+        if (pl.total_rows <= host_state_rows) {
             void* dev = nullptr;
             if (hipHostGetDevicePointer(&dev, c->h_state, 0) == hipSuccess && dev) a.state = (const PairState*)dev;
         }

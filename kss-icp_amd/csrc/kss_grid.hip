@@ -806,6 +806,153 @@ void launch_gridb_sort_sources(hipStream_t st, const float4* d_src, int total_sr
     hipLaunchKernelGGL(gridb_rank_fix_kernel, grid, block, 0, st, d_tmp, total_src, d_pairs, npairs, d_start, d_out);
 }
 
+// ---- one workgroup builds one pair's cell lists entirely in LDS --------------------------------------------------
+// The global-atomic path above spends ~0.4 ms per bin launch at C3 (10M scattered atomics over a 110 MB count array,
+// four launches) plus two 330 MB scans.  A C3-size pair has ~27k cells: its counters fit the CU's LDS, so ONE
+// workgroup per pair does count -> scan -> scatter for the targets, then count -> scan -> scatter -> rank fix for the
+// sources, with LDS atomics only; global memory sees each point once on the way in and once on the way out.
+// Same outputs as the global path: cell_start (global positions in `sorted`), `sorted` (.w = index inside the pair's
+// target; order inside a cell is arbitrary, the search's tie rule does not depend on it), sources in (cell, original
+// index) order with .w = global source index.
+constexpr int GB_THREADS = 1024;
+constexpr int GB_MAX_CELLS = 36 * 1024;   // 144 KB of counters (+ the scan's wave totals): one workgroup per CU
+
+int gridb_lds_max_cells() { return GB_MAX_CELLS; }
+
+// exclusive scan of cnt[0 .. n) in place by the whole workgroup; returns the total in every thread.
+// store_global != nullptr: also writes base + start to store_global[c] and base + total to store_global[n].
+__device__ __forceinline__ int lds_exclusive_scan(int32_t* cnt, int n, int32_t* wave_tot, int32_t* __restrict__ store_global, int base) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = (n + GB_THREADS - 1) / GB_THREADS;
+    const int lo = min(tid * chunk, n), hi = min(lo + chunk, n);
+    int s = 0;
+    for (int c = lo; c < hi; ++c) s += cnt[c];
+    int incl = s;   // inclusive scan of the per-thread totals inside the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int woff = 0, total = 0;
+    for (int k = 0; k < GB_THREADS / 64; ++k) {
+        const int v = wave_tot[k];
+        if (k < wave) woff += v;
+        total += v;
+    }
+    int run = woff + incl - s;
+    for (int c = lo; c < hi; ++c) {
+        const int v = cnt[c];
+        cnt[c] = run;
+        if (store_global) store_global[c] = base + run;
+        run += v;
+    }
+    if (store_global && tid == 0) store_global[n] = base + total;
+    __syncthreads();
+    return total;
+}
+
+__global__ __launch_bounds__(GB_THREADS) void gridb_build_pair_kernel(const float4* __restrict__ tgt4, const float4* src_in, float4* src_tmp,
+                                                                      float4* src_out, const GridPairDev* __restrict__ pairs,
+                                                                      int32_t* __restrict__ cell_start, float4* __restrict__ sorted) {
+    __shared__ int32_t cnt[GB_MAX_CELLS];
+    __shared__ int32_t wave_tot[GB_THREADS / 64];
+    const GridPairDev pr = pairs[blockIdx.x];
+    const GridParams& gp = pr.gp;
+    const int ncells = gp.gx * gp.gy * gp.gz;
+    const int tid = threadIdx.x;
+    auto cell_of = [&](const float4& p) {
+        return (cell_coord(p.z, gp.oz, gp.inv_h, gp.gz) * gp.gy + cell_coord(p.y, gp.oy, gp.inv_h, gp.gy)) * gp.gx + cell_coord(p.x, gp.ox, gp.inv_h, gp.gx);
+    };
+    // Every pass over the points takes them GB_U at a time per lane: the loads of a batch are issued together and the LDS
+    // atomics follow (one load, one atomic per trip was a chain of ~10 memory round trips per pass, 130 us per pair).
+    constexpr int GB_U = 8;
+    // ---- targets ----
+    for (int c = tid; c < ncells; c += GB_THREADS) cnt[c] = 0;
+    __syncthreads();
+    const float4* __restrict__ tp = tgt4 + pr.tgt_base;
+    for (int k0 = tid; k0 < pr.tgt_n; k0 += GB_THREADS * GB_U) {
+        float4 p[GB_U];
+#pragma unroll
+        for (int u = 0; u < GB_U; ++u) p[u] = tp[min(k0 + u * GB_THREADS, pr.tgt_n - 1)];
+#pragma unroll
+        for (int u = 0; u < GB_U; ++u)
+            if (k0 + u * GB_THREADS < pr.tgt_n) atomicAdd(&cnt[cell_of(p[u])], 1);
+    }
+    __syncthreads();
+    lds_exclusive_scan(cnt, ncells, wave_tot, cell_start + pr.cell_base, pr.sorted_base);
+    float4* __restrict__ so = sorted + pr.sorted_base;
+    for (int k0 = tid; k0 < pr.tgt_n; k0 += GB_THREADS * GB_U) {
+        float4 p[GB_U];
+#pragma unroll
+        for (int u = 0; u < GB_U; ++u) p[u] = tp[min(k0 + u * GB_THREADS, pr.tgt_n - 1)];
+#pragma unroll
+        for (int u = 0; u < GB_U; ++u) {
+            const int k = k0 + u * GB_THREADS;
+            if (k < pr.tgt_n) {
+                const int pos = atomicAdd(&cnt[cell_of(p[u])], 1);   // the start array doubles as the cursor
+                p[u].w = __int_as_float(k);
+                so[pos] = p[u];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- sources: same cells ----
+    for (int c = tid; c < ncells; c += GB_THREADS) cnt[c] = 0;
+    __syncthreads();
+    const float4* sp = src_in + pr.src_base;
+    for (int k0 = tid; k0 < pr.src_n; k0 += GB_THREADS * GB_U) {
+        float4 p[GB_U];
+#pragma unroll
+        for (int u = 0; u < GB_U; ++u) p[u] = sp[min(k0 + u * GB_THREADS, pr.src_n - 1)];
+#pragma unroll
+        for (int u = 0; u < GB_U; ++u)
+            if (k0 + u * GB_THREADS < pr.src_n) atomicAdd(&cnt[cell_of(p[u])], 1);
+    }
+    __syncthreads();
+    lds_exclusive_scan(cnt, ncells, wave_tot, nullptr, 0);
+    float4* tmp = src_tmp + pr.src_base;
+    for (int k0 = tid; k0 < pr.src_n; k0 += GB_THREADS * GB_U) {
+        float4 p[GB_U];
+#pragma unroll
+        for (int u = 0; u < GB_U; ++u) p[u] = sp[min(k0 + u * GB_THREADS, pr.src_n - 1)];
+#pragma unroll
+        for (int u = 0; u < GB_U; ++u) {
+            const int k = k0 + u * GB_THREADS;
+            if (k < pr.src_n) {
+                const int pos = atomicAdd(&cnt[cell_of(p[u])], 1);   // afterwards cnt[c] = END of cell c = start of cell c + 1
+                p[u].w = __int_as_float(pr.src_base + k);
+                tmp[pos] = p[u];
+            }
+        }
+    }
+    __syncthreads();   // (its release / acquire at workgroup scope makes the tmp stores visible to the loads below)
+    // deterministic in-cell order: rank by original index (see grid_rank_fix_kernel)
+    float4* out = src_out + pr.src_base;
+    for (int j0 = tid; j0 < pr.src_n; j0 += GB_THREADS * GB_U) {
+        float4 p[GB_U];
+#pragma unroll
+        for (int u = 0; u < GB_U; ++u) p[u] = tmp[min(j0 + u * GB_THREADS, pr.src_n - 1)];
+#pragma unroll
+        for (int u = 0; u < GB_U; ++u) {
+            if (j0 + u * GB_THREADS >= pr.src_n) continue;
+            const int c = cell_of(p[u]);
+            const int lo = c > 0 ? cnt[c - 1] : 0, hi = cnt[c];
+            const int me = __float_as_int(p[u].w);
+            int rank = 0;
+            for (int k = lo; k < hi; ++k) rank += __float_as_int(tmp[k].w) < me ? 1 : 0;
+            out[lo + rank] = p[u];
+        }
+    }
+}
+
+void launch_gridb_build_lds(hipStream_t st, const float4* d_tgt4, float4* d_src, float4* d_tmp, const GridPairDev* d_pairs, int npairs,
+                            int32_t* d_cell_start, float4* d_sorted) {
+    hipLaunchKernelGGL(gridb_build_pair_kernel, dim3(npairs), dim3(GB_THREADS), 0, st, d_tgt4, (const float4*)d_src, d_tmp, d_src, d_pairs,
+                       d_cell_start, d_sorted);
+}
+
 // statistics for the roofline statement: evaluations of one r = 1 pass and occupied cells (profiling only)
 __global__ __launch_bounds__(256) void grid_stats_kernel(const float4* __restrict__ src, int ns, GridParams gp,
                                                          const int32_t* __restrict__ cell_start, unsigned long long* __restrict__ out) {

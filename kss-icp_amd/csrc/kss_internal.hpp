@@ -72,6 +72,7 @@ struct alignas(16) GridPairDev {
     int32_t src_base, src_n;    // source segment
     int32_t tgt_pad;            // slots of the target segment in tgt4 (multiple of NN_TILE, +inf sentinels behind tgt_n)
     int32_t row_base, n_rows;   // this pair's chunks of 512 sources = workgroups of the fused pass = partial rows
+    int32_t sorted_base;        // first slot of this pair's targets in the cell-ordered array (sum of the earlier pairs' target counts)
 };
 
 // one pair's target segment for the batched pack kernel
@@ -171,6 +172,10 @@ void launch_gridb_build_targets(hipStream_t st, const float4* d_tgt, int total_t
                                 int total_cells, int32_t* d_counts, int32_t* d_start, int32_t* d_block_sums, float4* d_sorted);
 void launch_gridb_sort_sources(hipStream_t st, const float4* d_src, int total_src, const GridPairDev* d_pairs, int npairs,
                                int total_cells, int32_t* d_counts, int32_t* d_start, int32_t* d_block_sums, float4* d_tmp, float4* d_out);
+int gridb_lds_max_cells();
+// all of a batch's cell lists, one workgroup per pair, counters in LDS (every pair must have <= gridb_lds_max_cells() cells)
+void launch_gridb_build_lds(hipStream_t st, const float4* d_tgt4, float4* d_src, float4* d_tmp, const GridPairDev* d_pairs, int npairs,
+                            int32_t* d_cell_start, float4* d_sorted);
 void launch_grid_stats(hipStream_t st, const float4* d_src, int ns, const GridParams& gp, const int32_t* d_cell_start,
                        unsigned long long* d_out /* [0] evaluations of the 3x3x3 block, [1] occupied cells */);
 void launch_grid_sort_sources(hipStream_t st, const float4* d_src, int n, const GridParams& gp, int32_t* d_counts,
