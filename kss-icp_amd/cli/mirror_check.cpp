@@ -44,6 +44,24 @@ int main(int argc, char** argv) {
         std::printf("JUDGE %.17g\n", f);
         const double f2 = ki.shapeRegistration_ICP(1000, P, T);
         std::printf("ICP2 %.17g ALIGN0 %.17g %.17g %.17g\n", f2, ki.pointAlign[0][0], ki.pointAlign[0][1], ki.pointAlign[0][2]);
+        // the members no front-end path reaches: the full-resolution overload (KSS_ICP.hpp:133-183: ICP on the MEMBER
+        // clouds, pointAlign = PCL's float output cloud), the registered-cloud variant (:276-321) and the two pose helpers
+        // of initRegistration_KSS (:95-140)
+        KSSICP k3;
+        k3.KSSICP_init(P, T, 6);
+        const double f3 = k3.shapeRegistration_ICP(1000);
+        const size_t last = k3.pointAlign.size() - 1;
+        std::printf("ICPFULL %.17g %zu %.17g %.17g %.17g %.17g %.17g %.17g\n", f3, k3.pointAlign.size(), k3.pointAlign[0][0], k3.pointAlign[0][1],
+                    k3.pointAlign[0][2], k3.pointAlign[last][0], k3.pointAlign[last][1], k3.pointAlign[last][2]);
+        auto V = ki.shapeRegistration_ICP_AngleListV(1000, 0.0, P, T);
+        std::printf("ANGLV %zu %.17g %.17g %.17g %.17g %.17g %.17g\n", V.size(), V[0][0], V[0][1], V[0][2], V[7][0], V[7][1], V[7][2]);
+        std::printf("ANGL %.17g\n", ki.shapeRegistration_ICP_AngleList(1000, 0.0, P, T));
+        auto RA = ir.initRegistration_Rotation_Angle(S, std::vector<double>{0.7875, 5.5125, 3.15});
+        std::printf("ROTANG %.17g %.17g %.17g %.17g %.17g %.17g\n", RA[0][0], RA[0][1], RA[0][2], RA[11][0], RA[11][1], RA[11][2]);
+        auto RX = ir.initRegistration_Rotation_Axis(S, 2, 0.6);
+        std::printf("ROTAXIS %.17g %.17g %.17g %.17g %.17g %.17g\n", RX[0][0], RX[0][1], RX[0][2], RX[11][0], RX[11][1], RX[11][2]);
+        auto RB = ir.initRegistration_Rotation_Axis(S, 7, 0.6);   // illegal axis: the shifted cloud comes back (:131-133)
+        std::printf("ROTAXISBAD %.17g %.17g %.17g\n", RB[0][0], RB[0][1], RB[0][2]);
         PCR_QM pq;
         pq.PCR_QM_init(P, T);
         auto m = pq.PCR_QM_ReturnResult();

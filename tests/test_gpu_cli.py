@@ -63,6 +63,23 @@ def test_mirror_classes_against_oracle(O, ref_pairs):
     Td = ri["T"].astype(np.float64)
     exp0 = Td[:3, :3] @ S[0] + Td[:3, 3]        # member pointSource is the ORIGINAL source here (:224)
     assert np.allclose(icp2[2:5], exp0, atol=1e-4)     # icp2[1] is the "0" of the ALIGN0 tag
+    # members no front-end path reaches
+    Pf = P.astype(np.float32)
+    full = _vals(out, "ICPFULL")
+    assert abs(full[0] - ri["fitness"]) < 1e-8 and int(full[1]) == len(S)
+    al = O.transform_points_f32(ri["T"], Pf).astype(np.float64)      # PCL's output cloud: final Matrix4f applied in float (:169-180)
+    assert np.allclose(full[2:5], al[0], atol=1e-4) and np.allclose(full[5:8], al[-1], atol=1e-4)
+    v = _vals(out, "ANGLV")
+    assert int(v[0]) == len(S) and np.allclose(v[1:4], al[0], atol=1e-4) and np.allclose(v[4:7], al[7], atol=1e-4)
+    assert abs(_vals(out, "ANGL")[0] - ri["fitness"]) < 1e-8
+    ra = O.pose_apply(S, ps, [0.7875, 5.5125, 3.15])                # initRegistration_Rotation_Angle (:95-109)
+    got = _vals(out, "ROTANG")
+    assert np.allclose(got[0:3], ra[0], rtol=0, atol=1e-14) and np.allclose(got[3:6], ra[11], rtol=0, atol=1e-14)
+    xm = ps.c_tgt[0]                                                 # initRegistration_Rotation_Axis (:111-140): x_middle_S on ALL axes
+    rx = O.axis_rotate(2, 0.6, S - xm) + xm
+    got = _vals(out, "ROTAXIS")
+    assert np.allclose(got[0:3], rx[0], rtol=0, atol=1e-14) and np.allclose(got[3:6], rx[11], rtol=0, atol=1e-14)
+    assert np.allclose(_vals(out, "ROTAXISBAD"), S[0] - xm, rtol=0, atol=1e-15) and "error! illegal rotation" in out
     assert np.allclose(_vals(out, "QM"), O.pcr_qm(P, T), rtol=1e-10)
     reg = _vals(out, "REG")
     # KSSICP_Registration = AIVS down-sample (pNumber = min(n)/2, KSS_ICP.hpp:57-81) + kss_register: same pipeline on the oracle

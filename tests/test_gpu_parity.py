@@ -446,9 +446,10 @@ def test_register_batch_equals_one_by_one(ctx, pkg, ref_pairs):
 
 
 def test_gated_launches_give_the_same_registration(ctx, pkg):
-    """KSS_GATED=1 (opt-in): the next iteration's fused kernel is enqueued behind a stream wait-value gate while the
-    current one runs and fetches its transform from host-mapped memory.  Same registration, bit for bit, including a run
-    that converges early (the pre-enqueued kernel is cancelled) and one that needs the brute-force fallback."""
+    """Gated launches (the default on a context that owns its stream; KSS_GATED=0 switches them off): the next iteration's
+    fused kernel is enqueued while the current one runs and polls for its transform (workgroup 0 asks the host-mapped
+    record, re-publishes it in device memory).  Same registration, bit for bit, including a run that converges early (the
+    pre-enqueued kernel is cancelled) and one that needs the brute-force fallback."""
     import subprocess, sys, json
     code = r"""
 import sys, json, numpy as np
