@@ -50,6 +50,7 @@ struct kss_ctx {
     HostPool pool;   // per-pair host work of batched iterations
     std::vector<kss_ctx*> workers;   // contexts of kss_register_batch's worker threads (same device, own streams)
     std::vector<unsigned long long> last_stamps;
+    std::vector<float> h_bbox;   // bbox partials of the last single-pair target (host copy)
     double evals_sum = 0.0, evals_launches = 0.0;   // diagnostic runs: distance evaluations of the fused grid launches
     // pinned host staging
     void* h_sums = nullptr;  size_t h_sums_cap = 0;   // host-mapped: kernels write it through h_sums_dev
@@ -69,6 +70,11 @@ struct kss_ctx {
         const void* d_in = nullptr; void* d_out = nullptr;
         bool fma = false, full = false, want_full = false; double max_d2 = 0.0;
     } gated;
+    // pair_ticket, g_count and g_counts are ZERO AT REST: every kernel that uses them leaves them zeroed (tickets are re-armed
+    // by the last workgroup, the unresolved-list length is reset when the list is consumed, the cell counts are counted
+    // back down by the scatter), so a registration needs no memset of its own.  A call that fails midway sets ws_dirty
+    // and the next one clears them first; ensure_zeroed() clears a buffer it had to (re)allocate.
+    bool ws_dirty = false;
     bool defer_wait = false;   // batched fused pass: the ICP loop polls the pairs' result slots itself
     PairState* h_xf = nullptr; PairState* h_xf_dev = nullptr;
     unsigned long long seq = 0;
@@ -109,6 +115,14 @@ static inline int ensure(kss_ctx* c, DevBuf& b, size_t bytes) {
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess) { b.p = nullptr; return set_err(c, KSS_ERR_NOMEM, "hipMalloc", e); }
     b.cap = want;
+    return KSS_OK;
+}
+
+static inline int ensure_zeroed(kss_ctx* c, DevBuf& b, size_t bytes) {
+    const void* before = b.p;
+    const int rc = ensure(c, b, bytes);
+    if (rc != KSS_OK) return rc;
+    if (b.p != before && hipMemsetAsync(b.p, 0, b.cap, c->stream) != hipSuccess) return set_err(c, KSS_ERR_HIP, "hipMemsetAsync(zero-at-rest buffer)");
     return KSS_OK;
 }
 

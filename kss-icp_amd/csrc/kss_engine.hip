@@ -204,8 +204,7 @@ static int stage_plan(kss_ctx* c, const IcpPlan& pl) {
     KCHK(ensure(c, c->red_work, pl.red.size() * sizeof(RedWork)));
     KCHK(ensure(c, c->pair_red, pl.pred.size() * sizeof(PairRed)));
     KCHK(ensure(c, c->state, (size_t)pl.npairs * sizeof(PairState)));
-    KCHK(ensure(c, c->pair_ticket, (size_t)std::max(pl.npairs, PUB_PAIRS) * sizeof(int32_t)));
-    HIPCHK(c, hipMemsetAsync(c->pair_ticket.p, 0, (size_t)std::max(pl.npairs, PUB_PAIRS) * sizeof(int32_t), c->stream));
+    KCHK(ensure_zeroed(c, c->pair_ticket, (size_t)std::max(pl.npairs, PUB_PAIRS) * sizeof(int32_t)));   // zero at rest (kss_ctx.hpp)
     KCHK(ensure_pinned(c, c->h_sums, c->h_sums_cap, (size_t)pl.npairs * NSUMS * sizeof(double)));
     KCHK(ensure_pinned(c, c->h_state, c->h_state_cap, (size_t)pl.npairs * sizeof(PairState)));
     KCHK(ensure_pub(c, pl.npairs));
@@ -219,6 +218,14 @@ static int stage_plan(kss_ctx* c, const IcpPlan& pl) {
 static int pack_clouds(kss_ctx* c, const IcpPlan& pl, const void* d_src, const int64_t* src_off, const void* d_tgt,
                 const int64_t* tgt_off, int dtype) {
     const size_t esz = dtype == KSS_F64 ? sizeof(double) : sizeof(float);
+    if (pl.grid) {   // single pair on the cell list: both clouds and the target's bbox partials in one launch
+        const PairGeom& g = pl.g[0];
+        KCHK(ensure(c, c->g_bbox, (size_t)pack_pair_bbox_rows(g.tgt_pad) * 6 * sizeof(float)));
+        launch_pack_pair(c->stream, dtype, (const char*)d_tgt + (size_t)tgt_off[0] * 3 * esz, g.nt, (float4*)c->tgt4.p + g.tgt_base, g.tgt_pad,
+                         (float*)c->g_bbox.p, (const char*)d_src + (size_t)src_off[0] * 3 * esz, g.ns, (float4*)c->src0.p + g.src_base);
+        HIPCHK(c, hipGetLastError());
+        return KSS_OK;
+    }
     // sources are contiguous in both layouts
     {
         const char* base = (const char*)d_src + (size_t)src_off[0] * 3 * esz;
@@ -272,12 +279,11 @@ static int grid_setup(kss_ctx* c, IcpPlan& pl) {
     if (!pl.grid) return KSS_OK;
     const PairGeom& g = pl.g[0];
     const int nt = (int)g.nt, ns = (int)g.ns;
-    const int nbb = 64;
-    KCHK(ensure(c, c->g_bbox, (size_t)nbb * 6 * sizeof(float)));
+    const int nbb = pack_pair_bbox_rows(g.tgt_pad);   // one partial per 256 target slots, left by pack_clouds
     const float4* tgt = (const float4*)c->tgt4.p + g.tgt_base;
     ProfScope ps(c, KSS_K_GRID_BUILD);
-    launch_grid_bbox(c->stream, tgt, nt, (float*)c->g_bbox.p, nbb);
-    std::vector<float> hb((size_t)nbb * 6);
+    std::vector<float>& hb = c->h_bbox;
+    hb.resize((size_t)nbb * 6);
     HIPCHK(c, hipMemcpyAsync(hb.data(), c->g_bbox.p, hb.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -289,30 +295,22 @@ static int grid_setup(kss_ctx* c, IcpPlan& pl) {
     choose_cells(mn, mx, nt, gp);
     pl.gp = gp;
     const size_t ncells = (size_t)gp.gx * gp.gy * gp.gz;
-    KCHK(ensure(c, c->g_counts, ncells * sizeof(int32_t)));
+    KCHK(ensure_zeroed(c, c->g_counts, ncells * sizeof(int32_t)));   // zero at rest (kss_ctx.hpp)
     KCHK(ensure(c, c->g_start, (ncells + 8) * sizeof(int32_t)));   // [0] pad, starts at [1 .. ncells + 1], pads behind (block_walk reads 16 bytes per row)
     KCHK(ensure(c, c->g_bsums, ((ncells + 4095) / 4096 + 1) * sizeof(int32_t)));
     KCHK(ensure(c, c->g_sorted, (size_t)nt * sizeof(float4)));
     KCHK(ensure(c, c->g_list, (size_t)ns * sizeof(int32_t)));
-    KCHK(ensure(c, c->g_pos, (size_t)ns * sizeof(int32_t)));   // previous winner of every source: -1 = none yet
-    HIPCHK(c, hipMemsetAsync(c->g_pos.p, 0xff, (size_t)ns * sizeof(int32_t), c->stream));
-    KCHK(ensure(c, c->g_count, 64));   // [0] unresolved-list length
-    HIPCHK(c, hipMemsetAsync(c->g_count.p, 0, 64, c->stream));
+    KCHK(ensure(c, c->g_pos, (size_t)ns * sizeof(int32_t)));   // previous winner of every source (set to -1 = none by the source sort below)
+    KCHK(ensure_zeroed(c, c->g_count, 64));   // [0] unresolved-list length: zero at rest
     pl.gpairs[0].gp = gp;
     pl.gpairs[0].cell_base = 0;
-    {   // device-side state of the pair (active, identity): read by the fallback kernels only; pinned source, no sync
-        PairState* one = (PairState*)c->h_state;
-        std::memset(one, 0, sizeof *one);
-        one->active = 1;
-        HIPCHK(c, hipMemcpyAsync(c->state.p, one, sizeof *one, hipMemcpyHostToDevice, c->stream));
-    }
     launch_grid_build(c->stream, tgt, nt, gp, (int32_t*)c->g_counts.p, (int32_t*)c->g_start.p + 1,
-                      (int32_t*)c->g_bsums.p, (float4*)c->g_sorted.p, false);
+                      (int32_t*)c->g_bsums.p, (float4*)c->g_sorted.p, true);
     // sources into the same cell order (original index in .w): cur[0] is the scratch of the scatter
     KCHK(ensure(c, c->g_start2, (ncells + 1) * sizeof(int32_t)));
     launch_grid_sort_sources(c->stream, (const float4*)c->src0.p + g.src_base, ns, gp, (int32_t*)c->g_counts.p,
                              (int32_t*)c->g_start2.p, (int32_t*)c->g_bsums.p,
-                             (float4*)c->cur[0].p, (float4*)c->src0.p + g.src_base);   // (scatter: src0 -> cur[0]; rank fix: cur[0] -> src0)
+                             (float4*)c->cur[0].p, (float4*)c->src0.p + g.src_base, (int32_t*)c->g_pos.p);   // (scatter: src0 -> cur[0]; rank fix: cur[0] -> src0)
     HIPCHK(c, hipGetLastError());
     c->grid_stats[0] = gp.h; c->grid_stats[1] = gp.gx; c->grid_stats[2] = gp.gy; c->grid_stats[3] = gp.gz;
     if (c->stats_ns != ns || c->stats_nt != nt) { c->grid_stats[4] = 0; c->grid_stats[5] = 0; }
@@ -638,6 +636,12 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
             gated_cancel(c);              // the list pass must not queue up behind a closed gate
             c->gated.want_next = false;   // (clouds this far apart: plain launches until the loop says otherwise)
             KCHK(stage_tables(c, pl));
+            {   // the list sweep reads the pair's device-side state (active, identity): uploaded here, on the rare path only
+                PairState one;
+                std::memset(&one, 0, sizeof one);
+                one.active = 1;
+                HIPCHK(c, hipMemcpy(c->state.p, &one, sizeof one, hipMemcpyHostToDevice));
+            }
             {
                 ProfScope ps(c, KSS_K_NN_SWEEP);
                 launch_nn_sweep_list(c->stream, pl.S, fma, (const NNWork*)c->nn_work.p, (int)pl.nn.size(), (const PairState*)c->state.p,
@@ -889,6 +893,21 @@ static int icp_loop(kss_ctx* c, const IcpPlan& pl_in, const kss_icp_params& P, k
     return KSS_OK;
 }
 
+// zero-at-rest buffers (kss_ctx.hpp): cleared here when the previous call on this context did not finish
+static int restore_zero_at_rest(kss_ctx* c) {
+    if (!c->ws_dirty) return KSS_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (DevBuf* b : {&c->pair_ticket, &c->g_count, &c->g_counts})
+        if (b->p) HIPCHK(c, hipMemsetAsync(b->p, 0, b->cap, c->stream));
+    c->ws_dirty = false;
+    return KSS_OK;
+}
+struct DirtyGuard {   // a call that returns early leaves the zero-at-rest buffers in an unknown state
+    kss_ctx* c; bool ok = false;
+    explicit DirtyGuard(kss_ctx* c_) : c(c_) {}
+    ~DirtyGuard() { if (!ok) c->ws_dirty = true; }
+};
+
 int icp_run_dev(kss_ctx* c, const void* d_src, const int64_t* src_off, const void* d_tgt, const int64_t* tgt_off,
                 int npairs, bool shared_target, int dtype, const kss_icp_params* p, kss_icp_result* results) {
     if (!c || !d_src || !d_tgt || !src_off || !tgt_off || !p || !results || npairs <= 0) return set_err(c, KSS_ERR_ARG, "icp: bad argument");
@@ -901,16 +920,19 @@ int icp_run_dev(kss_ctx* c, const void* d_src, const int64_t* src_off, const voi
     }
     IcpPlan pl;
     const auto t0 = std::chrono::steady_clock::now();
+    KCHK(restore_zero_at_rest(c));
+    DirtyGuard guard(c);
+    c->timing = getenv("KSS_TIMING") != nullptr;
     KCHK(build_plan(c, ns.data(), nt.data(), npairs, shared_target, p->nn_sources_per_thread, p->nn_target_splits, p->nn_mode, pl));
     KCHK(stage_plan(c, pl));
     KCHK(pack_clouds(c, pl, d_src, src_off, d_tgt, tgt_off, dtype));
     KCHK(grid_setup(c, pl));
     KCHK(grid_setup_batch(c, pl));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->timing) HIPCHK(c, hipStreamSynchronize(c->stream));   // (only to split setup from loop in the KSS_TIMING report)
     const auto t1 = std::chrono::steady_clock::now();
-    c->timing = getenv("KSS_TIMING") != nullptr;
     c->t_launch_us = c->t_wait_us = 0;
     const int rc = icp_loop(c, pl, *p, results);
+    guard.ok = rc == KSS_OK;
     const auto t2 = std::chrono::steady_clock::now();
     c->last_setup_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
     c->last_loop_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
@@ -928,6 +950,8 @@ int nn_generic_dev(kss_ctx* c, const void* d_src, int64_t ns, const void* d_tgt,
     if (ns <= 0 || nt <= 0) return set_err(c, KSS_ERR_ARG, "nn: empty cloud");
     HIPCHK(c, hipSetDevice(c->device));
     IcpPlan pl;
+    KCHK(restore_zero_at_rest(c));
+    DirtyGuard guard(c);
     KCHK(build_plan(c, &ns, &nt, 1, false, 0, 0, KSS_NN_AUTO, pl));
     KCHK(stage_plan(c, pl));
     const int64_t so[2] = {0, ns}, to[2] = {0, nt};
@@ -938,6 +962,7 @@ int nn_generic_dev(kss_ctx* c, const void* d_src, int64_t ns, const void* d_tgt,
     set_state(((PairState*)c->h_state)[0], I, 1, 0);
     KCHK(nn_pass(c, pl, false, (const float4*)c->src0.p, (float4*)c->cur[0].p, 1e300, d_idx, d_d2, true));
     if (sums_out) std::memcpy(sums_out, c->h_sums, NSUMS * sizeof(double));
+    guard.ok = true;
     return KSS_OK;
 }
 

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(const float4* __restr
     sorted[pos] = p;
 }
 
-// counts_are_zero: the previous build over the same cells left them so (its scatter counts every cell back down)
+// counts_are_zero: the caller vouches for it (every complete build leaves them so: the scatter counts each cell back down)
 void launch_grid_build(hipStream_t st, const float4* d_tgt, int n, const GridParams& gp, int32_t* d_counts,
                        int32_t* d_start, int32_t* d_block_sums, float4* d_sorted, bool counts_are_zero) {
     const int ncells = gp.gx * gp.gy * gp.gz;
@@ -345,9 +345,11 @@ __device__ __forceinline__ int block_walk(const GridParams& gp, const int32_t* _
 // neighbours neighbours, so ONE sort per registration keeps the queries of a wave / workgroup / XCD in the
 // same few cells (L1 / L2 hits instead of Infinity-Cache trips) for all iterations.
 __global__ __launch_bounds__(256) void grid_rank_fix_kernel(const float4* __restrict__ tmp, int n, GridParams gp,
-                                                            const int32_t* __restrict__ start, float4* __restrict__ out) {
+                                                            const int32_t* __restrict__ start, float4* __restrict__ out,
+                                                            int32_t* __restrict__ pos_init) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
+    if (pos_init) pos_init[j] = -1;   // no previous winner yet (saves a memset per registration)
     const float4 p = tmp[j];
     const int cx = cell_coord(p.x, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(p.y, gp.oy, gp.inv_h, gp.gy),
               cz = cell_coord(p.z, gp.oz, gp.inv_h, gp.gz);
@@ -360,9 +362,9 @@ __global__ __launch_bounds__(256) void grid_rank_fix_kernel(const float4* __rest
 }
 
 void launch_grid_sort_sources(hipStream_t st, const float4* d_src, int n, const GridParams& gp, int32_t* d_counts,
-                              int32_t* d_start, int32_t* d_block_sums, float4* d_tmp, float4* d_out) {
+                              int32_t* d_start, int32_t* d_block_sums, float4* d_tmp, float4* d_out, int32_t* d_pos_init) {
     launch_grid_build(st, d_src, n, gp, d_counts, d_start, d_block_sums, d_tmp, true);   // (right after the target build over the same cells)
-    hipLaunchKernelGGL(grid_rank_fix_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_tmp, n, gp, d_start, d_out);
+    hipLaunchKernelGGL(grid_rank_fix_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_tmp, n, gp, d_start, d_out, d_pos_init);
 }
 
 // =============================================================================================

@@ -153,6 +153,10 @@ inline bool oct_adopt(OctBox& b, const float* p) {
 void launch_pack_f3_to_f4(hipStream_t st, const float* d_in, int64_t n, float4* d_out, int64_t n_pad, bool sentinel);
 void launch_pack_f64_to_f4(hipStream_t st, const double* d_in, int64_t n, float4* d_out, int64_t n_pad, bool sentinel);
 void launch_empty(hipStream_t st);
+// single pair: target (sentinel padded, + one bbox partial row of 6 floats per 256 slots) and source in ONE launch
+int pack_pair_bbox_rows(int64_t nt_pad);
+void launch_pack_pair(hipStream_t st, int dtype, const void* d_tgt, int64_t nt, float4* d_tgt_out, int64_t nt_pad, float* d_bbox_partial,
+                      const void* d_src, int64_t ns, float4* d_src_out);
 void launch_pack_batch(hipStream_t st, const void* d_in, int dtype, const PackSeg* d_seg, int nseg, int64_t total_out, float4* d_out);
 
 void launch_nn_sweep(hipStream_t st, int S, bool fma, const NNWork* d_work, int n_work,
@@ -179,7 +183,7 @@ void launch_gridb_build_lds(hipStream_t st, const float4* d_tgt4, float4* d_src,
 void launch_grid_stats(hipStream_t st, const float4* d_src, int ns, const GridParams& gp, const int32_t* d_cell_start,
                        unsigned long long* d_out /* [0] evaluations of the 3x3x3 block, [1] occupied cells */);
 void launch_grid_sort_sources(hipStream_t st, const float4* d_src, int n, const GridParams& gp, int32_t* d_counts,
-                              int32_t* d_start, int32_t* d_block_sums, float4* d_tmp, float4* d_out);
+                              int32_t* d_start, int32_t* d_block_sums, float4* d_tmp, float4* d_out, int32_t* d_pos_init);
 
 void launch_corr_reduce(hipStream_t st, const RedWork* d_work, int n_work, const PairState* d_state,
                         const float4* d_src, const float4* d_tgt4, const unsigned long long* d_keys,

@@ -52,6 +52,60 @@ void launch_pack_f64_to_f4(hipStream_t st, const double* d_in, int64_t n, float4
     hipLaunchKernelGGL(pack_to_f4_kernel<double>, dim3(blocks), dim3(256), 0, st, d_in, n, d_out, n_pad, sentinel ? 1 : 0);
 }
 
+// One launch for a single pair: blocks [0, nb_t) pack the target (sentinel padded) and leave one bbox partial
+// {min xyz, max xyz} of the real points per block; blocks [nb_t, nb_t + nb_s) pack the source.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_pair_kernel(const T* __restrict__ tgt, int64_t nt, float4* __restrict__ tgt_out, int64_t nt_pad,
+                                                        int nb_t, float* __restrict__ bbox_partial, const T* __restrict__ src, int64_t ns,
+                                                        float4* __restrict__ src_out) {
+    if ((int)blockIdx.x >= nb_t) {
+        const int64_t i = (int64_t)(blockIdx.x - nb_t) * 256 + threadIdx.x;
+        if (i < ns) src_out[i] = make_float4((float)src[3 * i], (float)src[3 * i + 1], (float)src[3 * i + 2], 0.f);
+        return;
+    }
+    __shared__ float sh[4][6];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const float inf = __builtin_inff();
+    float mn[3] = {inf, inf, inf}, mx[3] = {-inf, -inf, -inf};
+    if (i < nt_pad) {
+        float4 v = make_float4(inf, inf, inf, 0.f);   // sentinel padding: can never win an arg-min
+        if (i < nt) {
+            v = make_float4((float)tgt[3 * i], (float)tgt[3 * i + 1], (float)tgt[3 * i + 2], 0.f);
+            mn[0] = mx[0] = v.x; mn[1] = mx[1] = v.y; mn[2] = mx[2] = v.z;
+        }
+        tgt_out[i] = v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = fminf(mn[k], __shfl_down(mn[k], off, 64));
+            mx[k] = fmaxf(mx[k], __shfl_down(mx[k], off, 64));
+        }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+        for (int k = 0; k < 3; ++k) { sh[wave][k] = mn[k]; sh[wave][3 + k] = mx[k]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = sh[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fminf(v, sh[w][threadIdx.x]) : fmaxf(v, sh[w][threadIdx.x]);
+        bbox_partial[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+int pack_pair_bbox_rows(int64_t nt_pad) { return (int)((nt_pad + 255) / 256); }
+
+void launch_pack_pair(hipStream_t st, int dtype, const void* d_tgt, int64_t nt, float4* d_tgt_out, int64_t nt_pad, float* d_bbox_partial,
+                      const void* d_src, int64_t ns, float4* d_src_out) {
+    const int nb_t = pack_pair_bbox_rows(nt_pad), nb_s = (int)((ns + 255) / 256);
+    if (dtype == KSS_F64)
+        hipLaunchKernelGGL(pack_pair_kernel<double>, dim3(nb_t + nb_s), dim3(256), 0, st, (const double*)d_tgt, nt, d_tgt_out, nt_pad, nb_t,
+                           d_bbox_partial, (const double*)d_src, ns, d_src_out);
+    else
+        hipLaunchKernelGGL(pack_pair_kernel<float>, dim3(nb_t + nb_s), dim3(256), 0, st, (const float*)d_tgt, nt, d_tgt_out, nt_pad, nb_t,
+                           d_bbox_partial, (const float*)d_src, ns, d_src_out);
+}
+
 // empty launch: calibrates what a HIP event pair adds around a short kernel (kss_profile_event_overhead)
 __global__ void empty_kernel() {}
 void launch_empty(hipStream_t st) { hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, st); }
