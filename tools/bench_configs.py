@@ -54,14 +54,18 @@ def c4(pkg, ctx, torch, n=1000000, iters=10):
     src, tgt = S.config_c4(n)
     d_src = torch.from_numpy(src).cuda(); d_tgt = torch.from_numpy(tgt).cuda()
     out = {"config": "C4: one %dx%d pair, scale 2 + 60 deg: pre-shape stats, one NN sweep, %d ICP iterations" % (n, n, iters)}
+    for _ in range(3):
+        (cS, rS), (cT, rT) = ctx.preshape_stats_pair_dev(d_src.data_ptr(), n, d_tgt.data_ptr(), n, 0)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    cS, rS = ctx.preshape_stats_dev(d_src.data_ptr(), 0, n); cT, rT = ctx.preshape_stats_dev(d_tgt.data_ptr(), 0, n)
-    torch.cuda.synchronize(); out["preshape_stats_ms"] = (time.perf_counter() - t0) * 1e3
+    for _ in range(10):
+        (cS, rS), (cT, rT) = ctx.preshape_stats_pair_dev(d_src.data_ptr(), n, d_tgt.data_ptr(), n, 0)
+    torch.cuda.synchronize(); out["preshape_stats_ms"] = (time.perf_counter() - t0) * 1e2
     out["scale_estimate"] = rT / rS
-    # bring the source into the target's pre-shape on the host (plumbing for this script only), then ICP on device
-    s64 = src.astype(np.float64)
-    pre = (cT + ((s64 + (cT - cS)) - cT) * (rT / rS)).astype(np.float32)
-    d_pre = torch.from_numpy(pre).cuda()
+    # S' on the device in f64 (the reference's cloud type), narrowed to f32 for the NN engine
+    d_s64 = d_src.to(torch.float64); d_sp = torch.empty_like(d_s64)
+    pose = ctx.make_pose([cT[k] - cS[k] for k in range(3)], cT, rT / rS, [0.0, 0.0, 0.0])
+    ctx.pose_apply_dev(d_s64.data_ptr(), n, pose, d_sp.data_ptr()); ctx.synchronize()
+    d_pre = d_sp.to(torch.float32).contiguous()
     d_idx = torch.empty(n, dtype=torch.int32, device="cuda"); d_d2 = torch.empty(n, dtype=torch.float32, device="cuda")
     for mode, m in (("grid", pkg.NN_GRID), ("brute", pkg.NN_BRUTE)):
         ctx.set_nn_mode(m)
