@@ -58,8 +58,11 @@ def parse_args(argv=None):
                     help="N > 1: ONE registration, its source rows split over the ranks (target replicated), one RCCL "
                          "all-reduce of the 20 sums per iteration (SURVEY 8e alternative; strong scaling).  Default: one "
                          "independent pair per rank (weak scaling, no data-path collective)")
-    ap.add_argument("--prof-stride", type=int, default=8,
-                    help="HIP-event timing of every n-th kernel launch inside the timed region (1 = every launch)")
+    ap.add_argument("--prof-stride", type=int, default=53,
+                    help="HIP-event timing of every n-th kernel launch inside the timed region (1 = every launch).  A bracketed "
+                         "launch cannot be pre-enqueued behind the running one and costs the iteration ~20 us instead of ~14 "
+                         "(rocprof trace, DESIGN.md section 4), so the default samples about one launch per registration: 53 is "
+                         "coprime with the 51 launches of a step, the samples walk through all iteration positions")
     ap.add_argument("--dry-run-dist", action="store_true",
                     help="CPU rehearsal of the N-rank protocol (launcher, gloo process group, barriers, max-over-ranks timing, "
                          "record gather, one JSON line): the step is a stand-in, nothing is measured")
@@ -274,6 +277,7 @@ def secondary_legs(pkg, ctx, torch, np):
     sync(); nn_dt = time.perf_counter() - t0
     p = ctx.icp_params(max_iterations=10, fixed_iterations=1)
     ctx.icp_dev(d_pre.data_ptr(), n, d_tgt.data_ptr(), n, p)
+    ctx.profile_enable(5)        # (a bracketed launch is a plain one: sample a few of the 11, keep the others gated)
     ctx.profile_reset()
     sync(); t0 = time.perf_counter()
     r = ctx.icp_dev(d_pre.data_ptr(), n, d_tgt.data_ptr(), n, p)
