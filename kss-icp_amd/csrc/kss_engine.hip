@@ -198,7 +198,7 @@ static int stage_plan(kss_ctx* c, const IcpPlan& pl) {
     KCHK(ensure(c, c->cur[0], (size_t)pl.total_src * sizeof(float4)));
     KCHK(ensure(c, c->cur[1], (size_t)pl.total_src * sizeof(float4)));
     KCHK(ensure(c, c->keys, (size_t)pl.total_keys * sizeof(unsigned long long)));
-    KCHK(ensure(c, c->partials, std::max<size_t>(pl.red.size(), (size_t)pl.total_rows) * NSUMS * sizeof(double)));
+    KCHK(ensure(c, c->partials, std::max<size_t>(pl.red.size(), 2 * (size_t)pl.total_rows) * NSUMS * sizeof(double)));   // (x2: rows as 16-byte granules)
     KCHK(ensure(c, c->sums, (size_t)pl.npairs * NSUMS * sizeof(double)));
     KCHK(ensure(c, c->nn_work, pl.nn.size() * sizeof(NNWork)));
     KCHK(ensure(c, c->red_work, pl.red.size() * sizeof(RedWork)));
@@ -558,6 +558,10 @@ static PassArgs pass_args(kss_ctx* c, const IcpPlan& pl, const float4* d_in, flo
         a.row_pair = (const int32_t*)c->g_rowpair.p;
     } else {
         a.pair0 = pl.gpairs[0];
+        // rows as tagged granules + a designated reducer instead of drain + ticket: only when every workgroup is resident at
+        // once (one per CU), so the reducer never polls for a workgroup that cannot start.  KSS_TAGGED_ROWS=0: A/B switch.
+        static const bool tagged = getenv("KSS_TAGGED_ROWS") == nullptr || atoi(getenv("KSS_TAGGED_ROWS")) != 0;
+        a.tagged_rows = tagged && pl.total_rows <= 256 ? 1 : 0;
     }
     return a;
 }

@@ -571,6 +571,7 @@ __global__ __launch_bounds__(PASS_BS) void grid_pass_kernel(const PassArgs a) {
                 a.pos_prev[i] = -1;
                 const int slot = atomicAdd(a.list_count, 1);
                 a.list[slot] = i;
+                fell_back = true;   // counted in column 19 of the row, as the batch counts its in-wave fallbacks
             }
         } else {
             // sums only: the winner is where the search left it, or what the list pass found
@@ -635,7 +636,66 @@ __global__ __launch_bounds__(PASS_BS) void grid_pass_kernel(const PassArgs a) {
     KSS_STAMP(2);
 
     double v = 0.0 + r;                    // a single-chunk pair: exactly what the general path below computes
-    if (pr.n_rows > 1) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    if (pr.n_rows > 1 && a.tagged_rows) {
+        // Single pair whose workgroups are all resident at once (<= 256 of them): rows travel as self-validating 16-byte
+        // granules {bits(sum), launch sequence number} -- one sc1 store per sum, no drain, no ticket -- and the pair's FIRST
+        // workgroup, once its own row is out, polls every row until all carry this launch's number, then adds them in the
+        // canonical order.  Saves the store-acknowledge wait and the ticket round trip of the general protocol below
+        // (~2 us of a 11 us launch); every other workgroup is done the moment its row is stored.  The poll is bounded.
+        if (threadIdx.x < NSUMS) {
+            const unsigned long long rb = (unsigned long long)__double_as_longlong(r);
+            u32x4 o;
+            o.x = (unsigned)rb; o.y = (unsigned)(rb >> 32); o.z = (unsigned)a.seq; o.w = (unsigned)(a.seq >> 32);
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.rows) + 2 * ((int64_t)w * NSUMS + threadIdx.x);
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(o) : "memory");
+        }
+        if (w != pr.row_base) return;      // uniform
+        KSS_STAMP(3);
+        if (threadIdx.x == 0) s_last = 1;
+        __syncthreads();
+        {
+            const int g = threadIdx.x / NSUMS, c = threadIdx.x % NSUMS;
+            const unsigned long long* __restrict__ rows2 = reinterpret_cast<const unsigned long long*>(a.rows) + 2 * (int64_t)pr.row_base * NSUMS;
+            if (g < PASS_FG) {
+                double acc = 0.0;
+                for (int k = g; k < pr.n_rows; k += 8 * PASS_FG) {
+                    const unsigned long long* p[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) p[j] = rows2 + 2 * ((int64_t)(k + j * PASS_FG < pr.n_rows ? k + j * PASS_FG : k) * NSUMS + c);
+                    u32x4 t0, t1, t2, t3, t4, t5, t6, t7;
+                    int spins = 0;
+                    for (;;) {
+                        asm volatile(
+                            "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\t"
+                            "global_load_dwordx4 %2, %10, off sc1\n\tglobal_load_dwordx4 %3, %11, off sc1\n\t"
+                            "global_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
+                            "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\t"
+                            "s_waitcnt vmcnt(0)"
+                            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+                            : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+                            : "memory");
+                        const unsigned lo = (unsigned)a.seq, hi = (unsigned)(a.seq >> 32);
+                        const bool ok = t0.z == lo && t0.w == hi && t1.z == lo && t1.w == hi && t2.z == lo && t2.w == hi && t3.z == lo && t3.w == hi &&
+                                        t4.z == lo && t4.w == hi && t5.z == lo && t5.w == hi && t6.z == lo && t6.w == hi && t7.z == lo && t7.w == hi;
+                        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;      // wave-uniform: the loads stay convergent
+                        if (++spins > (1 << 20)) { s_last = 0; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    const u32x4 tt[8] = {t0, t1, t2, t3, t4, t5, t6, t7};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (k + j * PASS_FG < pr.n_rows) acc += __longlong_as_double((long long)(((unsigned long long)tt[j].y << 32) | tt[j].x));
+                }
+                shf[g][c] = acc;
+            }
+        }
+        __syncthreads();
+        if (!s_last) return;               // a row never arrived: leave without publishing, the host's wait reports it
+        v = 0.0;
+        if (threadIdx.x < NSUMS)
+            for (int gg = 0; gg < PASS_FG; ++gg) v += shf[gg][threadIdx.x];
+    } else if (pr.n_rows > 1) {
         if (threadIdx.x < NSUMS) {
             __hip_atomic_store(&a.rows[(int64_t)w * NSUMS + threadIdx.x], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -671,12 +731,9 @@ __global__ __launch_bounds__(PASS_BS) void grid_pass_kernel(const PassArgs a) {
     }
     if (threadIdx.x < NSUMS) {
         if (!FULL && (threadIdx.x == 17 || threadIdx.x == 18)) v = 0.0;
-        if (!BATCH && threadIdx.x == NSUMS - 1)   // single pair: slot 19 = sources left to the list pass
-            v = SEARCH ? (double)__hip_atomic_load(a.list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
         // {bits(sum), seq} as ONE aligned 16-byte system-scope store per sum into host-mapped memory: the host accepts a
         // slot when its sequence number matches, so no flag has to be ordered after the data (that ordering would cost a
         // write-acknowledge round trip over PCIe) and no L2 write-back fence is needed
-        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
         const unsigned long long vb = (unsigned long long)__double_as_longlong(v);
         u32x4 o;
         o.x = (unsigned)vb; o.y = (unsigned)(vb >> 32); o.z = (unsigned)a.seq; o.w = (unsigned)(a.seq >> 32);

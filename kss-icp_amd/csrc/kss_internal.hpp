@@ -96,7 +96,7 @@ struct PassArgs {
     const PairState* state;                     // BATCH: per-pair transforms; single pair: host-mapped transform of a gated launch or null
     GridPairDev pair0; PairState ps0;           // single pair: by value (no upload per iteration)
     int32_t total_rows, use_prev;
-    int32_t gate_seq, pad_;                     // gated single-pair launch: the stamp `state->pad[1]` must carry
+    int32_t gate_seq, tagged_rows;              // gated single-pair launch: the stamp `state->pad[1]` must carry; rows as tagged granules
     unsigned int* gate_dev;                     // ... and the device-side copy of the record (five 16-byte granules)
     double max_d2;
     double* rows; int32_t* tickets;
