@@ -217,11 +217,6 @@ void launch_grid_build(hipStream_t st, const float4* d_tgt, int n, const GridPar
 // unsigned order == smaller distance first, then lower index; d2 >= +0 so its bit pattern is monotone).
 // (2-16 cooperating lanes per query were measured as well: once sources are cell-sorted and the block's ranges
 // are fetched up front, one lane wins at every size tried.)
-#ifndef KSS_GRID_WALK
-#define KSS_GRID_WALK 8
-#endif
-constexpr int GRID_WALK = KSS_GRID_WALK;   // points in flight per step of the walk (4 / 8 / 16 measured equal)
-
 template <bool FMA>
 __device__ __forceinline__ unsigned long long point_key(const float4 p, float qx, float qy, float qz) {
     const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
@@ -232,20 +227,21 @@ __device__ __forceinline__ unsigned long long point_key(const float4 p, float qx
 }
 
 // Scan the cell-ordered points [lo, hi): four independent loads in flight per step (indices clamped to the
-// last point: a duplicate cannot change a minimum), tracking where the best point sits in `sorted` and its
-// coordinates (three selects per evaluation are cheaper than re-loading the winner afterwards).
+// last point: a duplicate cannot change a minimum), tracking the best key and where that point sits in `sorted`.
+// The winner's coordinates are re-read once at the end of the search (one L1-hot load) instead of being carried through
+// four selects per evaluation: the batched pass is VALU-bound (93 % VALU-busy at C3) and each select is an instruction.
 template <bool FMA>
 __device__ __forceinline__ void scan_range(const float4* __restrict__ sorted, int lo, int hi, float qx, float qy, float qz,
-                                           unsigned long long& key, int& kpos, float4& win) {
+                                           unsigned long long& key, int& kpos) {
     for (int k = lo; k < hi; k += 4) {
         const int k1 = min(k + 1, hi - 1), k2 = min(k + 2, hi - 1), k3 = min(k + 3, hi - 1);
         const float4 p0 = sorted[k], p1 = sorted[k1], p2 = sorted[k2], p3 = sorted[k3];
         const unsigned long long e0 = point_key<FMA>(p0, qx, qy, qz), e1 = point_key<FMA>(p1, qx, qy, qz),
                                  e2 = point_key<FMA>(p2, qx, qy, qz), e3 = point_key<FMA>(p3, qx, qy, qz);
-        if (e0 < key) { key = e0; kpos = k; win = p0; }
-        if (e1 < key) { key = e1; kpos = k1; win = p1; }
-        if (e2 < key) { key = e2; kpos = k2; win = p2; }
-        if (e3 < key) { key = e3; kpos = k3; win = p3; }
+        if (e0 < key) { key = e0; kpos = k; }
+        if (e1 < key) { key = e1; kpos = k1; }
+        if (e2 < key) { key = e2; kpos = k2; }
+        if (e3 < key) { key = e3; kpos = k3; }
     }
 }
 
@@ -261,15 +257,14 @@ __device__ __forceinline__ void scan_range(const float4* __restrict__ sorted, in
 // cell edge and ~4 of the 27 cells remain.  Results do not depend on `pp` (any target is a valid bound).
 //
 // The surviving ranges go into a per-lane queue in LDS (column threadIdx.x: private to the lane, so no barrier)
-// and are walked as ONE flattened list, GRID_WALK points in flight per step: the loads issued are the loads
-// needed (the vector memory pipe bounds this kernel: 36 unconditional float4 gathers per lane used to cost more
-// than the whole remaining search).  Returns the number of distance evaluations.
+// and are walked two ranges at a time, four points of each in flight per step (the vector memory pipe paces the
+// single-pair kernel, the VALU the batched one).  Returns the number of distance evaluations.
 typedef int32_t int4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at 4-byte alignment (one global_load_dwordx4)
 
 template <bool FMA, int BS>
 __device__ __forceinline__ int block_walk(const GridParams& gp, const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
                                           float qx, float qy, float qz, int cx, int cy, int cz, int pp, const float4 prevp,
-                                          int2 (*rowq)[BS], unsigned long long& key, int& kpos, float4& win) {
+                                          int2 (*rowq)[BS], unsigned long long& key, int& kpos) {
     // the four bounds of a row -- starts of cells cx-1, cx, cx+1, cx+2 -- are ONE unaligned 16-byte load (cell_start has a
     // readable element in front of cell 0 and two behind the last start): 9 loads per query instead of 36
     int s0[9], s1[9], s2[9], s3[9];
@@ -287,8 +282,7 @@ __device__ __forceinline__ int block_walk(const GridParams& gp, const int32_t* _
     }
     float d0 = __builtin_inff();
     if (pp >= 0) {
-        win = prevp;   // == sorted[pp], loaded by the caller ahead of time
-        key = point_key<FMA>(win, qx, qy, qz);
+        key = point_key<FMA>(prevp, qx, qy, qz);   // prevp == sorted[pp], loaded by the caller ahead of time
         kpos = pp;
         d0 = __uint_as_float((unsigned)(key >> 32));
     }
@@ -307,17 +301,18 @@ __device__ __forceinline__ int block_walk(const GridParams& gp, const int32_t* _
         const bool left = !(d0 < (g2 + exl2) * 0.999999f), right = !(d0 < (g2 + exr2) * 0.999999f);
         const int lo = left ? s0[t] : s1[t];
         const int hi = right ? s3[t] : s2[t];
-        if (need && hi > lo) {
-            rowq[nrow][threadIdx.x] = make_int2(lo, hi);
-            ++nrow;
-            total += hi - lo;
-        }
+        const bool take = need && hi > lo;
+        rowq[min(nrow, 8)][threadIdx.x] = make_int2(lo, hi);   // written unconditionally, kept only when taken: no branch per row
+        nrow += take ? 1 : 0;
+        total += take ? hi - lo : 0;
     }
+    // The queued ranges are walked as ONE flattened list, 8 points in flight per step.  (Measured and rejected: predicating
+    // the loads of a lane past the end of its list instead of letting it repeat its last point, +25 % search time; walking
+    // two ranges per step with four points each and no per-point queue bookkeeping, fewer instructions but more dependent
+    // steps: C3 9.5 -> 12.4 ms, C2 search 5.1 -> 5.8 us.)
     int cur = 0, end = 0, nxt = 0;
     if (nrow > 0) { const int2 v = rowq[0][threadIdx.x]; cur = v.x; end = v.y; nxt = 1; }
-    // U points in flight per step.  (Measured: predicating the loads of a lane past the end of its list -- instead of letting
-    // it repeat its last point -- turns the step into a chain of exec-masked blocks and costs 25 % of the search phase.)
-    constexpr int U = GRID_WALK;
+    constexpr int U = 8;
     for (int e = 0; e < total; e += U) {
         int at[U];
 #pragma unroll
@@ -332,7 +327,7 @@ __device__ __forceinline__ int block_walk(const GridParams& gp, const int32_t* _
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const unsigned long long kk = point_key<FMA>(pt[j], qx, qy, qz);
-            if (kk < key) { key = kk; kpos = at[j]; win = pt[j]; }
+            if (kk < key) { key = kk; kpos = at[j]; }
         }
     }
     return total + (pp >= 0 ? 1 : 0);
@@ -511,7 +506,7 @@ __global__ __launch_bounds__(PASS_BS) void grid_pass_kernel(const PassArgs a) {
                 const int cx = cell_coord(qx, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(qy, gp.oy, gp.inv_h, gp.gy),
                           cz = cell_coord(qz, gp.oz, gp.inv_h, gp.gz);
                 // ---- r = 1: the 3x3x3 block, pruned by the previous winner's distance ----
-                ev_lane = block_walk<FMA, BS>(gp, cs, sorted, qx, qy, qz, cx, cy, cz, a.use_prev ? pp : -1, prevp, rowq, key, kpos, win);
+                ev_lane = block_walk<FMA, BS>(gp, cs, sorted, qx, qy, qz, cx, cy, cz, a.use_prev ? pp : -1, prevp, rowq, key, kpos);
                 for (int r = 1; r <= gp.rcap; ++r) {
                     if (r > 1) {   // shell r: (2r+1)^2 rows
                         const int wd = 2 * r + 1;
@@ -523,11 +518,11 @@ __global__ __launch_bounds__(PASS_BS) void grid_pass_kernel(const PassArgs a) {
                             const int row = (z * gp.gy + y) * gp.gx;
                             if (dz == -r || dz == r || dy == -r || dy == r) {
                                 // a row on the shell's y/z faces: the whole x extent is new
-                                scan_range<FMA>(sorted, cs[row + x0], cs[row + x1 + 1], qx, qy, qz, key, kpos, win);
+                                scan_range<FMA>(sorted, cs[row + x0], cs[row + x1 + 1], qx, qy, qz, key, kpos);
                             } else {
                                 // interior row of shell r: only its two x end cells are new
-                                if (cx - r >= 0) scan_range<FMA>(sorted, cs[row + cx - r], cs[row + cx - r + 1], qx, qy, qz, key, kpos, win);
-                                if (cx + r < gp.gx) scan_range<FMA>(sorted, cs[row + cx + r], cs[row + cx + r + 1], qx, qy, qz, key, kpos, win);
+                                if (cx - r >= 0) scan_range<FMA>(sorted, cs[row + cx - r], cs[row + cx - r + 1], qx, qy, qz, key, kpos);
+                                if (cx + r < gp.gx) scan_range<FMA>(sorted, cs[row + cx + r], cs[row + cx + r + 1], qx, qy, qz, key, kpos);
                             }
                         }
                     }
@@ -557,7 +552,7 @@ __global__ __launch_bounds__(PASS_BS) void grid_pass_kernel(const PassArgs a) {
                         if constexpr (FMA) d = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
                         else d = (dx * dx + dy * dy) + dz * dz;
                         const unsigned long long kk = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(unsigned)j;
-                        if (!done && kk < key) { key = kk; win = q; kpos = -1; }   // (no position in `sorted` known: no warm start next time)
+                        if (!done && kk < key) { key = kk; kpos = -1; }   // (no position in `sorted` known: no warm start next time)
                     }
                     fell_back = !done;
                     done = true;
@@ -566,6 +561,9 @@ __global__ __launch_bounds__(PASS_BS) void grid_pass_kernel(const PassArgs a) {
             if (done) {
                 have = key != ~0ull;
                 a.pos_prev[i] = kpos;
+                // the winner's coordinates: one load of a line the search has just touched (or, after the in-wave sweep, of the
+                // pair's target in original order)
+                if (have) win = kpos >= 0 ? sorted[kpos] : a.tgt4[pr.tgt_base + (int)(unsigned)(key & 0xffffffffull)];
             } else {   // single pair: resolved by the brute-force list pass through atomicMin, sums by the SEARCH = false launch
                 a.keys[i] = ~0ull;
                 a.pos_prev[i] = -1;
