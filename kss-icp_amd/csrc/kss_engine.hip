@@ -295,22 +295,19 @@ static int grid_setup(kss_ctx* c, IcpPlan& pl) {
     choose_cells(mn, mx, nt, gp);
     pl.gp = gp;
     const size_t ncells = (size_t)gp.gx * gp.gy * gp.gz;
-    KCHK(ensure_zeroed(c, c->g_counts, ncells * sizeof(int32_t)));   // zero at rest (kss_ctx.hpp)
-    KCHK(ensure(c, c->g_start, (ncells + 8) * sizeof(int32_t)));   // [0] pad, starts at [1 .. ncells + 1], pads behind (block_walk reads 16 bytes per row)
-    KCHK(ensure(c, c->g_bsums, ((ncells + 4095) / 4096 + 1) * sizeof(int32_t)));
+    KCHK(ensure_zeroed(c, c->g_counts, 2 * ncells * sizeof(int32_t)));   // target cells, then source cells; zero at rest (kss_ctx.hpp)
+    KCHK(ensure(c, c->g_start, (2 * ncells + 8) * sizeof(int32_t)));   // [0] pad, target starts at [1 .. ncells + 1], source starts (+ nt) behind
+    KCHK(ensure(c, c->g_bsums, ((2 * ncells + 4095) / 4096 + 1) * sizeof(int32_t)));
     KCHK(ensure(c, c->g_sorted, (size_t)nt * sizeof(float4)));
     KCHK(ensure(c, c->g_list, (size_t)ns * sizeof(int32_t)));
     KCHK(ensure(c, c->g_pos, (size_t)ns * sizeof(int32_t)));   // previous winner of every source (set to -1 = none by the source sort below)
     KCHK(ensure_zeroed(c, c->g_count, 64));   // [0] unresolved-list length: zero at rest
     pl.gpairs[0].gp = gp;
     pl.gpairs[0].cell_base = 0;
-    launch_grid_build(c->stream, tgt, nt, gp, (int32_t*)c->g_counts.p, (int32_t*)c->g_start.p + 1,
-                      (int32_t*)c->g_bsums.p, (float4*)c->g_sorted.p, true);
-    // sources into the same cell order (original index in .w): cur[0] is the scratch of the scatter
-    KCHK(ensure(c, c->g_start2, (ncells + 1) * sizeof(int32_t)));
-    launch_grid_sort_sources(c->stream, (const float4*)c->src0.p + g.src_base, ns, gp, (int32_t*)c->g_counts.p,
-                             (int32_t*)c->g_start2.p, (int32_t*)c->g_bsums.p,
-                             (float4*)c->cur[0].p, (float4*)c->src0.p + g.src_base, (int32_t*)c->g_pos.p);   // (scatter: src0 -> cur[0]; rank fix: cur[0] -> src0)
+    // both cell lists by shared launches; the sources end up in src0 in the target's cell order (original index in .w);
+    // cur[0] is the scatter's scratch
+    launch_grid_build_pair(c->stream, tgt, nt, (float4*)c->src0.p + g.src_base, ns, gp, (int32_t*)c->g_counts.p, (int32_t*)c->g_start.p + 1,
+                           (int32_t*)c->g_bsums.p, (float4*)c->g_sorted.p, (float4*)c->cur[0].p, (int32_t*)c->g_pos.p);
     HIPCHK(c, hipGetLastError());
     c->grid_stats[0] = gp.h; c->grid_stats[1] = gp.gx; c->grid_stats[2] = gp.gy; c->grid_stats[3] = gp.gz;
     if (c->stats_ns != ns || c->stats_nt != nt) { c->grid_stats[4] = 0; c->grid_stats[5] = 0; }
@@ -714,8 +711,7 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
             launch_corr_reduce(c->stream, (const RedWork*)c->red_work.p, (int)pl.red.size(), d_state,
                                d_out, (const float4*)c->tgt4.p, (const unsigned long long*)c->keys.p, max_d2,
                                (double*)c->partials.p, d_idx_out, d_d2_out, pl.src_in_cell_order ? 1 : 0);
-            launch_finalize_sums(c->stream, (const PairRed*)c->pair_red.p, pl.npairs, (const double*)c->partials.p,
-                                 (double*)c->h_sums_dev, nullptr, nullptr, nullptr, 0);
+            launch_finalize_sums(c->stream, (const PairRed*)c->pair_red.p, pl.npairs, (const double*)c->partials.p, (double*)c->h_sums_dev);
         }
     }
     HIPCHK(c, hipGetLastError());

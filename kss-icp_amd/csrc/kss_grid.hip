@@ -31,53 +31,25 @@
 
 namespace kss {
 
-// ---- bbox of the real (non-sentinel) targets ---------------------------------------------------------
-__global__ __launch_bounds__(256) void grid_bbox_kernel(const float4* __restrict__ tgt, int n, float* __restrict__ partial) {
-    __shared__ float sh[4][6];
-    float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
-    float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float4 p = tgt[i];
-        mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
-        mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            mn[k] = fminf(mn[k], __shfl_down(mn[k], off, 64));
-            mx[k] = fmaxf(mx[k], __shfl_down(mx[k], off, 64));
-        }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0)
-        for (int k = 0; k < 3; ++k) { sh[wave][k] = mn[k]; sh[wave][3 + k] = mx[k]; }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        float v = sh[0][threadIdx.x];
-        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fminf(v, sh[w][threadIdx.x]) : fmaxf(v, sh[w][threadIdx.x]);
-        partial[blockIdx.x * 6 + threadIdx.x] = v;
-    }
-}
-
-void launch_grid_bbox(hipStream_t st, const float4* d_tgt, int n, float* d_partial, int n_blocks) {
-    hipLaunchKernelGGL(grid_bbox_kernel, dim3(n_blocks), dim3(256), 0, st, d_tgt, n, d_partial);
-}
-
 __device__ __forceinline__ int cell_coord(float v, float o, float inv_h, int g) {
     int c = (int)floorf((v - o) * inv_h);
     c = c < 0 ? 0 : c;
     return c >= g ? g - 1 : c;
 }
 
-// ---- counting sort into cell order ---------------------------------------------------------------------
-__global__ __launch_bounds__(256) void grid_count_kernel(const float4* __restrict__ tgt, int n, GridParams gp,
-                                                         int32_t* __restrict__ counts) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = tgt[i];
+// ---- counting sort into cell order: target AND source of a pair by the same launches ---------------------------
+// counts / starts are ONE array of 2 * ncells entries: [0, ncells) the target's cells, [ncells, 2 ncells) the source's.
+// One exclusive scan over the whole array gives the target's starts directly (and start[ncells] = nt is their end
+// sentinel) and the source's starts offset by nt.  Blocks [0, nbt) handle target points, the rest source points.
+__global__ __launch_bounds__(256) void grid_count2_kernel(const float4* __restrict__ tgt, int nt, int nbt, const float4* __restrict__ src, int ns,
+                                                          GridParams gp, int32_t* __restrict__ counts) {
+    const bool is_src = (int)blockIdx.x >= nbt;
+    const int i = ((int)blockIdx.x - (is_src ? nbt : 0)) * 256 + (int)threadIdx.x;
+    if (i >= (is_src ? ns : nt)) return;
+    const float4 p = is_src ? src[i] : tgt[i];
     const int cx = cell_coord(p.x, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(p.y, gp.oy, gp.inv_h, gp.gy),
               cz = cell_coord(p.z, gp.oz, gp.inv_h, gp.gz);
-    atomicAdd(&counts[(cz * gp.gy + cy) * gp.gx + cx], 1);
+    atomicAdd(&counts[(is_src ? gp.gx * gp.gy * gp.gz : 0) + (cz * gp.gy + cy) * gp.gx + cx], 1);
 }
 
 // exclusive scan, 3 phases; each workgroup owns SCAN_CHUNK consecutive elements
@@ -186,30 +158,22 @@ static void launch_scan(hipStream_t st, const int32_t* d_counts, int ncells, int
     }
 }
 
-__global__ __launch_bounds__(256) void grid_scatter_kernel(const float4* __restrict__ tgt, int n, GridParams gp,
-                                                           int32_t* __restrict__ counts, const int32_t* __restrict__ start,
-                                                           float4* __restrict__ sorted) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float4 p = tgt[i];
+// scatter of both clouds: the cell's count doubles as its cursor -- counting DOWN hands out the slots start + count-1 ..
+// start and leaves the array zeroed for the next build (no cursor array for the scan to write, no memset in between).
+// Targets go to `sorted` (.w = original index), sources to `src_tmp` (.w = original index; grid_rank_fix_kernel orders each cell).
+__global__ __launch_bounds__(256) void grid_scatter2_kernel(const float4* __restrict__ tgt, int nt, int nbt, const float4* __restrict__ src, int ns,
+                                                            GridParams gp, int32_t* __restrict__ counts, const int32_t* __restrict__ start,
+                                                            float4* __restrict__ sorted, float4* __restrict__ src_tmp) {
+    const bool is_src = (int)blockIdx.x >= nbt;
+    const int i = ((int)blockIdx.x - (is_src ? nbt : 0)) * 256 + (int)threadIdx.x;
+    if (i >= (is_src ? ns : nt)) return;
+    float4 p = is_src ? src[i] : tgt[i];
     const int cx = cell_coord(p.x, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(p.y, gp.oy, gp.inv_h, gp.gy),
               cz = cell_coord(p.z, gp.oz, gp.inv_h, gp.gz);
-    // the cell's count doubles as its cursor: counting DOWN hands out the slots start + count-1 .. start and leaves the
-    // array zeroed for the next build (no separate cursor array for the scan to write, no memset in between)
-    const int cell = (cz * gp.gy + cy) * gp.gx + cx;
-    const int pos = start[cell] + atomicSub(&counts[cell], 1) - 1;
-    p.w = __int_as_float(i);   // original index rides in .w
-    sorted[pos] = p;
-}
-
-// counts_are_zero: the caller vouches for it (every complete build leaves them so: the scatter counts each cell back down)
-void launch_grid_build(hipStream_t st, const float4* d_tgt, int n, const GridParams& gp, int32_t* d_counts,
-                       int32_t* d_start, int32_t* d_block_sums, float4* d_sorted, bool counts_are_zero) {
-    const int ncells = gp.gx * gp.gy * gp.gz;
-    if (!counts_are_zero) hipMemsetAsync(d_counts, 0, (size_t)ncells * sizeof(int32_t), st);
-    hipLaunchKernelGGL(grid_count_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_tgt, n, gp, d_counts);
-    launch_scan(st, d_counts, ncells, d_start, d_block_sums);
-    hipLaunchKernelGGL(grid_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_tgt, n, gp, d_counts, (const int32_t*)d_start, d_sorted);
+    const int cell = (is_src ? gp.gx * gp.gy * gp.gz : 0) + (cz * gp.gy + cy) * gp.gx + cx;
+    const int pos = start[cell] + atomicSub(&counts[cell], 1) - 1 - (is_src ? nt : 0);
+    p.w = __int_as_float(i);
+    (is_src ? src_tmp : sorted)[pos] = p;
 }
 
 // ---- query -----------------------------------------------------------------------------------------------
@@ -340,8 +304,8 @@ __device__ __forceinline__ int block_walk(const GridParams& gp, const int32_t* _
 // neighbours neighbours, so ONE sort per registration keeps the queries of a wave / workgroup / XCD in the
 // same few cells (L1 / L2 hits instead of Infinity-Cache trips) for all iterations.
 __global__ __launch_bounds__(256) void grid_rank_fix_kernel(const float4* __restrict__ tmp, int n, GridParams gp,
-                                                            const int32_t* __restrict__ start, float4* __restrict__ out,
-                                                            int32_t* __restrict__ pos_init) {
+                                                            const int32_t* __restrict__ start /* the source half: start[c] - shift */, int shift,
+                                                            float4* __restrict__ out, int32_t* __restrict__ pos_init) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     if (pos_init) pos_init[j] = -1;   // no previous winner yet (saves a memset per registration)
@@ -349,17 +313,26 @@ __global__ __launch_bounds__(256) void grid_rank_fix_kernel(const float4* __rest
     const int cx = cell_coord(p.x, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(p.y, gp.oy, gp.inv_h, gp.gy),
               cz = cell_coord(p.z, gp.oz, gp.inv_h, gp.gz);
     const int c = (cz * gp.gy + cy) * gp.gx + cx;
-    const int lo = start[c], hi = start[c + 1];
+    const int lo = start[c] - shift, hi = start[c + 1] - shift;
     const int me = __float_as_int(p.w);
     int rank = 0;
     for (int k = lo; k < hi; ++k) rank += __float_as_int(tmp[k].w) < me ? 1 : 0;
     out[lo + rank] = p;
 }
 
-void launch_grid_sort_sources(hipStream_t st, const float4* d_src, int n, const GridParams& gp, int32_t* d_counts,
-                              int32_t* d_start, int32_t* d_block_sums, float4* d_tmp, float4* d_out, int32_t* d_pos_init) {
-    launch_grid_build(st, d_src, n, gp, d_counts, d_start, d_block_sums, d_tmp, true);   // (right after the target build over the same cells)
-    hipLaunchKernelGGL(grid_rank_fix_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_tmp, n, gp, d_start, d_out, d_pos_init);
+// Both cell lists of a single pair: count -> scan (2 launches) -> scatter -> rank fix = 5 launches (one pair of lists used to
+// be 10).  d_counts: 2 * ncells zeroed ints (zero at rest: left zeroed again); d_start: 2 * ncells + 1 ints, target starts
+// in [0, ncells], source starts + nt behind; d_src is read and, after the rank fix, rewritten in cell order (d_tmp: scratch).
+void launch_grid_build_pair(hipStream_t st, const float4* d_tgt, int nt, float4* d_src, int ns, const GridParams& gp, int32_t* d_counts,
+                            int32_t* d_start, int32_t* d_block_sums, float4* d_sorted, float4* d_tmp, int32_t* d_pos_init) {
+    const int ncells = gp.gx * gp.gy * gp.gz;
+    const int nbt = (nt + 255) / 256, nbs = (ns + 255) / 256;
+    hipLaunchKernelGGL(grid_count2_kernel, dim3(nbt + nbs), dim3(256), 0, st, d_tgt, nt, nbt, (const float4*)d_src, ns, gp, d_counts);
+    launch_scan(st, d_counts, 2 * ncells, d_start, d_block_sums);
+    hipLaunchKernelGGL(grid_scatter2_kernel, dim3(nbt + nbs), dim3(256), 0, st, d_tgt, nt, nbt, (const float4*)d_src, ns, gp, d_counts,
+                       (const int32_t*)d_start, d_sorted, d_tmp);
+    hipLaunchKernelGGL(grid_rank_fix_kernel, dim3(nbs), dim3(256), 0, st, (const float4*)d_tmp, ns, gp, (const int32_t*)d_start + ncells, nt,
+                       d_src, d_pos_init);
 }
 
 // =============================================================================================

@@ -166,9 +166,9 @@ void launch_nn_sweep(hipStream_t st, int S, bool fma, const NNWork* d_work, int 
 void launch_nn_sweep_list(hipStream_t st, int S, bool fma, const NNWork* d_work, int n_work,
                           const PairState* d_state, float4* d_src_cur, const float4* d_tgt4,
                           unsigned long long* d_keys, const int32_t* d_list, const int32_t* d_count);
-void launch_grid_bbox(hipStream_t st, const float4* d_tgt, int n, float* d_partial, int n_blocks);
-void launch_grid_build(hipStream_t st, const float4* d_tgt, int n, const GridParams& gp, int32_t* d_counts,
-                       int32_t* d_start, int32_t* d_block_sums, float4* d_sorted, bool counts_are_zero);
+// both cell lists of a single pair (count -> scan -> scatter -> rank fix, shared launches)
+void launch_grid_build_pair(hipStream_t st, const float4* d_tgt, int nt, float4* d_src, int ns, const GridParams& gp, int32_t* d_counts,
+                            int32_t* d_start, int32_t* d_block_sums, float4* d_sorted, float4* d_tmp, int32_t* d_pos_init);
 int grid_pass_blocks(int total_rows);
 void launch_grid_pass(hipStream_t st, bool fma, bool full, bool batch, bool search, const PassArgs& a);
 void launch_gridb_bbox(hipStream_t st, const float4* d_tgt, const GridPairDev* d_pairs, int npairs, float* d_bbox);
@@ -182,8 +182,6 @@ void launch_gridb_build_lds(hipStream_t st, const float4* d_tgt4, float4* d_src,
                             int32_t* d_cell_start, float4* d_sorted);
 void launch_grid_stats(hipStream_t st, const float4* d_src, int ns, const GridParams& gp, const int32_t* d_cell_start,
                        unsigned long long* d_out /* [0] evaluations of the 3x3x3 block, [1] occupied cells */);
-void launch_grid_sort_sources(hipStream_t st, const float4* d_src, int n, const GridParams& gp, int32_t* d_counts,
-                              int32_t* d_start, int32_t* d_block_sums, float4* d_tmp, float4* d_out, int32_t* d_pos_init);
 
 void launch_corr_reduce(hipStream_t st, const RedWork* d_work, int n_work, const PairState* d_state,
                         const float4* d_src, const float4* d_tgt4, const unsigned long long* d_keys,
@@ -197,10 +195,7 @@ void launch_corr_reduce_publish(hipStream_t st, const RedWork* d_work, int n_wor
 void launch_corr_reduce_idx(hipStream_t st, const float* d_src3, const float* d_tgt3, const int32_t* d_idx,
                             int64_t n, double max_d2, double* d_partials, int n_blocks);
 void launch_finalize_sums(hipStream_t st, const PairRed* d_pairs, int n_pairs, const double* d_partials,
-                          double* d_out /* n_pairs * NSUMS, device or host-mapped */,
-                          const int32_t* d_unresolved /* may be null */, int32_t* d_unresolved_reset /* may be null */,
-                          unsigned long long* d_pub = nullptr /* host-mapped {bits, seq} pairs, may be null */,
-                          unsigned long long seq = 0);
+                          double* d_out /* n_pairs * NSUMS, device or host-mapped */);
 
 // pre-shape statistics of one or two clouds: two launches, result published to host-mapped {bits, seq} slots
 void launch_preshape_pair(hipStream_t st, const void* const d_xyz[2], const int64_t n[2], int dtype, double* d_partials,

@@ -438,41 +438,20 @@ void launch_corr_reduce_idx(hipStream_t st, const float* d_src3, const float* d_
                        max_d2, d_partials);
 }
 
-// final stage: sums[pair][c] = sum over that pair's partial rows, in row order (deterministic).  With `pub` the sums
-// are ALSO published as {bits(sum), seq} 16-byte pairs into host-mapped memory (slot pair * NSUMS + c): the host spins
-// on the sequence numbers instead of paying a stream-sync wake-up per ICP iteration (see grid_nn_kernel).
+// final stage of brute-force batches above PUB_PAIRS pairs: sums[pair][c] = sum over that pair's partial rows, in row
+// order (deterministic), written to host-mapped memory; the host synchronizes the stream.
 __global__ __launch_bounds__(256) void finalize_sums_kernel(const PairRed* __restrict__ pairs,
                                                             const double* __restrict__ partials,
-                                                            double* __restrict__ out, const int32_t* __restrict__ unresolved,
-                                                            int32_t* __restrict__ unresolved_reset,
-                                                            unsigned long long* __restrict__ pub, unsigned long long seq) {
+                                                            double* __restrict__ out) {
     __shared__ double shg[ROWSUM_GROUPS][NSUMS];
     const PairRed pr = pairs[blockIdx.x];
-    double v = rows_column_sum(partials + (int64_t)pr.first * NSUMS, pr.count, shg);
-    const int c = threadIdx.x;
-    if (c >= NSUMS) return;
-    if (c == NSUMS - 1 && unresolved) {
-        // slot 19 reports how many sources the cell search left to the brute-force list pass
-        v = (double)*unresolved;
-        if (unresolved_reset) *unresolved_reset = 0;
-    }
-    out[(int64_t)blockIdx.x * NSUMS + c] = v;
-    if (pub) {
-        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-        const unsigned long long vb = (unsigned long long)__double_as_longlong(v);
-        u32x4 w;
-        w.x = (unsigned)vb; w.y = (unsigned)(vb >> 32); w.z = (unsigned)seq; w.w = (unsigned)(seq >> 32);
-        unsigned long long* dst = pub + 2 * ((int64_t)blockIdx.x * NSUMS + c);
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(w) : "memory");
-    }
+    const double v = rows_column_sum(partials + (int64_t)pr.first * NSUMS, pr.count, shg);
+    if (threadIdx.x < NSUMS) out[(int64_t)blockIdx.x * NSUMS + threadIdx.x] = v;
 }
 
-void launch_finalize_sums(hipStream_t st, const PairRed* d_pairs, int n_pairs, const double* d_partials, double* d_out,
-                          const int32_t* d_unresolved, int32_t* d_unresolved_reset, unsigned long long* d_pub,
-                          unsigned long long seq) {
+void launch_finalize_sums(hipStream_t st, const PairRed* d_pairs, int n_pairs, const double* d_partials, double* d_out) {
     if (n_pairs <= 0) return;
-    hipLaunchKernelGGL(finalize_sums_kernel, dim3(n_pairs), dim3(256), 0, st, d_pairs, d_partials, d_out, d_unresolved,
-                       d_unresolved_reset, d_pub, seq);
+    hipLaunchKernelGGL(finalize_sums_kernel, dim3(n_pairs), dim3(256), 0, st, d_pairs, d_partials, d_out);
 }
 
 // ---------------------------------------------------------------------------------------------
