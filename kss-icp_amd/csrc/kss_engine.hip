@@ -757,31 +757,15 @@ static int icp_loop(kss_ctx* c, const IcpPlan& pl_in, const kss_icp_params& P, k
         for (int p = 0; p < np; ++p) { active[p] = 0; }
     int it = 0;
     GatedGuard gated_guard(c);
-    while (n_active > 0) {
-        const float4* d_in = it == 0 ? (const float4*)c->src0.p : (const float4*)c->cur[(it - 1) & 1].p;
-        float4* d_out = (float4*)c->cur[it & 1].p;
-        // (cancelled if this iteration converges; never with an all-reduce callback: its collective would queue up on
-        // this stream BEHIND the closed gate and the host would wait for it forever)
-        c->gated.want_next = plan->grid && !P.allreduce && it + 1 < P.max_iterations;
-        c->gated.want_full = full;
-        // batched cell lists: every pair's sums are published as its last workgroup finishes, and the solve loop below
-        // picks the pairs up in that order while the rest of the launch is still running
-        c->defer_wait = plan->gridb;
-        const auto tb0 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-        const int rc_pass = nn_pass(c, *plan, P.nn_fma != 0, d_in, d_out, max_d2, nullptr, nullptr, full, active.data());
-        const bool deferred = c->defer_wait;
-        c->defer_wait = false;
-        const auto tb1 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-        KCHK(rc_pass);
-        const unsigned long long pass_seq = c->seq;
-        // source rows split over ranks: the sums of all ranks, identical on every rank from here on
-        if (P.allreduce && P.allreduce(P.allreduce_user, (double*)c->h_sums, NSUMS) != 0)
-            return set_err(c, KSS_ERR_RCCL, "icp: the allreduce callback failed");
-        // per-pair solve + convergence test: pairs are independent (a large batch is split over a few host threads;
-        // each pair is handled by exactly one thread, so the results do not depend on the split)
+
+    // ---- per-pair solve + convergence test of the pairs [p0, p1) after a pass: pairs are independent (a large batch is
+    // split over a few host threads; each pair is handled by exactly one thread with the serial code, so the results do
+    // not depend on the split).  poll: the pass published per pair (batched cell lists) and the pairs are picked up as
+    // their sums land, in launch order, while the rest of the launch is still running.  Returns the pairs that finished.
+    auto solve_pairs = [&](int p0, int p1, unsigned long long pass_seq, bool poll_first, int* n_finished) -> int {
         std::atomic<int> finished{0}, stuck{0};
-        bool poll = deferred;
-        std::fill(solved.begin(), solved.end(), 0);
+        bool poll = poll_first;
+        std::fill(solved.begin() + p0, solved.begin() + p1, 0);
         auto solve = [&](int pb, int pe) {
             int fin_here = 0;
             for (int p = pb; p < pe; ++p) {
@@ -816,34 +800,60 @@ static int icp_loop(kss_ctx* c, const IcpPlan& pl_in, const kss_icp_params& P, k
             }
             finished.fetch_add(fin_here, std::memory_order_relaxed);
         };
-        // the fallback statistics of this pass need the pairs that were active when it ran
-        if (plan->gridb) was_active = active;
-        if (np >= 64) {
+        const int n = p1 - p0;
+        if (n >= 64) {
             std::atomic<int> next{0};
-            constexpr int kBlock = 16;   // pairs claimed at a time, in launch order: the first threads start while the GPU is still on later pairs
-            c->pool.parallel_for(np, [&](int, int) {
+            static const int kBlock = [] { const char* e = getenv("KSS_SOLVE_BLOCK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 64; }();   // pairs claimed at a time, in launch order: the first threads start while the GPU is still on later pairs.  Tuning hook; measured at C3: blocks of 4 pairs 11.7 ms (threads share cache lines of the per-pair arrays), 16: 9.85, 64: 9.5
+            c->pool.parallel_for(n, [&](int, int) {
                 for (;;) {
-                    const int pb = next.fetch_add(1) * kBlock;
-                    if (pb >= np) break;
-                    solve(pb, std::min(np, pb + kBlock));
+                    const int pb = p0 + next.fetch_add(1) * kBlock;
+                    if (pb >= p1) break;
+                    solve(pb, std::min(p1, pb + kBlock));
                 }
             });
         } else {
-            solve(0, np);
-        }
-        if (c->timing && deferred) {   // batch: time to enqueue the pass vs time until every pair was solved
-            const auto tb2 = std::chrono::steady_clock::now();
-            c->t_launch_us += std::chrono::duration<double, std::micro>(tb1 - tb0).count();
-            c->t_wait_us += std::chrono::duration<double, std::micro>(tb2 - tb1).count();
+            solve(p0, p1);
         }
         if (stuck.load() > 0) {   // a pair did not publish in time: synchronize (surfaces a faulted kernel), then finish the stragglers
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            for (int p = 0; p < np; ++p) {
+            for (int p = p0; p < p1; ++p) {
                 if (!active[p] || solved[p]) continue;
                 if (!collect_pair(c, p, pass_seq)) return set_err(c, KSS_ERR_HIP, "kernel finished without publishing its result");
             }
             poll = false;        // their sums are in h_sums now
-            solve(0, np);        // (pairs already solved in this pass are skipped)
+            solve(p0, p1);       // (pairs already solved in this pass are skipped)
+        }
+        *n_finished = finished.load(std::memory_order_relaxed);
+        return KSS_OK;
+    };
+
+    while (n_active > 0) {
+        const float4* d_in = it == 0 ? (const float4*)c->src0.p : (const float4*)c->cur[(it - 1) & 1].p;
+        float4* d_out = (float4*)c->cur[it & 1].p;
+        // (cancelled if this iteration converges; never with an all-reduce callback: its collective would queue up on
+        // this stream BEHIND the polling kernel, whose transform depends on it)
+        c->gated.want_next = plan->grid && !P.allreduce && it + 1 < P.max_iterations;
+        c->gated.want_full = full;
+        // batched cell lists: every pair's sums are published as its last workgroup finishes, and the solve loop
+        // picks the pairs up in that order while the rest of the launch is still running
+        c->defer_wait = plan->gridb;
+        const auto tb0 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+        const int rc_pass = nn_pass(c, *plan, P.nn_fma != 0, d_in, d_out, max_d2, nullptr, nullptr, full, active.data());
+        const bool deferred = c->defer_wait;
+        c->defer_wait = false;
+        const auto tb1 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+        KCHK(rc_pass);
+        const unsigned long long pass_seq = c->seq;
+        // source rows split over ranks: the sums of all ranks, identical on every rank from here on
+        if (P.allreduce && P.allreduce(P.allreduce_user, (double*)c->h_sums, NSUMS) != 0)
+            return set_err(c, KSS_ERR_RCCL, "icp: the allreduce callback failed");
+        if (plan->gridb) was_active = active;   // the fallback statistics of this pass need the pairs that were active when it ran
+        int fin_now = 0;
+        KCHK(solve_pairs(0, np, pass_seq, deferred, &fin_now));
+        if (c->timing && deferred) {   // batch: time to enqueue the pass vs time until every pair was solved
+            const auto tb2 = std::chrono::steady_clock::now();
+            c->t_launch_us += std::chrono::duration<double, std::micro>(tb1 - tb0).count();
+            c->t_wait_us += std::chrono::duration<double, std::micro>(tb2 - tb1).count();
         }
         if (plan->gridb) {
             // Batched cell lists: slot 19 counts the lanes that ended in the in-wave brute-force fallback.  When more
@@ -862,7 +872,7 @@ static int icp_loop(kss_ctx* c, const IcpPlan& pl_in, const kss_icp_params& P, k
                 plan = &brute_plan;
             }
         }
-        n_active -= finished.load(std::memory_order_relaxed);
+        n_active -= fin_now;
         ++it;
     }
     for (int p = 0; p < np; ++p) {
