@@ -55,6 +55,9 @@ static int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npai
     static const int64_t min_ns = [] { const char* e = getenv("KSS_GRID_MIN_NS"); return e ? (int64_t)atoll(e) : (int64_t)512; }();
     pl.grid = nn_mode == KSS_NN_GRID || (nn_mode == KSS_NN_AUTO && npairs == 1 && nt[0] >= min_nt && ns[0] >= min_ns);
     if (npairs != 1) pl.grid = false;
+    // (Pairs sharing ONE target -- the candidate batch of kss_register -- stay on the brute-force engine: measured this round
+    // on the fused batch kernel too, 14 candidates x 1406 points: the candidates start from local minima of the rotation
+    // search, a few percent of their sources need the in-wave fallback EVERY pass, 123 us per pass against 25 us: 14.3 vs 4.5 ms.)
     if (npairs > 1 && !shared_target) {
         // batch: one cell list per pair.  Measured against the brute-force batch (tools/batch_small.py): brute force wins
         // at 16 pairs x 600 points, they tie at 4 x 1500, the cell lists win from 16 x 1500 and 8 x 4000 up; badly posed
@@ -866,7 +869,7 @@ static int icp_loop(kss_ctx* c, const IcpPlan& pl_in, const kss_icp_params& P, k
             if (fallback > 0.10 * act && !getenv("KSS_GRID_NOSWITCH")) {
                 std::vector<int64_t> ns(np), nt(np);
                 for (int p = 0; p < np; ++p) { ns[p] = plan->g[p].ns; nt[p] = plan->g[p].nt; }
-                KCHK(build_plan(c, ns.data(), nt.data(), np, false, P.nn_sources_per_thread, P.nn_target_splits, KSS_NN_BRUTE, brute_plan));
+                KCHK(build_plan(c, ns.data(), nt.data(), np, pl_in.shared_target, P.nn_sources_per_thread, P.nn_target_splits, KSS_NN_BRUTE, brute_plan));
                 brute_plan.src_in_cell_order = true;
                 KCHK(stage_plan(c, brute_plan));
                 plan = &brute_plan;
