@@ -533,28 +533,24 @@ __device__ __forceinline__ double pre_radius_scalar(const T* __restrict__ xyz, i
     return acc;
 }
 
-// radius pass of the float4 stream: lane j reads float4 j and j+1 (32 contiguous bytes; the second is the neighbour's
-// first: an L1/TA hit, memory traffic unchanged) and finishes the points that START inside float4 j: two when
-// j % 3 == 0, else one.
+// radius pass of the float4 stream: a lane takes THREE consecutive float4 = 12 floats = exactly four points (48 contiguous
+// bytes per lane, 3 KB per wave: every byte is requested once -- the first version read float4 j and j+1 per lane, i.e.
+// every byte twice, and ran at half the sum pass's rate).
 __device__ __forceinline__ double pre_radius_f32v(const float* __restrict__ xyz, int64_t n, int lb, int nb, double cx, double cy, double cz) {
     const float4* __restrict__ v = (const float4*)xyz;
-    const int64_t nf4 = (3 * n) / 4;
+    const int64_t ngroups = n / 4;
     double acc = 0.0;
     auto add = [&](float x, float y, float z) {
         const double xl = (double)x - cx, yl = (double)y - cy, zl = (double)z - cz;
         acc += sqrt((xl * xl + yl * yl) + zl * zl);
     };
-    const int64_t nv = nf4 > 0 ? nf4 - 1 : 0;   // lanes that may read j + 1
 #pragma unroll 2
-    for (int64_t j = (int64_t)lb * 256 + threadIdx.x; j < nv; j += (int64_t)nb * 256) {
-        const float4 a = v[j], b = v[j + 1];
-        const int m = (int)(j % 3);
-        if (m == 0) { add(a.x, a.y, a.z); add(a.w, b.x, b.y); }
-        else if (m == 1) add(a.z, a.w, b.x);
-        else add(a.y, a.z, a.w);
+    for (int64_t q = (int64_t)lb * 256 + threadIdx.x; q < ngroups; q += (int64_t)nb * 256) {
+        const float4 a = v[3 * q], b = v[3 * q + 1], c = v[3 * q + 2];
+        add(a.x, a.y, a.z); add(a.w, b.x, b.y); add(b.z, b.w, c.x); add(c.y, c.z, c.w);
     }
-    if (lb == 0 && threadIdx.x == 0)   // points that start at or after float 4 * nv: at most three, or all of a tiny cloud
-        for (int64_t k = (4 * nv + 2) / 3; k < n; ++k) add(xyz[3 * k], xyz[3 * k + 1], xyz[3 * k + 2]);
+    if (lb == 0 && threadIdx.x == 0)   // the last n % 4 points
+        for (int64_t k = 4 * ngroups; k < n; ++k) add(xyz[3 * k], xyz[3 * k + 1], xyz[3 * k + 2]);
     return acc;
 }
 
