@@ -61,13 +61,14 @@ __global__ __launch_bounds__(256) void aivs_bbox_kernel(const double* __restrict
 
 // ---- box of a point: BallRegion_BoxInput, ballRegionCompute.hpp:646-664 -------------------------------------------
 __device__ __forceinline__ int aivs_box_of(const double* __restrict__ P, int i, const AivsGrid& g) {
-    const double xNum = (P[3 * (int64_t)i] - g.minx) / g.unit, yNum = (P[3 * (int64_t)i + 1] - g.miny) / g.unit,
-                 zNum = (P[3 * (int64_t)i + 2] - g.minz) / g.unit;
-    int xi = (int)xNum, yi = (int)yNum, zi = (int)zNum;
-    if (xi < xNum || xi == 0) xi++;
-    if (yi < yNum || yi == 0) yi++;
-    if (zi < zNum || zi == 0) zi++;
-    return xi + g.nx * (yi - 1) + g.nx * g.ny * (zi - 1);
+    // 1-based box coordinates: ceil of the scaled offset, with 0 mapped to 1 (the reference's rule, in its f64 arithmetic)
+    const double fx = (P[3 * (int64_t)i] - g.minx) / g.unit, fy = (P[3 * (int64_t)i + 1] - g.miny) / g.unit,
+                 fz = (P[3 * (int64_t)i + 2] - g.minz) / g.unit;
+    int bx = (int)fx, by = (int)fy, bz = (int)fz;
+    if (bx < fx || bx == 0) bx++;
+    if (by < fy || by == 0) by++;
+    if (bz < fz || bz == 0) bz++;
+    return bx + g.nx * (by - 1) + g.nx * g.ny * (bz - 1);
 }
 
 __global__ __launch_bounds__(256) void aivs_count_kernel(const double* __restrict__ P, int n, AivsGrid g, int32_t* __restrict__ box_of,
@@ -100,15 +101,16 @@ __global__ __launch_bounds__(256) void aivs_rank_kernel(const int32_t* __restric
     members[lo + rank] = me;
 }
 
-__device__ __forceinline__ void aivs_box_center(const AivsGrid& g, int boxIndex, double c[3]) {   // :1150-1172
-    int z_num = boxIndex / (g.nx * g.ny) + 1;
-    const int leveZ = boxIndex % (g.nx * g.ny);
-    int y_num = leveZ / g.nx + 1;
-    int x_num = leveZ % g.nx;
-    if (x_num == 0) { x_num = g.nx; y_num = y_num - 1; }
-    c[0] = (g.minx + (x_num - 1) * g.unit + g.minx + x_num * g.unit) / 2;
-    c[1] = (g.miny + (y_num - 1) * g.unit + g.miny + y_num * g.unit) / 2;
-    c[2] = (g.minz + (z_num - 1) * g.unit + g.minz + z_num * g.unit) / 2;
+__device__ __forceinline__ void aivs_box_center(const AivsGrid& g, int box, double c[3]) {   // :1150-1172
+    // inverse of aivs_box_of's linear index (1-based coordinates; a multiple of nx belongs to the last column of the row before)
+    int bz = box / (g.nx * g.ny) + 1;
+    const int in_layer = box % (g.nx * g.ny);
+    int by = in_layer / g.nx + 1;
+    int bx = in_layer % g.nx;
+    if (bx == 0) { bx = g.nx; by = by - 1; }
+    c[0] = (g.minx + (bx - 1) * g.unit + g.minx + bx * g.unit) / 2;
+    c[1] = (g.miny + (by - 1) * g.unit + g.miny + by * g.unit) / 2;
+    c[2] = (g.minz + (bz - 1) * g.unit + g.minz + bz * g.unit) / 2;
 }
 
 // per box: the member closest to the box centre (:634-686, strict '>' keeps the first minimum) and the sampling
