@@ -300,7 +300,7 @@ static int grid_setup(kss_ctx* c, IcpPlan& pl) {
     const size_t ncells = (size_t)gp.gx * gp.gy * gp.gz;
     KCHK(ensure_zeroed(c, c->g_counts, 2 * ncells * sizeof(int32_t)));   // target cells, then source cells; zero at rest (kss_ctx.hpp)
     KCHK(ensure(c, c->g_start, (2 * ncells + 8) * sizeof(int32_t)));   // [0] pad, target starts at [1 .. ncells + 1], source starts (+ nt) behind
-    KCHK(ensure(c, c->g_bsums, ((2 * ncells + 4095) / 4096 + 1) * sizeof(int32_t)));
+    KCHK(ensure(c, c->g_bsums, scan_scratch_bytes((int)(2 * ncells))));
     KCHK(ensure(c, c->g_sorted, (size_t)nt * sizeof(float4)));
     KCHK(ensure(c, c->g_list, (size_t)ns * sizeof(int32_t)));
     KCHK(ensure(c, c->g_pos, (size_t)ns * sizeof(int32_t)));   // previous winner of every source (set to -1 = none by the source sort below)
@@ -375,7 +375,7 @@ static int grid_setup_batch(kss_ctx* c, IcpPlan& pl) {
     } else {
         KCHK(ensure(c, c->g_counts, (size_t)cells * sizeof(int32_t)));
         KCHK(ensure(c, c->g_start2, ((size_t)cells + 1) * sizeof(int32_t)));
-        KCHK(ensure(c, c->g_bsums, (((size_t)cells + 4095) / 4096 + 1) * sizeof(int32_t)));
+        KCHK(ensure(c, c->g_bsums, scan_scratch_bytes((int)cells)));
         if ((cells + 4095) / 4096 > 1024 * 16) return set_err(c, KSS_ERR_ARG, "batch cell lists too large for the scan");
         launch_gridb_build_targets(c->stream, (const float4*)c->tgt4.p, (int)pl.total_tgt_pad, (const GridPairDev*)c->g_pairs.p, np,
                                    (int)cells, (int32_t*)c->g_counts.p, (int32_t*)c->g_start.p + 1,

@@ -169,6 +169,7 @@ void launch_nn_sweep_list(hipStream_t st, int S, bool fma, const NNWork* d_work,
 // both cell lists of a single pair (count -> scan -> scatter -> rank fix, shared launches)
 void launch_grid_build_pair(hipStream_t st, const float4* d_tgt, int nt, float4* d_src, int ns, const GridParams& gp, int32_t* d_counts,
                             int32_t* d_start, int32_t* d_block_sums, float4* d_sorted, float4* d_tmp, int32_t* d_pos_init);
+size_t scan_scratch_bytes(int n);   // scratch of the cell-count scan over n cells
 int grid_pass_blocks(int total_rows);
 void launch_grid_pass(hipStream_t st, bool fma, bool full, bool batch, bool search, const PassArgs& a);
 void launch_gridb_bbox(hipStream_t st, const float4* d_tgt, const GridPairDev* d_pairs, int npairs, float* d_bbox);
