@@ -25,7 +25,9 @@ struct PairGeom {
 struct IcpPlan {
     int npairs = 0, S = 4;
     std::vector<PairGeom> g;
-    std::vector<NNWork> nn;
+    mutable std::vector<NNWork> nn;   // (single pair on the cell list: filled only if the search ever needs the list pass)
+    int per_block = 0;
+    size_t nn_count = 0;
     std::vector<RedWork> red;
     std::vector<PairRed> pred;
     int64_t total_src = 0, total_tgt_pad = 0, total_keys = 0;
@@ -41,6 +43,30 @@ struct IcpPlan {
     int total_rows = 0;
 };
 constexpr int PASS_CHUNK = 512;   // == PASS_BS of kss_device.hpp (device-only header)
+
+// sweep work items of pair p: (block of sources) x (target split)
+static void fill_nn_table(const IcpPlan& pl, int p) {
+    const PairGeom& g = pl.g[p];
+    const int per_block = pl.per_block;
+    for (int b = 0; b < g.n_src_blocks; ++b)
+        for (int s = 0; s < g.n_split; ++s) {
+            NNWork w;
+            w.pair = p;
+            w.src_begin = g.src_base + b * per_block;
+            w.src_count = (int32_t)std::min<int64_t>(per_block, g.ns - (int64_t)b * per_block);
+            w.tgt_begin = g.tgt_base + s * g.chunk;
+            w.tgt_count = g.chunk;
+            w.tgt_pair_base = g.tgt_base;
+            w.key_begin = g.key_base + (int32_t)((int64_t)s * g.ns) + b * per_block;
+            w.write_src = s == 0;
+            if (pl.grid) {   // LIST semantics (kss_kernels.hip): offsets into the unresolved list, key row 0
+                w.src_begin = b * per_block;
+                w.key_begin = g.key_base;
+                w.write_src = g.src_base;
+            }
+            pl.nn.push_back(w);
+        }
+}
 
 static int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npairs, bool shared_target,
                int S_req, int split_req, int nn_mode, IcpPlan& pl) {
@@ -138,34 +164,20 @@ static int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npai
     }
 
     pl.nn.clear(); pl.red.clear(); pl.pred.resize(npairs);
+    pl.per_block = per_block;
+    pl.nn_count = 0;
     int32_t prow = 0;
     for (int p = 0; p < npairs; ++p) {
         const PairGeom& g = pl.g[p];
-        for (int b = 0; b < (pl.gridb ? 0 : g.n_src_blocks); ++b)
-            for (int s = 0; s < g.n_split; ++s) {
-                NNWork w;
-                w.pair = p;
-                w.src_begin = g.src_base + b * per_block;
-                w.src_count = (int32_t)std::min<int64_t>(per_block, g.ns - (int64_t)b * per_block);
-                w.tgt_begin = g.tgt_base + s * g.chunk;
-                w.tgt_count = g.chunk;
-                w.tgt_pair_base = g.tgt_base;
-                w.key_begin = g.key_base + (int32_t)((int64_t)s * g.ns) + b * per_block;
-                w.write_src = s == 0;
-                if (pl.grid) {   // LIST semantics (kss_kernels.hip): offsets into the unresolved list, key row 0
-                    w.src_begin = b * per_block;
-                    w.key_begin = g.key_base;
-                    w.write_src = g.src_base;
-                }
-                pl.nn.push_back(w);
-            }
+        if (!pl.gridb) pl.nn_count += (size_t)g.n_src_blocks * g.n_split;
+        if (!pl.gridb && !pl.grid) fill_nn_table(pl, p);   // (cell-list single pair: ~4000 entries nobody reads unless a source falls back; built then)
         pl.pred[p].first = prow;
         // reduce workgroups own 256*R consecutive sources (R = 1 up to 131k sources: the reduce is latency bound,
         // it wants many workgroups; the 240-lane final reduction handles hundreds of rows in a few microseconds)
         int64_t R = (g.ns + 256 * 512 - 1) / (256 * 512);   // <= ~512 partial rows per pair
         R = std::max<int64_t>(1, std::min<int64_t>(R, 64));
         const int64_t rchunk = 256 * R;
-        const int nrb = pl.gridb ? 0 : (int)((g.ns + rchunk - 1) / rchunk);   // (the batched cell lists reduce inside the fused pass)
+        const int nrb = (pl.gridb || pl.grid) ? 0 : (int)((g.ns + rchunk - 1) / rchunk);   // (the cell-list engines reduce inside the fused pass)
         for (int b = 0; b < nrb; ++b) {
             RedWork r;
             r.pair = p;
@@ -186,6 +198,8 @@ static int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npai
 // Work tables of the sweep / reduce kernels (uploaded lazily on the fused cell-list path).
 static int stage_tables(kss_ctx* c, const IcpPlan& pl) {
     if (c->tables_staged) return KSS_OK;
+    if (pl.grid && pl.nn.empty())
+        for (int p = 0; p < pl.npairs; ++p) fill_nn_table(pl, p);
     HIPCHK(c, hipMemcpyAsync(c->nn_work.p, pl.nn.data(), pl.nn.size() * sizeof(NNWork), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->red_work.p, pl.red.data(), pl.red.size() * sizeof(RedWork), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->pair_red.p, pl.pred.data(), pl.pred.size() * sizeof(PairRed), hipMemcpyHostToDevice, c->stream));
@@ -203,7 +217,7 @@ static int stage_plan(kss_ctx* c, const IcpPlan& pl) {
     KCHK(ensure(c, c->keys, (size_t)pl.total_keys * sizeof(unsigned long long)));
     KCHK(ensure(c, c->partials, std::max<size_t>(pl.red.size(), 2 * (size_t)pl.total_rows) * NSUMS * sizeof(double)));   // (x2: rows as 16-byte granules)
     KCHK(ensure(c, c->sums, (size_t)pl.npairs * NSUMS * sizeof(double)));
-    KCHK(ensure(c, c->nn_work, pl.nn.size() * sizeof(NNWork)));
+    KCHK(ensure(c, c->nn_work, pl.nn_count * sizeof(NNWork)));
     KCHK(ensure(c, c->red_work, pl.red.size() * sizeof(RedWork)));
     KCHK(ensure(c, c->pair_red, pl.pred.size() * sizeof(PairRed)));
     KCHK(ensure(c, c->state, (size_t)pl.npairs * sizeof(PairState)));
@@ -943,12 +957,24 @@ int icp_run_dev(kss_ctx* c, const void* d_src, const int64_t* src_off, const voi
     KCHK(restore_zero_at_rest(c));
     DirtyGuard guard(c);
     c->timing = getenv("KSS_TIMING") != nullptr;
+    auto lap = [&](const char* what, std::chrono::steady_clock::time_point& from) {   // KSS_TIMING: host time of each setup stage
+        if (!c->timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[kss]   %s %.1f us\n", what, std::chrono::duration<double, std::micro>(now - from).count());
+        from = now;
+    };
+    auto ts = t0;
     KCHK(build_plan(c, ns.data(), nt.data(), npairs, shared_target, p->nn_sources_per_thread, p->nn_target_splits, p->nn_mode, pl));
+    lap("plan", ts);
     KCHK(stage_plan(c, pl));
+    lap("stage", ts);
     KCHK(pack_clouds(c, pl, d_src, src_off, d_tgt, tgt_off, dtype));
+    lap("pack (enqueue)", ts);
     KCHK(grid_setup(c, pl));
     KCHK(grid_setup_batch(c, pl));
+    lap("cell lists (bbox sync + enqueue)", ts);
     if (c->timing) HIPCHK(c, hipStreamSynchronize(c->stream));   // (only to split setup from loop in the KSS_TIMING report)
+    lap("drain", ts);
     const auto t1 = std::chrono::steady_clock::now();
     c->t_launch_us = c->t_wait_us = 0;
     const int rc = icp_loop(c, pl, *p, results);
