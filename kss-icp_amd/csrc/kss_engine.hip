@@ -5,6 +5,8 @@
 // (kss_host_math.hpp) and evaluates the PCL convergence criteria.  There is no CPU compute fallback in this file.
 #pragma clang fp contract(off)
 
+#include <emmintrin.h>
+
 #include "kss_ctx.hpp"
 
 namespace kss {
@@ -512,6 +514,23 @@ static bool gated_available(kss_ctx* c) {
     static const bool want = getenv("KSS_GATED") == nullptr || atoi(getenv("KSS_GATED")) != 0;   // KSS_GATED=0 switches it off
     if (!want || !c->own_stream || kss_live_contexts().load() != 1) return false;
     if (c->gated.supported < 0) {
+        c->gated.supported = 0;
+        // the device-side granules: on a large-BAR system in FINE-GRAINED device memory, which the host can store into directly
+        // (tools/bar_probe.hip: same 2.1 us host -> kernel -> host round trip as a kernel polling host memory, but every
+        // workgroup can poll it: no asking workgroup, no re-publication hop).  KSS_GATE_BAR=0: always the re-publishing form.
+        static const bool want_bar = getenv("KSS_GATE_BAR") == nullptr || atoi(getenv("KSS_GATE_BAR")) != 0;
+        hipDeviceProp_t prop;
+        void* bar = nullptr;
+        if (want_bar && hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.isLargeBar &&
+            hipExtMallocWithFlags(&bar, 4096, hipDeviceMallocFinegrained) == hipSuccess && bar) {
+            if (hipMemset(bar, 0, 4096) == hipSuccess && hipDeviceSynchronize() == hipSuccess) {
+                c->gate_bar = (unsigned int*)bar;
+                c->gated.supported = 1;
+                return true;
+            }
+            hipFree(bar);
+        }
+        (void)hipGetLastError();
         void *x = nullptr, *xd = nullptr;
         if (ensure(c, c->g_gate, 256) == KSS_OK && hipMemsetAsync(c->g_gate.p, 0, 256, c->stream) == hipSuccess &&
             hipHostMalloc(&x, 2 * sizeof(PairState), hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&xd, x, 0) == hipSuccess) {
@@ -521,13 +540,27 @@ static bool gated_available(kss_ctx* c) {
         } else {
             (void)hipGetLastError();
             if (x) hipHostFree(x);
-            c->gated.supported = 0;
         }
     }
     return c->gated.supported == 1;
 }
 
-static void gated_release(kss_ctx* c, const PairState& st, int skip) {   // transform (or the cancel mark), then the stamp
+static void gated_release(kss_ctx* c, const PairState& st, int skip) {   // transform (or the cancel mark), stamped
+    if (c->gate_bar) {
+        // five 16-byte granules {3 words, stamp} straight into device memory through the BAR; each is one aligned 16-byte
+        // store (never seen torn), so their order does not matter; the fence pushes them out of the write-combining buffers
+        int words[16];
+        std::memcpy(words, &st, sizeof st);
+        words[14] = skip;                       // pad[0]
+        unsigned int* slot = c->gate_bar + 32 * c->gated.slot;   // two records, 128 bytes apart
+        for (int g = 0; g < 5; ++g) {
+            const __m128i v = _mm_set_epi32(c->gated.stamp, words[3 * g + 2], words[3 * g + 1], words[3 * g]);
+            _mm_store_si128((__m128i*)(slot + 4 * g), v);
+        }
+        _mm_sfence();
+        c->gated.pending = false;
+        return;
+    }
     PairState* rec = &c->h_xf[c->gated.slot];
     for (int k = 0; k < 12; ++k) rec->m[k] = st.m[k];
     rec->active = st.active; rec->apply = st.apply; rec->pad[0] = skip;
@@ -626,9 +659,14 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
             if (G.stamp == 0) G.stamp = 1;   // (0 is what a fresh record holds)
             PassArgs n = pass_args(c, pl, d_out, nxt_out, max_d2, nullptr, nullptr);
             n.ps0 = hs[0];
-            n.state = c->h_xf_dev + G.slot;
             n.gate_seq = G.stamp;
-            n.gate_dev = (unsigned int*)c->g_gate.p;
+            if (c->gate_bar) {   // the host writes the granules itself
+                n.state = nullptr;
+                n.gate_dev = c->gate_bar + 32 * G.slot;
+            } else {             // workgroup 0 asks the host-mapped record and re-publishes
+                n.state = c->h_xf_dev + G.slot;
+                n.gate_dev = (unsigned int*)c->g_gate.p;
+            }
             n.seq = ++c->seq;
             launch_grid_pass(c->stream, fma, G.want_full, false, true, n);
             G.pending = true; G.seq = c->seq; G.d_in = d_out; G.d_out = nxt_out; G.fma = fma; G.full = G.want_full; G.max_d2 = max_d2;

@@ -426,16 +426,18 @@ __global__ __launch_bounds__(PASS_BS) void grid_pass_kernel(const PassArgs a) {
         if (SEARCH && a.use_prev && pp >= 0) prevp = sorted[pp];
     }
     if constexpr (!BATCH && SEARCH) {
-        if (a.state) {
+        if (a.gate_seq != 0) {
             // GATED launch (kss_engine.hip): this kernel was enqueued while the previous iteration was still running, before
-            // its transform existed.  Workgroup 0 polls the host-mapped 64-byte record (one cache line, one PCIe read per poll)
-            // until the host has stamped it with this launch's number -- the host writes the stamp last and a line is read
-            // as a whole, so a matching stamp comes with its transform -- and re-publishes it in device memory, where every
-            // workgroup polls for it (200 workgroups polling HOST memory at once were measured: 45 us per iteration).  Both
-            // polls are bounded: a host that never answers makes the kernel leave without publishing, which the host's own
-            // wait reports.  pad[0] != 0: cancelled.  (The loads above are already in flight while this waits.)
+            // its transform existed.  It polls five self-validating 16-byte granules {3 words, stamp} in DEVICE memory (one
+            // 80-byte request per poll and workgroup) until all carry this launch's stamp.  Who writes them: on a large-BAR
+            // system the HOST, straight into that (fine-grained) device memory with five 16-byte stores; otherwise workgroup 0,
+            // which polls a host-mapped 64-byte record (one cache line, one PCIe read per poll; the host writes the stamp
+            // last and a line is read as a whole) and re-publishes it.  (All 200 workgroups polling HOST memory at once were
+            // measured: 45 us per iteration.)  Both polls are bounded: a host that never answers makes the kernel leave
+            // without publishing, which the host's own wait reports.  pad[0] != 0: cancelled.  (The loads above are
+            // already in flight while this waits.)
             typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-            if (w == 0 && threadIdx.x < 16) {
+            if (a.state && w == 0 && threadIdx.x < 16) {
                 // the ONE workgroup that asks the host: lanes 0-15 read the 64-byte record as one request per poll
                 const int* w32 = reinterpret_cast<const int*>(a.state);
                 int v = 0, n = 0;
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(PASS_BS) void grid_pass_kernel(const PassArgs a) {
                 int n = 0;
                 bool ok = true;
                 for (;;) {
-                    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(src) : "memory");
+                    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(src) : "memory");   // system scope: the writer may be the host
                     if (__builtin_amdgcn_ballot_w64((int)v.w == a.gate_seq) == 0xffull) break;
                     __builtin_amdgcn_s_sleep(1);
                     if (++n > (1 << 22)) { ok = false; break; }
