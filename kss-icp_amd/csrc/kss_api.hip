@@ -68,6 +68,7 @@ int kss_ctx_destroy(kss_ctx* c) {
     if (c->h_seq) hipHostFree(c->h_seq);
     if (c->h_xf) hipHostFree(c->h_xf);
     if (c->gate_bar) hipFree(c->gate_bar);
+    if (c->bar_state) hipFree(c->bar_state);
     if (c->h_state) hipHostFree(c->h_state);
     for (kss_ctx* w : c->workers) kss_ctx_destroy(w);
     c->workers.clear();

@@ -77,6 +77,7 @@ struct kss_ctx {
     bool ws_dirty = false;
     bool defer_wait = false;   // batched fused pass: the ICP loop polls the pairs' result slots itself
     PairState* h_xf = nullptr; PairState* h_xf_dev = nullptr;
+    PairState* bar_state = nullptr; int bar_state_cap = 0; bool bar_state_failed = false;   // batched pass: per-pair states, same kind of memory
     unsigned int* gate_bar = nullptr;   // fine-grained device memory the host stores into through the BAR (large-BAR systems)
     unsigned long long seq = 0;
     void* h_state = nullptr; size_t h_state_cap = 0;

@@ -725,8 +725,12 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
         // workgroups) gets the table copied to device memory once per pass.
         PassArgs a = pass_args(c, pl, d_in, d_out, max_d2, d_idx_out, d_d2_out);
         a.state = (const PairState*)c->state.p;
+        if (c->bar_state && c->bar_state_cap >= pl.npairs) {   // the host has stored the states there itself (mirror_state)
+            _mm_sfence();
+            a.state = c->bar_state;
+        }
         static const int host_state_rows = [] { const char* e = getenv("KSS_BATCH_HOST_STATE_ROWS"); return e ? atoi(e) : 32768; }();   // tuning hook (measured at C3, 20480 workgroups: 9.71 ms from host memory vs 9.85 ms with the copy)
-        if (pl.total_rows <= host_state_rows) {
+        if (a.state != c->bar_state && pl.total_rows <= host_state_rows) {
             void* dev = nullptr;
             if (hipHostGetDevicePointer(&dev, c->h_state, 0) == hipSuccess && dev) a.state = (const PairState*)dev;
         }
@@ -775,9 +779,37 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
     return KSS_OK;
 }
 
+// the batched pass's per-pair state table in fine-grained device memory the host can store into (null: no large BAR)
+static PairState* bar_state_table(kss_ctx* c, int npairs) {
+    static const bool want_bar = getenv("KSS_GATE_BAR") == nullptr || atoi(getenv("KSS_GATE_BAR")) != 0;
+    if (!want_bar || c->bar_state_failed) return nullptr;
+    if (c->bar_state && c->bar_state_cap >= npairs) return c->bar_state;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess || !prop.isLargeBar) { c->bar_state_failed = true; return nullptr; }
+    if (c->bar_state) { hipStreamSynchronize(c->stream); hipFree(c->bar_state); c->bar_state = nullptr; c->bar_state_cap = 0; }
+    void* p = nullptr;
+    const int cap = npairs + npairs / 4 + 64;
+    if (hipExtMallocWithFlags(&p, (size_t)cap * sizeof(PairState), hipDeviceMallocFinegrained) != hipSuccess || !p) {
+        (void)hipGetLastError();
+        c->bar_state_failed = true;
+        return nullptr;
+    }
+    c->bar_state = (PairState*)p; c->bar_state_cap = cap;
+    return c->bar_state;
+}
+
 static void set_state(PairState& s, const float T[16], int active, int apply) {
     for (int k = 0; k < 12; ++k) s.m[k] = T[k];
     s.active = active; s.apply = apply; s.pad[0] = s.pad[1] = 0;
+}
+// ... and its mirror in fine-grained device memory (large-BAR systems, batched cell lists): the workgroups of the next pass
+// read their pair's state from device memory, the host having stored it there directly -- no copy operation, no PCIe read
+// per workgroup.  Write-only on the host side (a host READ through the BAR costs microseconds).
+static inline void mirror_state(PairState* bar, int p, const PairState& s) {
+    if (!bar) return;
+    const __m128i* v = reinterpret_cast<const __m128i*>(&s);
+    __m128i* d = reinterpret_cast<__m128i*>(bar + p);
+    for (int k = 0; k < 4; ++k) _mm_store_si128(d + k, _mm_loadu_si128(v + k));
 }
 
 // The ICP loop over a packed workspace (src0/tgt4 already filled).
@@ -791,6 +823,7 @@ static int icp_loop(kss_ctx* c, const IcpPlan& pl_in, const kss_icp_params& P, k
     std::vector<double> last_mse(np, 0.0);
     const bool full = P.trace_sums != nullptr;   // traced runs report all 20 sums of every pass
     PairState* hs = (PairState*)c->h_state;
+    PairState* bar = pl_in.gridb ? bar_state_table(c, np) : nullptr;   // (null without a large BAR)
     float I[16];
     mat4_identity(I);
     for (int p = 0; p < np; ++p) {
@@ -803,6 +836,7 @@ static int icp_loop(kss_ctx* c, const IcpPlan& pl_in, const kss_icp_params& P, k
         cv.fixed_iterations = P.fixed_iterations != 0;
         mat4_identity(&fin[(size_t)p * 16]);
         set_state(hs[p], I, 1, 0);
+        mirror_state(bar, p, hs[p]);
     }
     const double max_d2 = P.max_corr_dist * P.max_corr_dist;
     const double* hsum = (const double*)c->h_sums;
@@ -830,6 +864,7 @@ static int icp_loop(kss_ctx* c, const IcpPlan& pl_in, const kss_icp_params& P, k
                 if ((int)s[0] < P.min_correspondences) {   // PCL: "Not enough correspondences found"
                     state[p] = KSS_STATE_NO_CORRESPONDENCES; converged[p] = 0; active[p] = 0; ++fin_here; solved[p] = 1;
                     set_state(hs[p], I, 0, 0);
+                    mirror_state(bar, p, hs[p]);
                     continue;
                 }
                 float* tk = &Tk[(size_t)p * 16];
@@ -852,6 +887,7 @@ static int icp_loop(kss_ctx* c, const IcpPlan& pl_in, const kss_icp_params& P, k
                 } else {
                     set_state(hs[p], tk, 1, 1);   // next sweep applies T_k on load (transformCloud)
                 }
+                mirror_state(bar, p, hs[p]);
             }
             finished.fetch_add(fin_here, std::memory_order_relaxed);
         };
@@ -938,7 +974,7 @@ static int icp_loop(kss_ctx* c, const IcpPlan& pl_in, const kss_icp_params& P, k
     }
     if (P.compute_fitness) {
         // getFitnessScore(): NN of final * ORIGINAL input, mean d2 over all source points
-        for (int p = 0; p < np; ++p) set_state(hs[p], &fin[(size_t)p * 16], 1, 1);
+        for (int p = 0; p < np; ++p) { set_state(hs[p], &fin[(size_t)p * 16], 1, 1); mirror_state(bar, p, hs[p]); }
         c->gated.want_next = false;
         int32_t* d_idx = nullptr;
         float* d_d2 = nullptr;
