@@ -121,10 +121,10 @@ static inline int ensure(kss_ctx* c, DevBuf& b, size_t bytes) {
 }
 
 static inline int ensure_zeroed(kss_ctx* c, DevBuf& b, size_t bytes) {
-    const void* before = b.p;
+    const size_t before = b.cap;   // (not the pointer: a freed block can come back at the same address with a larger size)
     const int rc = ensure(c, b, bytes);
     if (rc != KSS_OK) return rc;
-    if (b.p != before && hipMemsetAsync(b.p, 0, b.cap, c->stream) != hipSuccess) return set_err(c, KSS_ERR_HIP, "hipMemsetAsync(zero-at-rest buffer)");
+    if (b.cap != before && hipMemsetAsync(b.p, 0, b.cap, c->stream) != hipSuccess) return set_err(c, KSS_ERR_HIP, "hipMemsetAsync(zero-at-rest buffer)");
     return KSS_OK;
 }
 

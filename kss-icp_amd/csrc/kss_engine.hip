@@ -321,6 +321,19 @@ static int grid_setup(kss_ctx* c, IcpPlan& pl) {
     KCHK(ensure(c, c->g_list, (size_t)ns * sizeof(int32_t)));
     KCHK(ensure(c, c->g_pos, (size_t)ns * sizeof(int32_t)));   // previous winner of every source (set to -1 = none by the source sort below)
     KCHK(ensure_zeroed(c, c->g_count, 64));   // [0] unresolved-list length: zero at rest
+    if (getenv("KSS_COUNTS_CHECK")) {   // diagnostic: the zero-at-rest invariant of the cell counters, checked on the host
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::vector<int32_t> h(2 * ncells);
+        HIPCHK(c, hipMemcpy(h.data(), c->g_counts.p, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        size_t bad = 0, first = 0;
+        for (size_t k = 0; k < h.size(); ++k)
+            if (h[k] != 0) { if (!bad) first = k; ++bad; }
+        if (bad) {
+            std::fprintf(stderr, "[kss] counts check: %zu cells x 2 (%d x %d x %d), buffer %zu bytes, %zu non-zero counters, first at %zu = %d\n", ncells, gp.gx,
+                         gp.gy, gp.gz, c->g_counts.cap, bad, first, h[first]);
+            return set_err(c, KSS_ERR_HIP, "cell counters not zero at rest");
+        }
+    }
     pl.gpairs[0].gp = gp;
     pl.gpairs[0].cell_base = 0;
     // both cell lists by shared launches; the sources end up in src0 in the target's cell order (original index in .w);
@@ -389,7 +402,7 @@ static int grid_setup_batch(kss_ctx* c, IcpPlan& pl) {
         launch_gridb_build_lds(c->stream, (const float4*)c->tgt4.p, (float4*)c->src0.p, (float4*)c->cur[0].p, (const GridPairDev*)c->g_pairs.p, np,
                                (int32_t*)c->g_start.p + 1, (float4*)c->g_sorted.p);
     } else {
-        KCHK(ensure(c, c->g_counts, (size_t)cells * sizeof(int32_t)));
+        KCHK(ensure_zeroed(c, c->g_counts, (size_t)cells * sizeof(int32_t)));   // zero at rest, as the single-pair build expects of this buffer
         KCHK(ensure(c, c->g_start2, ((size_t)cells + 1) * sizeof(int32_t)));
         KCHK(ensure(c, c->g_bsums, scan_scratch_bytes((int)cells)));
         if ((cells + 4095) / 4096 > 1024 * 16) return set_err(c, KSS_ERR_ARG, "batch cell lists too large for the scan");

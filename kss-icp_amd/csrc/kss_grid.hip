@@ -845,7 +845,7 @@ void launch_gridb_bbox(hipStream_t st, const float4* d_tgt, const GridPairDev* d
 // targets: tgt4 (padded layout, total_tgt_pad slots) -> d_sorted (pair by pair, sum of nt entries), d_start
 void launch_gridb_build_targets(hipStream_t st, const float4* d_tgt, int total_tgt_pad, const GridPairDev* d_pairs, int npairs,
                                 int total_cells, int32_t* d_counts, int32_t* d_start, int32_t* d_block_sums, float4* d_sorted) {
-    hipMemsetAsync(d_counts, 0, (size_t)total_cells * sizeof(int32_t), st);
+    // d_counts: zero at rest (kss_ctx.hpp); the count-down scatters below leave it zeroed again
     const dim3 grid((total_tgt_pad + 255) / 256), block(256);
     hipLaunchKernelGGL((gridb_bin_kernel<false, false>), grid, block, 0, st, d_tgt, total_tgt_pad, d_pairs, npairs, d_counts, (const int32_t*)nullptr, (float4*)nullptr);
     launch_scan(st, d_counts, total_cells, d_start, d_block_sums);
