@@ -61,7 +61,7 @@ int kss_ctx_destroy(kss_ctx* c) {
     DevBuf* bufs[] = {&c->tgt4, &c->src0, &c->cur[0], &c->cur[1], &c->keys, &c->partials, &c->sums, &c->nn_work,
                       &c->red_work, &c->pair_red, &c->state, &c->cs, &c->scratch_a, &c->scratch_b, &c->scratch_c,
                       &c->stage_src, &c->stage_tgt, &c->stage_idx, &c->stage_d2, &c->stage_out, &c->g_counts, &c->g_start,
-                      &c->g_cursor, &c->g_bsums, &c->g_sorted, &c->g_list, &c->g_count, &c->g_bbox, &c->g_partials, &c->g_start2, &c->g_pairs, &c->g_stamps, &c->g_pos, &c->pack_seg, &c->reg_s, &c->reg_t, &c->reg_p, &c->reg_all, &c->reg_f, &c->reg_g, &c->oct_pts, &c->oct_cen, &c->oct_a, &c->oct_b, &c->oct_tmp, &c->pair_ticket, &c->pre_partials, &c->pre_state, &c->g_rowpair, &c->g_gate};
+                      &c->g_cursor, &c->g_bsums, &c->g_sorted, &c->g_list, &c->g_count, &c->g_bbox, &c->g_partials, &c->g_start2, &c->g_pairs, &c->g_stamps, &c->g_pos, &c->g_nnst, &c->pack_seg, &c->reg_s, &c->reg_t, &c->reg_p, &c->reg_all, &c->reg_f, &c->reg_g, &c->oct_pts, &c->oct_cen, &c->oct_a, &c->oct_b, &c->oct_tmp, &c->pair_ticket, &c->pre_partials, &c->pre_state, &c->g_rowpair, &c->g_gate};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (c->h_sums) hipHostFree(c->h_sums);
@@ -123,6 +123,12 @@ int kss_debug_grid_evals(kss_ctx* c, double out[2]) {
 // diagnostic: in-kernel timeline stamps of the last fused grid launch (KSS_GRID_STAMPS=1); not part of the ABI header
 int kss_debug_grid_stamps(kss_ctx* c, unsigned long long* out, int64_t cap) {
     if (!c || !out) return KSS_ERR_ARG;
+    if (c->stamps_nblk > 0 && c->g_stamps.p) {   // KSS_GRID_STAMPS=2: the buffer of the last launch that was waited for
+        hipStreamSynchronize(c->stream);
+        c->last_stamps.resize((size_t)c->stamps_nblk * 16);
+        if (hipMemcpy(c->last_stamps.data(), (const unsigned long long*)c->g_stamps.p + (size_t)(c->stamps_seq & 1) * c->stamps_nblk * 16,
+                      c->last_stamps.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return KSS_ERR_HIP;
+    }
     const int64_t n = std::min<int64_t>(cap, (int64_t)c->last_stamps.size());
     for (int64_t i = 0; i < n; ++i) out[i] = c->last_stamps[(size_t)i];
     return (int)n;

@@ -46,10 +46,11 @@ struct kss_ctx {
     // grow-only device workspace
     DevBuf tgt4, src0, cur[2], keys, partials, sums, nn_work, red_work, pair_red, state, cs, scratch_a,
         scratch_b, scratch_c, stage_src, stage_tgt, stage_idx, stage_d2, stage_out, g_counts, g_start, g_cursor,
-        g_bsums, g_sorted, g_list, g_count, g_bbox, g_partials, g_start2, g_pairs, g_stamps, g_pos, pack_seg, reg_s, reg_t, reg_p, reg_all, reg_f, reg_g, oct_pts, oct_cen, oct_a, oct_b, oct_tmp, pair_ticket, pre_partials, pre_state, g_rowpair, g_gate;
+        g_bsums, g_sorted, g_list, g_count, g_bbox, g_partials, g_start2, g_pairs, g_stamps, g_pos, g_nnst, pack_seg, reg_s, reg_t, reg_p, reg_all, reg_f, reg_g, oct_pts, oct_cen, oct_a, oct_b, oct_tmp, pair_ticket, pre_partials, pre_state, g_rowpair, g_gate;
     HostPool pool;   // per-pair host work of batched iterations
     std::vector<kss_ctx*> workers;   // contexts of kss_register_batch's worker threads (same device, own streams)
     std::vector<unsigned long long> last_stamps;
+    int stamps_nblk = 0; unsigned long long stamps_seq = 0;   // KSS_GRID_STAMPS=2
     std::vector<float> h_bbox;   // bbox partials of the last single-pair target (host copy)
     double evals_sum = 0.0, evals_launches = 0.0;   // diagnostic runs: distance evaluations of the fused grid launches
     // pinned host staging
@@ -77,6 +78,7 @@ struct kss_ctx {
     bool ws_dirty = false;
     bool defer_wait = false;   // batched fused pass: the ICP loop polls the pairs' result slots itself
     PairState* h_xf = nullptr; PairState* h_xf_dev = nullptr;
+    bool nn_have = false;             // the cell-list pass has written nn_win / nn_state for the current lists
     PairState* bar_state = nullptr; int bar_state_cap = 0; bool bar_state_failed = false;   // batched pass: per-pair states, same kind of memory
     unsigned int* gate_bar = nullptr;   // fine-grained device memory the host stores into through the BAR (large-BAR systems)
     unsigned long long seq = 0;

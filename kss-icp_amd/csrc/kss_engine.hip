@@ -319,7 +319,9 @@ static int grid_setup(kss_ctx* c, IcpPlan& pl) {
     KCHK(ensure(c, c->g_bsums, scan_scratch_bytes((int)(2 * ncells))));
     KCHK(ensure(c, c->g_sorted, (size_t)nt * sizeof(float4)));
     KCHK(ensure(c, c->g_list, (size_t)ns * sizeof(int32_t)));
-    KCHK(ensure(c, c->g_pos, (size_t)ns * sizeof(int32_t)));   // previous winner of every source (set to -1 = none by the source sort below)
+    KCHK(ensure(c, c->g_pos, (size_t)ns * sizeof(float4)));   // last winner of every source (written by the first pass before any pass reads it)
+    c->nn_have = false;
+    KCHK(ensure(c, c->g_nnst, (size_t)ns * sizeof(float2)));   // ... and its skip state (written by the first pass before any pass reads it)
     KCHK(ensure_zeroed(c, c->g_count, 64));   // [0] unresolved-list length: zero at rest
     if (getenv("KSS_COUNTS_CHECK")) {   // diagnostic: the zero-at-rest invariant of the cell counters, checked on the host
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -328,18 +330,16 @@ static int grid_setup(kss_ctx* c, IcpPlan& pl) {
         size_t bad = 0, first = 0;
         for (size_t k = 0; k < h.size(); ++k)
             if (h[k] != 0) { if (!bad) first = k; ++bad; }
-        if (bad) {
-            std::fprintf(stderr, "[kss] counts check: %zu cells x 2 (%d x %d x %d), buffer %zu bytes, %zu non-zero counters, first at %zu = %d\n", ncells, gp.gx,
-                         gp.gy, gp.gz, c->g_counts.cap, bad, first, h[first]);
-            return set_err(c, KSS_ERR_HIP, "cell counters not zero at rest");
-        }
+        std::fprintf(stderr, "[kss] counts check: %zu cells x 2 (%d x %d x %d), buffer %zu bytes, %zu non-zero counters%s", ncells, gp.gx, gp.gy, gp.gz,
+                     c->g_counts.cap, bad, bad ? "" : "\n");
+        if (bad) { std::fprintf(stderr, ", first at %zu = %d\n", first, h[first]); return set_err(c, KSS_ERR_HIP, "cell counters not zero at rest"); }
     }
     pl.gpairs[0].gp = gp;
     pl.gpairs[0].cell_base = 0;
     // both cell lists by shared launches; the sources end up in src0 in the target's cell order (original index in .w);
     // cur[0] is the scatter's scratch
     launch_grid_build_pair(c->stream, tgt, nt, (float4*)c->src0.p + g.src_base, ns, gp, (int32_t*)c->g_counts.p, (int32_t*)c->g_start.p + 1,
-                           (int32_t*)c->g_bsums.p, (float4*)c->g_sorted.p, (float4*)c->cur[0].p, (int32_t*)c->g_pos.p);
+                           (int32_t*)c->g_bsums.p, (float4*)c->g_sorted.p, (float4*)c->cur[0].p);
     HIPCHK(c, hipGetLastError());
     c->grid_stats[0] = gp.h; c->grid_stats[1] = gp.gx; c->grid_stats[2] = gp.gy; c->grid_stats[3] = gp.gz;
     if (c->stats_ns != ns || c->stats_nt != nt) { c->grid_stats[4] = 0; c->grid_stats[5] = 0; }
@@ -392,8 +392,9 @@ static int grid_setup_batch(kss_ctx* c, IcpPlan& pl) {
     HIPCHK(c, hipMemcpyAsync(c->g_pairs.p, hp.data(), (size_t)np * sizeof(GridPairDev), hipMemcpyHostToDevice, c->stream));
     KCHK(ensure(c, c->g_start, ((size_t)cells + 8) * sizeof(int32_t)));   // [0] pad, starts at [1 ..], pads behind
     KCHK(ensure(c, c->g_sorted, (size_t)sum_nt * sizeof(float4)));
-    KCHK(ensure(c, c->g_pos, (size_t)pl.total_src * sizeof(int32_t)));   // previous winners: -1 = none yet
-    HIPCHK(c, hipMemsetAsync(c->g_pos.p, 0xff, (size_t)pl.total_src * sizeof(int32_t), c->stream));
+    KCHK(ensure(c, c->g_pos, (size_t)pl.total_src * sizeof(float4)));   // last winners (no initialisation: the first pass does not read them)
+    c->nn_have = false;
+    KCHK(ensure(c, c->g_nnst, (size_t)pl.total_src * sizeof(float2)));
     KCHK(ensure(c, c->g_rowpair, pl.row_pair.size() * sizeof(int32_t)));
     HIPCHK(c, hipMemcpyAsync(c->g_rowpair.p, pl.row_pair.data(), pl.row_pair.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     static const bool no_lds = getenv("KSS_GRIDB_NOLDS") != nullptr;   // A/B switch: always the global-atomic build
@@ -402,7 +403,9 @@ static int grid_setup_batch(kss_ctx* c, IcpPlan& pl) {
         launch_gridb_build_lds(c->stream, (const float4*)c->tgt4.p, (float4*)c->src0.p, (float4*)c->cur[0].p, (const GridPairDev*)c->g_pairs.p, np,
                                (int32_t*)c->g_start.p + 1, (float4*)c->g_sorted.p);
     } else {
-        KCHK(ensure_zeroed(c, c->g_counts, (size_t)cells * sizeof(int32_t)));   // zero at rest, as the single-pair build expects of this buffer
+        // (zero at rest, as the single-pair build expects of this buffer: a plain ensure() here once left the slack behind
+        // `cells` uninitialised, and a later single pair with more cells scanned garbage counts -- see DESIGN.md, incidents)
+        KCHK(ensure_zeroed(c, c->g_counts, (size_t)cells * sizeof(int32_t)));
         KCHK(ensure(c, c->g_start2, ((size_t)cells + 1) * sizeof(int32_t)));
         KCHK(ensure(c, c->g_bsums, scan_scratch_bytes((int)cells)));
         if ((cells + 4095) / 4096 > 1024 * 16) return set_err(c, KSS_ERR_ARG, "batch cell lists too large for the scan");
@@ -603,12 +606,16 @@ static PassArgs pass_args(kss_ctx* c, const IcpPlan& pl, const float4* d_in, flo
     a.cell_start = (const int32_t*)c->g_start.p + 1;
     a.sorted = (const float4*)c->g_sorted.p;
     a.tgt4 = (const float4*)c->tgt4.p;
-    a.pos_prev = (int32_t*)c->g_pos.p;
+    a.nn_win = (float4*)c->g_pos.p;
+    a.nn_state = (float2*)c->g_nnst.p;
+    static const float skin = getenv("KSS_SKIN") ? (float)atof(getenv("KSS_SKIN")) : 0.25f;   // KSS_SKIN=-1: every source searches in every pass
+    a.skin = skin;
+    a.chained = d_in != (const float4*)c->src0.p ? 1 : 0;   // (the first pass and the fitness pass read the original cloud)
     a.keys = (unsigned long long*)c->keys.p;
     a.list = (int32_t*)c->g_list.p; a.list_count = (int32_t*)c->g_count.p;
     a.total_rows = pl.total_rows;
     static const bool noprev = getenv("KSS_GRID_NOPREV") != nullptr;   // A/B switch: the previous winner is stored but not used as a bound
-    a.use_prev = noprev ? 0 : 1;
+    a.use_prev = !noprev && c->nn_have ? 1 : 0;   // (nn_have: a search pass of this registration has written the per-source state)
     a.max_d2 = max_d2;
     a.rows = (double*)c->partials.p; a.tickets = (int32_t*)c->pair_ticket.p;
     a.pub = c->h_seq_dev;
@@ -636,10 +643,20 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
         // single pair: the transform rides in the kernel arguments
         PassArgs a = pass_args(c, pl, d_in, d_out, max_d2, d_idx_out, d_d2_out);
         const int nblk = grid_pass_blocks(pl.total_rows);
-        if (getenv("KSS_GRID_STAMPS")) {   // diagnostic build of the timeline (tools/grid_stamps.py)
+        // diagnostic builds of the timeline (tools/grid_stamps.py).  KSS_GRID_STAMPS=1: plain launches, buffer cleared and read
+        // back every pass.  =2: the gated chain as it runs in production; two buffers alternate with the launch sequence number
+        // (the launch pre-enqueued behind the last real one is cancelled but has stamped its start) and kss_debug_grid_stamps
+        // fetches the one of the last launch that was waited for.
+        static const int stamps_mode = getenv("KSS_GRID_STAMPS") ? atoi(getenv("KSS_GRID_STAMPS")) : 0;
+        unsigned long long* stamps2 = nullptr;
+        if (stamps_mode == 1) {
             KCHK(ensure(c, c->g_stamps, (size_t)nblk * 16 * sizeof(unsigned long long)));
             HIPCHK(c, hipMemsetAsync(c->g_stamps.p, 0, (size_t)nblk * 16 * sizeof(unsigned long long), c->stream));
             a.stamps = (unsigned long long*)c->g_stamps.p;
+        } else if (stamps_mode == 2) {
+            KCHK(ensure(c, c->g_stamps, (size_t)nblk * 32 * sizeof(unsigned long long)));
+            stamps2 = (unsigned long long*)c->g_stamps.p;
+            c->stamps_nblk = nblk;
         }
         const auto tl0 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
         unsigned long long want_seq = 0;
@@ -655,7 +672,9 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
             // search + correspondence sums + final reduction in ONE launch; sums land in host-mapped memory
             a.ps0 = hs[0];
             a.seq = ++c->seq;
+            if (stamps2) a.stamps = stamps2 + (size_t)(a.seq & 1) * nblk * 16;
             launch_grid_pass(c->stream, fma, full, false, true, a);
+            c->nn_have = true;
             want_seq = c->seq;
         }
         HIPCHK(c, hipGetLastError());
@@ -681,18 +700,20 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
                 n.gate_dev = (unsigned int*)c->g_gate.p;
             }
             n.seq = ++c->seq;
+            if (stamps2) n.stamps = stamps2 + (size_t)(n.seq & 1) * nblk * 16;
             launch_grid_pass(c->stream, fma, G.want_full, false, true, n);
             G.pending = true; G.seq = c->seq; G.d_in = d_out; G.d_out = nxt_out; G.fma = fma; G.full = G.want_full; G.max_d2 = max_d2;
             if (hipGetLastError() != hipSuccess) { gated_cancel(c); G.supported = 0; }   // (if it did get queued it is answered; gating is given up)
         }
         const auto tl1 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
         KCHK(wait_seq(c, 1, want_seq));
+        if (stamps2) c->stamps_seq = want_seq;
         if (c->timing) {
             const auto tl2 = std::chrono::steady_clock::now();
             c->t_launch_us += std::chrono::duration<double, std::micro>(tl1 - tl0).count();
             c->t_wait_us += std::chrono::duration<double, std::micro>(tl2 - tl1).count();
         }
-        if (a.stamps) {
+        if (a.stamps && !stamps2) {
             c->last_stamps.resize((size_t)nblk * 16);
             HIPCHK(c, hipMemcpy(c->last_stamps.data(), a.stamps, c->last_stamps.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             for (int b = 0; b < nblk; ++b) c->evals_sum += (double)c->last_stamps[(size_t)b * 16 + 10];
@@ -710,6 +731,19 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
                 std::memset(&one, 0, sizeof one);
                 one.active = 1;
                 HIPCHK(c, hipMemcpy(c->state.p, &one, sizeof one, hipMemcpyHostToDevice));
+            }
+            if (getenv("KSS_LIST_CHECK")) {   // diagnostic: the list the search pass has left, checked on the host before it is used
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                int32_t cnt = -1;
+                HIPCHK(c, hipMemcpy(&cnt, c->g_count.p, sizeof cnt, hipMemcpyDeviceToHost));
+                const int64_t ns0 = pl.g[0].ns;
+                std::vector<int32_t> l((size_t)std::max<int64_t>(0, std::min<int64_t>(cnt, ns0)));
+                if (!l.empty()) HIPCHK(c, hipMemcpy(l.data(), c->g_list.p, l.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+                int64_t bad = 0;
+                for (int32_t v : l) bad += v < 0 || v >= ns0;
+                std::fprintf(stderr, "[kss] list check: count %d of %lld sources (column 19 said %.0f), %lld entries out of range, nn table %zu items, S %d\n",
+                             cnt, (long long)ns0, ((const double*)c->h_sums)[NSUMS - 1], (long long)bad, pl.nn.size(), pl.S);
+                if (cnt < 0 || cnt > ns0 || bad) return set_err(c, KSS_ERR_HIP, "list check failed");
             }
             {
                 ProfScope ps(c, KSS_K_NN_SWEEP);
@@ -749,12 +783,24 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
         }
         if (a.state == (const PairState*)c->state.p)
             HIPCHK(c, hipMemcpyAsync(c->state.p, hs, (size_t)pl.npairs * sizeof(PairState), hipMemcpyHostToDevice, c->stream));
+        const int nblk = grid_pass_blocks(pl.total_rows);
+        if (getenv("KSS_GRID_STAMPS")) {   // diagnostic build of the timeline (tools/batch_stamps.py)
+            KCHK(ensure(c, c->g_stamps, (size_t)nblk * 16 * sizeof(unsigned long long)));
+            HIPCHK(c, hipMemsetAsync(c->g_stamps.p, 0, (size_t)nblk * 16 * sizeof(unsigned long long), c->stream));
+            a.stamps = (unsigned long long*)c->g_stamps.p;
+        }
         {
             ProfScope ps(c, KSS_K_GRID_NN);
             a.seq = ++c->seq;
             launch_grid_pass(c->stream, fma, full, true, true, a);
+            c->nn_have = true;
         }
         HIPCHK(c, hipGetLastError());
+        if (a.stamps) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));   // (the stream does not synchronise with the null stream)
+            c->last_stamps.resize((size_t)nblk * 16);
+            HIPCHK(c, hipMemcpy(c->last_stamps.data(), a.stamps, c->last_stamps.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        }
         if (!c->defer_wait) KCHK(wait_seq(c, pl.npairs, c->seq, active));
         return KSS_OK;
     }

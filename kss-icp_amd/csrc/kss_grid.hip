@@ -12,14 +12,17 @@
 //             distance b(r) from the query to the faces of the visited block; the search stops when
 //             best_d2 < (b(r) - eps)^2 * (1 - 1e-6), a bound that is conservative w.r.t. the f32 rounding
 //             of both the cell assignment and the distance, so it can only search MORE than needed.
-//   warm start: inside an ICP every source remembers where its previous winner sits; that point is evaluated
-//             first and its distance prunes the cells of the first block that cannot hold the winner nor a tie
-//             (block_walk); the result does not depend on it.
+//   warm start: inside an ICP every source carries its last winner {coordinates, index} and a pair {B, acc}: "every other
+//             target was at distance >= B when this source was last searched; it has moved by at most acc since".  While
+//             (B - acc)^2 exceeds the winner's new distance (with margins for the f32 roundings) the winner stands and the
+//             source is not searched at all (grid_pass_kernel, phase A).  A source that is searched evaluates its last
+//             winner first; that distance, grown by a skin, prunes the cells of the first block that cannot hold the winner
+//             nor a tie (block_walk / row_walk).  Results never depend on any of this.
 //   fallback: a query not resolved within GridParams::rcap shells is appended to a list and resolved by the
 //             brute-force sweep (nn_sweep_kernel<LIST>) -- far-away clouds never degrade below it.  (The batched
-//             kernel sweeps the pair's targets inside the wave instead: gridb_nn_kernel.)
+//             kernel sweeps the pair's targets inside the wave instead.)
 //   fusion  : the correspondence sums are accumulated by the searching lanes (the winner's coordinates are still in
-//             registers) and reduced in the same launch; see grid_nn_kernel / gridb_nn_kernel.
+//             registers) and reduced in the same launch: grid_pass_kernel.
 #pragma clang fp contract(off)
 
 #include <hip/hip_runtime.h>
@@ -238,22 +241,22 @@ __device__ __forceinline__ void scan_range(const float4* __restrict__ sorted, in
 // row ONE contiguous range of `sorted`.  A row-by-row scan is a chain of ~20 dependent L2 round trips; instead ALL
 // range bounds are issued at once and the points of all rows are then walked as one list.
 //
-// Temporal coherence: the target this source matched in the PREVIOUS iteration (position `pp` in `sorted`, -1 = none)
-// is evaluated first.  Its distance d0 is an upper bound of the answer, so a row / end cell of the block whose
-// distance from the query exceeds d0 cannot hold the winner NOR a tie and is not read at all: with g = the f32 gap
-// to the cell's slab minus eps (eps covers the rounding of the cell assignment and of the gap), every point there
-// has computed d2 >= (1 - 3 ulp) * sum(g^2) > 0.999999 * sum(g^2) > d0.  Near convergence d0 is a fraction of a
-// cell edge and ~4 of the 27 cells remain.  Results do not depend on `pp` (any target is a valid bound).
+// Pruning: the caller passes `rho`, a squared radius that is at least the distance of a target it has already
+// evaluated (key / kpos on entry; +inf with none).  A row / end cell of the block whose distance from the query exceeds
+// rho cannot hold the winner NOR a tie and is not read at all: with g = the f32 gap to the cell's slab minus eps (eps
+// covers the rounding of the cell assignment and of the gap), every point there has computed d2 >= (1 - 3 ulp) *
+// sum(g^2) > 0.999999 * sum(g^2) > rho.  Results do not depend on rho (any such radius is a valid bound).
 //
-// The surviving ranges go into a per-lane queue in LDS (column threadIdx.x: private to the lane, so no barrier)
-// and are walked two ranges at a time, four points of each in flight per step (the vector memory pipe paces the
-// single-pair kernel, the VALU the batched one).  Returns the number of distance evaluations.
+// The surviving ranges go into a per-lane queue in LDS (column threadIdx.x: private to the lane, so no barrier) and are
+// walked as one list, eight points in flight per step.  m2 returns the SECOND smallest computed distance among the
+// (distinct) points walked -- with rho and the block's faces it bounds how far every target other than the winner is
+// (the skip test of grid_pass_kernel).  Returns the number of distance evaluations.
 typedef int32_t int4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at 4-byte alignment (one global_load_dwordx4)
 
-template <bool FMA, int BS>
+template <bool FMA, int BS, int U>
 __device__ __forceinline__ int block_walk(const GridParams& gp, const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
-                                          float qx, float qy, float qz, int cx, int cy, int cz, int pp, const float4 prevp,
-                                          int2 (*rowq)[BS], unsigned long long& key, int& kpos) {
+                                          float qx, float qy, float qz, int cx, int cy, int cz, float rho, unsigned rowmask,
+                                          int2 (*rowq)[BS], unsigned long long& key, int& kpos, float& m1, float& m2) {
     // the four bounds of a row -- starts of cells cx-1, cx, cx+1, cx+2 -- are ONE unaligned 16-byte load (cell_start has a
     // readable element in front of cell 0 and two behind the last start): 9 loads per query instead of 36
     int s0[9], s1[9], s2[9], s3[9];
@@ -261,19 +264,13 @@ __device__ __forceinline__ int block_walk(const GridParams& gp, const int32_t* _
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int z = cz + t / 3 - 1, y = cy + t % 3 - 1;
-        ok[t] = z >= 0 && z < gp.gz && y >= 0 && y < gp.gy;
+        ok[t] = z >= 0 && z < gp.gz && y >= 0 && y < gp.gy && ((rowmask >> t) & 1u) != 0u;   // (rowmask: the rows this lane walks)
         const int row = ok[t] ? (z * gp.gy + y) * gp.gx : 0;
         const int4u v = *(const int4u*)(cell_start + row + cx - 1);
         s0[t] = cx > 0 ? v.x : v.y;               // [s0, s1) = cell cx-1 (empty when it does not exist)
         s1[t] = v.y;                              // [s1, s2) = cell cx
         s2[t] = v.z;                              // [s2, s3) = cell cx+1 (empty when it does not exist)
         s3[t] = cx + 1 < gp.gx ? v.w : v.z;
-    }
-    float d0 = __builtin_inff();
-    if (pp >= 0) {
-        key = point_key<FMA>(prevp, qx, qy, qz);   // prevp == sorted[pp], loaded by the caller ahead of time
-        kpos = pp;
-        d0 = __uint_as_float((unsigned)(key >> 32));
     }
     // squared slack-reduced gaps from the query to the neighbouring slabs (same face expressions as the termination
     // bound of the shell loop); index 1 = the query's own slab
@@ -286,8 +283,8 @@ __device__ __forceinline__ int block_walk(const GridParams& gp, const int32_t* _
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const float g2 = ey2[t % 3] + ez2[t / 3];
-        const bool need = ok[t] && !(d0 < g2 * 0.999999f);
-        const bool left = !(d0 < (g2 + exl2) * 0.999999f), right = !(d0 < (g2 + exr2) * 0.999999f);
+        const bool need = ok[t] && !(rho < g2 * 0.999999f);
+        const bool left = !(rho < (g2 + exl2) * 0.999999f), right = !(rho < (g2 + exr2) * 0.999999f);
         const int lo = left ? s0[t] : s1[t];
         const int hi = right ? s3[t] : s2[t];
         const bool take = need && hi > lo;
@@ -301,7 +298,8 @@ __device__ __forceinline__ int block_walk(const GridParams& gp, const int32_t* _
     // steps: C3 9.5 -> 12.4 ms, C2 search 5.1 -> 5.8 us.)
     int cur = 0, end = 0, nxt = 0;
     if (nrow > 0) { const int2 v = rowq[0][threadIdx.x]; cur = v.x; end = v.y; nxt = 1; }
-    constexpr int U = 8;
+    m1 = __builtin_inff();
+    m2 = __builtin_inff();
     for (int e = 0; e < total; e += U) {
         int at[U];
 #pragma unroll
@@ -317,9 +315,54 @@ __device__ __forceinline__ int block_walk(const GridParams& gp, const int32_t* _
         for (int j = 0; j < U; ++j) {
             const unsigned long long kk = point_key<FMA>(pt[j], qx, qy, qz);
             if (kk < key) { key = kk; kpos = at[j]; }
+            // the two smallest distances over the DISTINCT points of the list (a repeated point counts once: masked)
+            const float dd = e + j < total ? __uint_as_float((unsigned)(kk >> 32)) : __builtin_inff();
+            m2 = __builtin_amdgcn_fmed3f(m1, m2, dd);
+            m1 = fminf(m1, dd);
         }
     }
-    return total + (pp >= 0 ? 1 : 0);
+    return total;
+}
+
+// One ROW of the 3x3x3 block per lane (phase B of grid_pass_kernel when a workgroup has few walkers: 16 lanes share a
+// walker, lanes 0-8 of the group take rows 0-8).  Same pruning rule and the same m1 / m2 bookkeeping as block_walk, but no
+// range queue and -- for the usual row of <= 8 points -- a single step: the serial instruction count of a search, which is
+// what a lone wave pays for, drops to less than half.
+template <bool FMA>
+__device__ __forceinline__ void row_walk(const GridParams& gp, const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
+                                         float qx, float qy, float qz, int cx, int cy, int cz, float rho, int t,
+                                         unsigned long long& key, int& kpos, float& m1, float& m2) {
+    m1 = __builtin_inff();
+    m2 = __builtin_inff();
+    const int tz = t / 3, ty = t - 3 * tz;
+    const int z = cz + tz - 1, y = cy + ty - 1;
+    if (!(t < 9 && z >= 0 && z < gp.gz && y >= 0 && y < gp.gy)) return;
+    const int4u v = *(const int4u*)(cell_start + (z * gp.gy + y) * gp.gx + cx - 1);
+    const int s0 = cx > 0 ? v.x : v.y, s1 = v.y, s2 = v.z, s3 = cx + 1 < gp.gx ? v.w : v.z;
+    const float exl = fmaxf((qx - (gp.ox + (float)cx * gp.h)) - gp.eps, 0.f), exr = fmaxf(((gp.ox + (float)(cx + 1) * gp.h) - qx) - gp.eps, 0.f);
+    const float eyl = fmaxf((qy - (gp.oy + (float)cy * gp.h)) - gp.eps, 0.f), eyr = fmaxf(((gp.oy + (float)(cy + 1) * gp.h) - qy) - gp.eps, 0.f);
+    const float ezl = fmaxf((qz - (gp.oz + (float)cz * gp.h)) - gp.eps, 0.f), ezr = fmaxf(((gp.oz + (float)(cz + 1) * gp.h) - qz) - gp.eps, 0.f);
+    const float ey2 = ty == 0 ? eyl * eyl : ty == 2 ? eyr * eyr : 0.f, ez2 = tz == 0 ? ezl * ezl : tz == 2 ? ezr * ezr : 0.f;
+    const float g2 = ey2 + ez2;
+    if (rho < g2 * 0.999999f) return;
+    const bool left = !(rho < (g2 + exl * exl) * 0.999999f), right = !(rho < (g2 + exr * exr) * 0.999999f);
+    const int lo = left ? s0 : s1, hi = right ? s3 : s2;
+    for (int k = lo; k < hi; k += 8) {
+        int at[8];
+        float4 pt[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) at[j] = min(k + j, hi - 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pt[j] = sorted[at[j]];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned long long kk = point_key<FMA>(pt[j], qx, qy, qz);
+            if (kk < key) { key = kk; kpos = at[j]; }
+            const float dd = k + j < hi ? __uint_as_float((unsigned)(kk >> 32)) : __builtin_inff();
+            m2 = __builtin_amdgcn_fmed3f(m1, m2, dd);
+            m1 = fminf(m1, dd);
+        }
+    }
 }
 
 // ---- spatial order for the SOURCES: same cell order as the target, original index in .w ------------------
@@ -330,10 +373,9 @@ __device__ __forceinline__ int block_walk(const GridParams& gp, const int32_t* _
 // same few cells (L1 / L2 hits instead of Infinity-Cache trips) for all iterations.
 __global__ __launch_bounds__(256) void grid_rank_fix_kernel(const float4* __restrict__ tmp, int n, GridParams gp,
                                                             const int32_t* __restrict__ start /* the source half: start[c] - shift */, int shift,
-                                                            float4* __restrict__ out, int32_t* __restrict__ pos_init) {
+                                                            float4* __restrict__ out) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    if (pos_init) pos_init[j] = -1;   // no previous winner yet (saves a memset per registration)
     const float4 p = tmp[j];
     const int cx = cell_coord(p.x, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(p.y, gp.oy, gp.inv_h, gp.gy),
               cz = cell_coord(p.z, gp.oz, gp.inv_h, gp.gz);
@@ -349,7 +391,7 @@ __global__ __launch_bounds__(256) void grid_rank_fix_kernel(const float4* __rest
 // be 10).  d_counts: 2 * ncells zeroed ints (zero at rest: left zeroed again); d_start: 2 * ncells + 1 ints, target starts
 // in [0, ncells], source starts + nt behind; d_src is read and, after the rank fix, rewritten in cell order (d_tmp: scratch).
 void launch_grid_build_pair(hipStream_t st, const float4* d_tgt, int nt, float4* d_src, int ns, const GridParams& gp, int32_t* d_counts,
-                            int32_t* d_start, int32_t* d_block_sums, float4* d_sorted, float4* d_tmp, int32_t* d_pos_init) {
+                            int32_t* d_start, int32_t* d_block_sums, float4* d_sorted, float4* d_tmp) {
     const int ncells = gp.gx * gp.gy * gp.gz;
     const int nbt = (nt + 255) / 256, nbs = (ns + 255) / 256;
     hipLaunchKernelGGL(grid_count2_kernel, dim3(nbt + nbs), dim3(256), 0, st, d_tgt, nt, nbt, (const float4*)d_src, ns, gp, d_counts);
@@ -357,7 +399,7 @@ void launch_grid_build_pair(hipStream_t st, const float4* d_tgt, int nt, float4*
     hipLaunchKernelGGL(grid_scatter2_kernel, dim3(nbt + nbs), dim3(256), 0, st, d_tgt, nt, nbt, (const float4*)d_src, ns, gp, d_counts,
                        (const int32_t*)d_start, d_sorted, d_tmp);
     hipLaunchKernelGGL(grid_rank_fix_kernel, dim3(nbs), dim3(256), 0, st, (const float4*)d_tmp, ns, gp, (const int32_t*)d_start + ncells, nt,
-                       d_src, d_pos_init);
+                       d_src);
 }
 
 // =============================================================================================
@@ -365,11 +407,14 @@ void launch_grid_build_pair(hipStream_t st, const float4* d_tgt, int nt, float4*
 //   - one workgroup = one CHUNK of 512 consecutive cell-sorted sources of one pair, one lane per source; workgroups
 //     are laid out pair by pair and handed to XCDs in contiguous runs (blockIdx % 8 remap), so the workgroups of a
 //     pair -- and with them that pair's cell list -- stay in one XCD's L2;
-//   - search: previous winner first (its distance bounds the answer), the 3x3x3 block pruned by that bound
-//     (block_walk), further shells up to GridParams::rcap, then the fallback: BATCH -> the wave sweeps the pair's
-//     targets by brute force for its unresolved lanes (uniform addresses, no LDS, no barrier); single pair -> the
-//     source goes to a device list that nn_sweep_kernel<LIST> resolves, after which a SEARCH = false launch of this
-//     kernel (same rows, same order) redoes the sums from the stored winners;
+//   - search in three phases.  A: every lane moves its source and tries to keep its last winner (the skip test above);
+//     the lanes that must search ("walkers", a few per cent near convergence) queue up in LDS.  B: the first lanes of
+//     the workgroup serve the walkers, 16 / 8 / 4 lanes per walker when there are few (one row or a few rows of the
+//     3x3x3 block each, merged by DPP), one lane each otherwise: last winner first, the block pruned by its distance
+//     (block_walk / row_walk), further shells up to GridParams::rcap, then the fallback -- BATCH: the wave sweeps the
+//     pair's targets by brute force for its unresolved lanes (uniform addresses, no barrier); single pair: the source
+//     goes to a device list that nn_sweep_kernel<LIST> resolves, after which a SEARCH = false launch of this kernel
+//     (same rows, same order) redoes the sums from the stored winners.  C: every lane picks its answer up from LDS;
 //   - sums: every lane contributes its correspondence to 16 f64 columns (+ 2 in FULL mode: sum of all d2 and of
 //     sqrt(d2) for getFitnessScore / PCR_QM; counts are ballots), reduced in the canonical order of kss_device.hpp:
 //     in-wave tree by permlane swaps + DPP (no LDS, no barrier), 8 wave totals through LDS, one row per workgroup;
@@ -380,10 +425,14 @@ void launch_grid_build_pair(hipStream_t st, const float4* d_tgt, int nt, float4*
 //   - a pair of a single chunk skips the hand-over (0.0 + row: the same bits as the general path).
 // The result of a pair is a function of its own clouds only: alone or in a batch of any size, bit for bit.
 // =============================================================================================
+#ifndef KSS_BATCH_WAVES
+#define KSS_BATCH_WAVES 6   // waves per SIMD the batched variant is compiled for (3 workgroups per CU; 8 spills)
+#endif
 template <bool FMA, bool FULL, bool BATCH, bool SEARCH>
-__global__ __launch_bounds__(PASS_BS) void grid_pass_kernel(const PassArgs a) {
-    // diagnostic stamps (100 MHz s_memrealtime): [block*16 + {0 start, 1 searched, 2 row ready, 3 ticketed, 4 result stored
-    // (last workgroup)}], 10 = distance evaluations of the r = 1 block (a count)
+__global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pass_kernel(const PassArgs a) {
+    // diagnostic stamps (100 MHz s_memrealtime): [block*16 + {0 start, 13 first loads in, 9 gate open, 14 phase A done,
+    // 5 phase B entered, 8 answered, 15 phase B done, 1 searched, 2 row ready, 3 ticketed, 4 result stored (last
+    // workgroup)}]; counts: 10 = distance evaluations of the r = 1 block, 11 = evaluation slots, 12 = walkers
 #define KSS_STAMP(k) do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     KSS_STAMP(0);
     constexpr int BS = PASS_BS;
@@ -401,30 +450,45 @@ __global__ __launch_bounds__(PASS_BS) void grid_pass_kernel(const PassArgs a) {
     const GridParams& gp = pr.gp;
     const int32_t* __restrict__ cs = a.cell_start + pr.cell_base;
     const float4* __restrict__ sorted = a.sorted;
-    __shared__ int2 rowq[9][BS];           // block_walk's per-lane queue of point ranges
+    constexpr int WQ = 256;                // lanes that search in phase B
+    __shared__ int2 rowq[9][WQ];           // block_walk's per-lane queue of point ranges
     __shared__ double shw[BS / 64][NSUMS];
     __shared__ int s_last;
     __shared__ int sh_ps[16];
+    __shared__ int s_nwalk;
+    // per-lane hand-over columns.  A walker leaves its request {query, key and position of the last winner, pruning radius}
+    // in its own column and its lane number in s_wl; the lanes of phase B overwrite the column with the answer {winner, key,
+    // flags}.  A lane that keeps its winner writes the answer itself.  (Through LDS rather than registers: nothing but the
+    // lane's identity stays live across the search, which is what lets four workgroups share a CU.)
+    __shared__ unsigned s_ent[8][BS];
+    __shared__ unsigned short s_wl[BS];
+    enum { WK_X, WK_Y, WK_Z, WK_IDX, WK_D2, WK_POS, WK_R, WK_FL };
     static_assert(sizeof(PairState) == 64, "the gated launch reads the transform record as 16 dwords");
     double (*shf)[NSUMS] = reinterpret_cast<double (*)[NSUMS]>(&rowq[0][0]);   // the last workgroup's group totals: rowq is dead by then (two barriers later)
-    static_assert(sizeof(double) * PASS_FG * NSUMS <= sizeof(int2) * 9 * BS, "shf must fit inside rowq");
+    static_assert(sizeof(double) * PASS_FG * NSUMS <= sizeof(int2) * 9 * WQ, "shf must fit inside rowq");
 
     const int local = (w - pr.row_base) * BS + (int)threadIdx.x;
     const bool valid = local < pr.src_n;
     const int i = pr.src_base + local;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // this lane's correspondence
     bool have = false, fell_back = false;
-    int ev_lane = 0;                       // diagnostic runs: distance evaluations of the r = 1 block
     float qx = 0.f, qy = 0.f, qz = 0.f, d2 = 0.f;
     float4 win = make_float4(0.f, 0.f, 0.f, 0.f);
-    // what does not depend on the transform is fetched first: the source, where its last winner sits, and that point
-    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), prevp = p;
-    int pp = -1;
+    // what does not depend on the transform is fetched first: the source, where its last winner sits, that point, and the
+    // skip state {B, acc} (see below)
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), prevp = make_float4(0.f, 0.f, 0.f, __uint_as_float(~0u));
+    float2 st = make_float2(0.f, 0.f);
     if (valid) {
         p = SEARCH ? a.src_in[i] : a.src_out[i];
-        pp = a.pos_prev[i];
-        if (SEARCH && a.use_prev && pp >= 0) prevp = sorted[pp];
+        // (one round trip: nothing here depends on another load.  The sums-only pass always follows a search pass that has
+        // just written every source's winner.)
+        if (!SEARCH || a.use_prev) { prevp = a.nn_win[i]; st = a.nn_state[i]; }
     }
+    const bool has_prev = __float_as_uint(prevp.w) != ~0u;   // prevp = the last winner's coordinates, .w = its index in the pair's target
+    if (SEARCH && threadIdx.x == 0) s_nwalk = 0;
+    if constexpr (SEARCH) __syncthreads();
+    KSS_STAMP(13);
     if constexpr (!BATCH && SEARCH) {
         if (a.gate_seq != 0) {
             // GATED launch (kss_engine.hip): this kernel was enqueued while the previous iteration was still running, before
@@ -483,8 +547,21 @@ __global__ __launch_bounds__(PASS_BS) void grid_pass_kernel(const PassArgs a) {
             for (int k = 0; k < 16; ++k) d32[k] = sh_ps[k];
             if (ps.pad[0] != 0) return;
             __syncthreads();               // s_last is reused by the ticket below
+            KSS_STAMP(9);
         }
     }
+    // ---- the search ------------------------------------------------------------------------------------------
+    // Phase A, every lane: move the source, then try to KEEP last pass's winner w without searching.  Per source the
+    // kernel carries {B, acc}: at the position q_ref where the source was last searched, every target other than w was at
+    // true distance >= B; acc bounds how far the source has moved since (sum of the per-pass displacements, rounded up).
+    // By the triangle inequality every other target is now at true distance >= B - acc, so its COMPUTED squared distance
+    // (5 roundings: relative error < 6 * 2^-24) exceeds (B - acc)^2 * 0.99999.  If the winner's computed distance is
+    // below that, w wins again, strictly -- no tie to break -- and the lane is done: exactly the key a search would
+    // return.  (1e-10: below it, float underflow in the displacement could matter; such a lane searches.)
+    // Lanes that cannot skip ("walkers") are compacted into the first waves of the workgroup (phase B): near convergence
+    // ~8 % of the sources walk, so ONE wave per workgroup pays for the walk instead of eight (the pass is VALU-bound).
+    unsigned long long key = ~0ull;
+    const float pold_x = p.x, pold_y = p.y, pold_z = p.z;   // where the source was in the last pass
     if (valid) {
         if constexpr (SEARCH) {
             if (ps.apply) {   // pcl transformCloud with the previous iteration's Matrix4f, Eigen order, float, no fma
@@ -496,17 +573,132 @@ __global__ __launch_bounds__(PASS_BS) void grid_pass_kernel(const PassArgs a) {
             a.src_out[i] = p;
         }
         qx = p.x; qy = p.y; qz = p.z;
-        unsigned long long key = ~0ull;
-        int kpos = -1;
         // a non-finite query matches nothing (its distances are NaN; as an integer key NaN bits would beat every real one)
         const bool qok = (qx - qx) == 0.f && (qy - qy) == 0.f && (qz - qz) == 0.f;
-        if constexpr (SEARCH) {
-            bool done = !qok;
+        if constexpr (!SEARCH) {
+            // sums only: the winner is where the search left it, or what the list pass found
+            if (has_prev) {
+                win = prevp;
+                key = point_key<FMA>(win, qx, qy, qz);
+            } else if (qok) {
+                key = a.keys[i];
+                if (key != ~0ull) win = a.tgt4[pr.tgt_base + (int)(unsigned)(key & 0xffffffffull)];
+            }
+            have = key != ~0ull;
+        }
+    }
+    if constexpr (SEARCH) {
+        bool walker = false;
+        {
+            const bool qok = valid && (qx - qx) == 0.f && (qy - qy) == 0.f && (qz - qz) == 0.f;
+            int kpos = -1;
+            float rho = __builtin_inff();
+            unsigned fl = 0u;
             if (qok) {
-                const int cx = cell_coord(qx, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(qy, gp.oy, gp.inv_h, gp.gy),
-                          cz = cell_coord(qz, gp.oz, gp.inv_h, gp.gz);
-                // ---- r = 1: the 3x3x3 block, pruned by the previous winner's distance ----
-                ev_lane = block_walk<FMA, BS>(gp, cs, sorted, qx, qy, qz, cx, cy, cz, a.use_prev ? pp : -1, prevp, rowq, key, kpos);
+                walker = true;
+                if (has_prev) {
+                    key = point_key<FMA>(prevp, qx, qy, qz);
+                    kpos = -2;                     // "the last winner, whose coordinates are in nn_win"
+                    const float d0 = __uint_as_float((unsigned)(key >> 32));
+                    const float mx = qx - pold_x, my = qy - pold_y, mz = qz - pold_z;
+                    const float moved = __builtin_amdgcn_sqrtf((mx * mx + my * my) + mz * mz);
+                    const float acc = (st.y + moved) * 1.00001f;
+                    const float room = st.x - acc;
+                    if (a.chained && a.skin >= 0.f && room > 1e-10f && (room * room) * 0.99999f > d0) {
+                        walker = false;            // w again
+                        fl = 1u;
+                        a.nn_state[i] = make_float2(st.x, acc);
+                    } else {
+                        // the walk prunes with the winner's distance grown by a skin (a fraction of the cell edge): what it
+                        // then proves about the other targets leaves room for the next passes.  A source that is still
+                        // moving by more than a quarter of the skin per pass would not profit: plain radius.
+                        const float skin = fmaxf(a.skin, 0.f) * gp.h, grown = __builtin_amdgcn_sqrtf(d0) + skin;
+                        rho = !a.chained || moved * 4.f <= skin ? fmaxf(d0, grown * grown) : d0;
+                    }
+                }
+            } else if (valid) {
+                a.nn_win[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(~0u));
+                a.nn_state[i] = make_float2(0.f, 0.f);
+            }
+            // the lane's column: a walker's request, or the answer of a lane that needs no search
+            const float4 c4 = walker ? make_float4(qx, qy, qz, 0.f) : prevp;
+            s_ent[WK_X][threadIdx.x] = __float_as_uint(c4.x); s_ent[WK_Y][threadIdx.x] = __float_as_uint(c4.y); s_ent[WK_Z][threadIdx.x] = __float_as_uint(c4.z);
+            s_ent[WK_IDX][threadIdx.x] = (unsigned)key; s_ent[WK_D2][threadIdx.x] = (unsigned)(key >> 32);
+            s_ent[WK_POS][threadIdx.x] = (unsigned)kpos;
+            s_ent[WK_R][threadIdx.x] = __float_as_uint(rho);
+            s_ent[WK_FL][threadIdx.x] = fl;
+        }
+        // compaction: walkers take consecutive slots (wave by wave in arrival order, lane order inside a wave)
+        const unsigned long long wm = __builtin_amdgcn_ballot_w64(walker);
+        if (wm != 0ull) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_nwalk, (int)__builtin_popcountll(wm));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (walker) s_wl[base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(wm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)wm, 0u))] = (unsigned short)threadIdx.x;
+        }
+        KSS_STAMP(14);
+        __syncthreads();
+        const int nwalk = s_nwalk;
+        if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + 12] = (unsigned long long)nwalk;
+        // Phase B: the first WQ lanes of the workgroup search for the walkers, WQ / L of them per round.  With few walkers
+        // L = 8 or 4 lanes share one: each walks its own rows of the 3x3x3 block (disjoint, so "distinct points" still
+        // holds) and the group merges key / position / the two smallest distances by DPP -- the dependent chain of a
+        // search drops from ~4 walk steps to ~1, on lanes the compaction has left idle anyway.
+        const bool row16 = !BATCH && 16 * nwalk <= BS;   // single pair, few walkers: one row per lane (row_walk)
+        const int L = row16 ? 16 : 8 * nwalk <= WQ ? 8 : 4 * nwalk <= WQ ? 4 : 1;
+        const int nserve = row16 ? BS : WQ;              // lanes that search (block_walk's range queue has WQ columns)
+        for (int rb = 0; rb < nwalk; rb += nserve / L)
+        if ((int)threadIdx.x < nserve && (int)(threadIdx.x & ~63u) < (nwalk - rb) * L) {   // wave-uniform
+            const int sub = (int)threadIdx.x & (L - 1);
+            const int wj = rb + (L == 16 ? (int)threadIdx.x >> 4 : L == 8 ? (int)threadIdx.x >> 3 : L == 4 ? (int)threadIdx.x >> 2 : (int)threadIdx.x);
+            const bool wk = wj < nwalk;
+            // rows by lane of a group of 8: row `sub`, lane 0 also row 8; of a quad: {0, 2, 8}, {4, 6}, {1, 7}, {3, 5} (the
+            // corner rows 0, 2, 6, 8 are the ones most often pruned)
+            const unsigned rowmask = L == 1 ? 0x1ffu : L == 8 ? (1u << sub) | (sub == 0 ? 0x100u : 0u)
+                                                     : sub == 0 ? 0x105u : sub == 1 ? 0x050u : sub == 2 ? 0x082u : 0x028u;
+            float wx = 0.f, wy = 0.f, wz = 0.f, wrho = __builtin_inff(), bnew = 0.f;
+            unsigned long long wkey = ~0ull;
+            int wpos = -1, owner = 0, evl = 0, rfin = 0;   // rfin: the shell the search ended with (0: it did not)
+            bool done = true, wfell = false;
+            if (wk) {
+                owner = (int)s_wl[wj];
+                wx = __uint_as_float(s_ent[WK_X][owner]); wy = __uint_as_float(s_ent[WK_Y][owner]); wz = __uint_as_float(s_ent[WK_Z][owner]);
+                wkey = ((unsigned long long)s_ent[WK_D2][owner] << 32) | (unsigned long long)s_ent[WK_IDX][owner];
+                wpos = (int)s_ent[WK_POS][owner];
+                wrho = __uint_as_float(s_ent[WK_R][owner]);
+                done = false;
+            }
+            if (wk) {
+                const int cx = cell_coord(wx, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(wy, gp.oy, gp.inv_h, gp.gy),
+                          cz = cell_coord(wz, gp.oz, gp.inv_h, gp.gz);
+                // ---- r = 1: the 3x3x3 block, pruned by rho ----
+                KSS_STAMP(5);
+                float m1, m2;
+                if (row16) row_walk<FMA>(gp, cs, sorted, wx, wy, wz, cx, cy, cz, wrho, sub, wkey, wpos, m1, m2);
+                else evl = block_walk<FMA, WQ, BATCH ? 4 : 8>(gp, cs, sorted, wx, wy, wz, cx, cy, cz, wrho, rowmask, rowq, wkey, wpos, m1, m2);
+                if (L > 1) {   // (uniform) all lanes of a group are walkers of the same source: merge by DPP
+#define KSS_GROUP_MERGE(X)                                                                                                          \
+    do {                                                                                                                            \
+        const unsigned olo = (unsigned)X((int)(unsigned)wkey), ohi = (unsigned)X((int)(unsigned)(wkey >> 32));                      \
+        const int opos = X(wpos);                                                                                                   \
+        const float o1 = __int_as_float(X(__float_as_int(m1))), o2 = __int_as_float(X(__float_as_int(m2)));                         \
+        const unsigned long long okey = ((unsigned long long)ohi << 32) | olo;                                                      \
+        if (okey < wkey) { wkey = okey; wpos = opos; }                                                                            \
+        m2 = fminf(fmaxf(m1, o1), fminf(m2, o2)); /* two smallest of the union of two sorted pairs */                               \
+        m1 = fminf(m1, o1);                                                                                                         \
+    } while (0)
+                    auto x1 = [](int v) { return __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, false); };   // quad_perm [1,0,3,2]
+                    auto x2 = [](int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4e, 0xf, 0xf, false); };   // quad_perm [2,3,0,1]
+                    // lane ^ 4: row_shl:4 into the lanes with bit 2 clear, row_shr:4 into the others; lane ^ 8: row_ror:8
+                    auto x4 = [](int v) { const int r = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xf, 0x5, false); return __builtin_amdgcn_update_dpp(r, v, 0x114, 0xf, 0xa, false); };
+                    auto x8 = [](int v) { return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false); };
+                    KSS_GROUP_MERGE(x1);
+                    KSS_GROUP_MERGE(x2);
+                    if (L >= 8) KSS_GROUP_MERGE(x4);
+                    if (L == 16) KSS_GROUP_MERGE(x8);
+#undef KSS_GROUP_MERGE
+                }
+                float face2 = __builtin_inff();    // squared distance to the faces of the block the search ended with
                 for (int r = 1; r <= gp.rcap; ++r) {
                     if (r > 1) {   // shell r: (2r+1)^2 rows
                         const int wd = 2 * r + 1;
@@ -518,28 +710,32 @@ __global__ __launch_bounds__(PASS_BS) void grid_pass_kernel(const PassArgs a) {
                             const int row = (z * gp.gy + y) * gp.gx;
                             if (dz == -r || dz == r || dy == -r || dy == r) {
                                 // a row on the shell's y/z faces: the whole x extent is new
-                                scan_range<FMA>(sorted, cs[row + x0], cs[row + x1 + 1], qx, qy, qz, key, kpos);
+                                scan_range<FMA>(sorted, cs[row + x0], cs[row + x1 + 1], wx, wy, wz, wkey, wpos);
                             } else {
                                 // interior row of shell r: only its two x end cells are new
-                                if (cx - r >= 0) scan_range<FMA>(sorted, cs[row + cx - r], cs[row + cx - r + 1], qx, qy, qz, key, kpos);
-                                if (cx + r < gp.gx) scan_range<FMA>(sorted, cs[row + cx + r], cs[row + cx + r + 1], qx, qy, qz, key, kpos);
+                                if (cx - r >= 0) scan_range<FMA>(sorted, cs[row + cx - r], cs[row + cx - r + 1], wx, wy, wz, wkey, wpos);
+                                if (cx + r < gp.gx) scan_range<FMA>(sorted, cs[row + cx + r], cs[row + cx + r + 1], wx, wy, wz, wkey, wpos);
                             }
                         }
                     }
-                    const float best = __uint_as_float((unsigned)(key >> 32));
+                    const float best = __uint_as_float((unsigned)(wkey >> 32));
                     // distance from the query to the faces of the visited block; faces on the grid border are open
                     float b = __builtin_inff();
-                    if (cx - r > 0) b = fminf(b, qx - (gp.ox + (float)(cx - r) * gp.h));
-                    if (cx + r < gp.gx - 1) b = fminf(b, (gp.ox + (float)(cx + r + 1) * gp.h) - qx);
-                    if (cy - r > 0) b = fminf(b, qy - (gp.oy + (float)(cy - r) * gp.h));
-                    if (cy + r < gp.gy - 1) b = fminf(b, (gp.oy + (float)(cy + r + 1) * gp.h) - qy);
-                    if (cz - r > 0) b = fminf(b, qz - (gp.oz + (float)(cz - r) * gp.h));
-                    if (cz + r < gp.gz - 1) b = fminf(b, (gp.oz + (float)(cz + r + 1) * gp.h) - qz);
+                    if (cx - r > 0) b = fminf(b, wx - (gp.ox + (float)(cx - r) * gp.h));
+                    if (cx + r < gp.gx - 1) b = fminf(b, (gp.ox + (float)(cx + r + 1) * gp.h) - wx);
+                    if (cy - r > 0) b = fminf(b, wy - (gp.oy + (float)(cy - r) * gp.h));
+                    if (cy + r < gp.gy - 1) b = fminf(b, (gp.oy + (float)(cy + r + 1) * gp.h) - wy);
+                    if (cz - r > 0) b = fminf(b, wz - (gp.oz + (float)(cz - r) * gp.h));
+                    if (cz + r < gp.gz - 1) b = fminf(b, (gp.oz + (float)(cz + r + 1) * gp.h) - wz);
                     const float bs = b - gp.eps;
                     if (b == __builtin_inff()) done = true;                              // the whole grid has been visited
-                    else if (bs > 0.f && best < bs * bs * 0.999999f) done = true;        // every unvisited point is strictly farther
-                    if (done) break;
+                    else if (bs > 0.f && best < bs * bs * 0.999999f) { done = true; face2 = bs * bs; }   // every unvisited point is strictly farther
+                    if (done) { rfin = r; break; }
                 }
+                // What the r = 1 walk has proven about every target but the winner: walked ones are at computed distance >= m2,
+                // pruned ones beyond rho, unvisited ones beyond the block's faces.  (Shells r > 1 are not tracked: B = 0.)
+                if (done && rfin == 1 && wkey != ~0ull)
+                    bnew = fminf(__builtin_amdgcn_sqrtf(fminf(fminf(m2, wrho), face2) * 0.99999f) * 0.999999f, 1e30f);
             }
             if constexpr (BATCH) {
                 // bounded fallback: brute force over the pair's targets for the lanes the shells did not resolve
@@ -547,55 +743,71 @@ __global__ __launch_bounds__(PASS_BS) void grid_pass_kernel(const PassArgs a) {
                     const float4* __restrict__ tp = a.tgt4 + pr.tgt_base;      // original order; uniform addresses below
                     for (int j = 0; j < pr.tgt_n; ++j) {
                         const float4 q = tp[j];
-                        const float dx = qx - q.x, dy = qy - q.y, dz = qz - q.z;
+                        const float dx = wx - q.x, dy = wy - q.y, dz = wz - q.z;
                         float d;
                         if constexpr (FMA) d = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
                         else d = (dx * dx + dy * dy) + dz * dz;
                         const unsigned long long kk = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(unsigned)j;
-                        if (!done && kk < key) { key = kk; kpos = -1; }   // (no position in `sorted` known: no warm start next time)
+                        if (!done && kk < wkey) { wkey = kk; wpos = -1; }   // (no position in `sorted` known: no warm start next time)
                     }
-                    fell_back = !done;
+                    wfell = !done;
                     done = true;
                 }
             }
-            if (done) {
-                have = key != ~0ull;
-                a.pos_prev[i] = kpos;
-                // the winner's coordinates: one load of a line the search has just touched (or, after the in-wave sweep, of the
-                // pair's target in original order)
-                if (have) win = kpos >= 0 ? sorted[kpos] : a.tgt4[pr.tgt_base + (int)(unsigned)(key & 0xffffffffull)];
-            } else {   // single pair: resolved by the brute-force list pass through atomicMin, sums by the SEARCH = false launch
-                a.keys[i] = ~0ull;
-                a.pos_prev[i] = -1;
-                const int slot = atomicAdd(a.list_count, 1);
-                a.list[slot] = i;
-                fell_back = true;   // counted in column 19 of the row, as the batch counts its in-wave fallbacks
+            if (wk && sub == 0) {              // (the lanes of a group agree on everything from the merge on)
+                bool whave = false;
+                float4 ww = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int io = pr.src_base + (w - pr.row_base) * BS + owner;
+                if (done) {
+                    whave = wkey != ~0ull;
+                    // the winner's coordinates: carried through the r = 1 walk (the shells beyond do not carry them: read back; after
+                    // the in-wave sweep: read from the pair's target in original order)
+                    if (whave) ww = wpos >= 0 ? sorted[wpos] : wpos == -2 ? a.nn_win[io] : a.tgt4[pr.tgt_base + (int)(unsigned)(wkey & 0xffffffffull)];
+                } else {   // single pair: resolved by the brute-force list pass through atomicMin, sums by the SEARCH = false launch
+                    a.keys[io] = ~0ull;
+                    const int ls = atomicAdd(a.list_count, 1);
+                    a.list[ls] = io;
+                    wfell = true;   // counted in column 19 of the row, as the batch counts its in-wave fallbacks
+                }
+                a.nn_win[io] = make_float4(ww.x, ww.y, ww.z, __uint_as_float(whave ? (unsigned)wkey : ~0u));
+                a.nn_state[io] = make_float2(wfell ? 0.f : bnew, 0.f);
+                s_ent[WK_X][owner] = __float_as_uint(ww.x); s_ent[WK_Y][owner] = __float_as_uint(ww.y); s_ent[WK_Z][owner] = __float_as_uint(ww.z);
+                s_ent[WK_IDX][owner] = (unsigned)wkey; s_ent[WK_D2][owner] = (unsigned)(wkey >> 32);
+                s_ent[WK_FL][owner] = (whave ? 1u : 0u) | (wfell ? 2u : 0u);
             }
-        } else {
-            // sums only: the winner is where the search left it, or what the list pass found
-            if (pp >= 0) {
-                win = sorted[pp];
-                key = point_key<FMA>(win, qx, qy, qz);
-            } else if (qok) {
-                key = a.keys[i];
-                if (key != ~0ull) win = a.tgt4[pr.tgt_base + (int)(unsigned)(key & 0xffffffffull)];
+            KSS_STAMP(8);
+            if (a.stamps) {   // slot 10: evaluations, 11: evaluation slots issued (slowest lane, rounded up to 8, x 64)
+                int evs = evl, mx = evl;
+#pragma unroll
+                for (int m = 32; m > 0; m >>= 1) { evs += __shfl_xor(evs, m, 64); mx = max(mx, __shfl_xor(mx, m, 64)); }
+                if (lane == 0) {
+                    atomicAdd(&a.stamps[(size_t)blockIdx.x * 16 + 10], (unsigned long long)evs);
+                    atomicAdd(&a.stamps[(size_t)blockIdx.x * 16 + 11], (unsigned long long)(((mx + 7) / 8) * 8 * 64));
+                }
             }
-            have = key != ~0ull;
         }
-        if (have) {
-            d2 = __uint_as_float((unsigned)(key >> 32));
-            const int oi = __float_as_int(p.w);   // original source index (sources are in cell order)
-            if (a.idx_out) a.idx_out[oi] = (int)(unsigned)(key & 0xffffffffull);
-            if (a.d2_out) a.d2_out[oi] = d2;
+        KSS_STAMP(15);
+        __syncthreads();
+        // Phase C: every lane reads its column
+        {
+            const unsigned fl = s_ent[WK_FL][threadIdx.x];
+            have = (fl & 1u) != 0u; fell_back = (fl & 2u) != 0u;
+            win = make_float4(__uint_as_float(s_ent[WK_X][threadIdx.x]), __uint_as_float(s_ent[WK_Y][threadIdx.x]), __uint_as_float(s_ent[WK_Z][threadIdx.x]), 0.f);
+            key = ((unsigned long long)s_ent[WK_D2][threadIdx.x] << 32) | (unsigned long long)s_ent[WK_IDX][threadIdx.x];
         }
+        if constexpr (BATCH) {   // (the query comes back from memory rather than staying in registers across the search)
+            p = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid) p = a.src_out[i];
+            qx = p.x; qy = p.y; qz = p.z;
+        }
+    }
+    if (valid && have) {
+        d2 = __uint_as_float((unsigned)(key >> 32));
+        const int oi = __float_as_int(p.w);   // original source index (sources are in cell order)
+        if (a.idx_out) a.idx_out[oi] = (int)(unsigned)(key & 0xffffffffull);
+        if (a.d2_out) a.d2_out[oi] = d2;
     }
     KSS_STAMP(1);
-    if (a.stamps) {   // evaluations summed per workgroup into slot 10
-        int evs = ev_lane;
-#pragma unroll
-        for (int m = 32; m > 0; m >>= 1) evs += __shfl_xor(evs, m, 64);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&a.stamps[(size_t)blockIdx.x * 16 + 10], (unsigned long long)evs);
-    }
 
     // ---- the row of this chunk, canonical order (kss_device.hpp) ----
     const double d2d = have ? (double)d2 : 0.0;
@@ -611,7 +823,6 @@ __global__ __launch_bounds__(PASS_BS) void grid_pass_kernel(const PassArgs a) {
         col[15] = kept ? d2d : 0.0;
     }
     wave_tree16(col);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long mk = __builtin_amdgcn_ballot_w64(kept), mf = __builtin_amdgcn_ballot_w64(fell_back);
     double extra = 0.0;
     if constexpr (FULL) extra = wave_tree2(d2d, have ? sqrt(d2d) : 0.0);   // lane 0: sum of all d2, lane 32: sum of sqrt(d2)

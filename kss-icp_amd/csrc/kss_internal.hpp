@@ -88,7 +88,10 @@ struct PassArgs {
     const int32_t* cell_start;                  // exclusive prefix of the cell counts; [-1] and [cells + 1] are readable
     const float4* sorted;                       // targets in cell order, .w = index within the pair's target
     const float4* tgt4;                         // targets in original order (fallback sweep, SEARCH = false gathers)
-    int32_t* pos_prev;                          // per source: position of its last winner in `sorted`, -1 = none
+    float4* nn_win;                             // per source: its last winner {x, y, z, index in the pair's target}; .w = ~0: none
+    float2* nn_state;                           // per source: {B, acc} of the skip test (grid_pass_kernel, phase A)
+    int32_t chained;                            // src_in is what the previous search pass wrote (its queries): displacements are measurable
+    float skin;                                 // pruning radius grows by skin * cell edge; < 0: never skip (A/B switch)
     unsigned long long* keys;                   // single pair: key of the sources left to the list pass
     int32_t* list; int32_t* list_count;         // single pair: those sources
     const GridPairDev* pairs;                   // BATCH: per-pair table
@@ -168,7 +171,7 @@ void launch_nn_sweep_list(hipStream_t st, int S, bool fma, const NNWork* d_work,
                           unsigned long long* d_keys, const int32_t* d_list, const int32_t* d_count);
 // both cell lists of a single pair (count -> scan -> scatter -> rank fix, shared launches)
 void launch_grid_build_pair(hipStream_t st, const float4* d_tgt, int nt, float4* d_src, int ns, const GridParams& gp, int32_t* d_counts,
-                            int32_t* d_start, int32_t* d_block_sums, float4* d_sorted, float4* d_tmp, int32_t* d_pos_init);
+                            int32_t* d_start, int32_t* d_block_sums, float4* d_sorted, float4* d_tmp);
 size_t scan_scratch_bytes(int n);   // scratch of the cell-count scan over n cells
 int grid_pass_blocks(int total_rows);
 void launch_grid_pass(hipStream_t st, bool fma, bool full, bool batch, bool search, const PassArgs& a);
