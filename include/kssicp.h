@@ -66,7 +66,10 @@ int   kss_ctx_set_nn_mode(kss_ctx *ctx, int nn_mode);
  * n > 1 = every n-th launch of each class (an event pair costs a few microseconds, comparable to the fused
  * cell-list launch it brackets); kss_profile_get reports the sampled launches only. */
 enum { KSS_K_NN_SWEEP = 0, KSS_K_CORR_REDUCE = 1, KSS_K_PRESHAPE = 2, KSS_K_ROT_SEARCH = 3,
-       KSS_K_POSE_APPLY = 4, KSS_K_GRID_NN = 5, KSS_K_GRID_BUILD = 6, KSS_K_COUNT = 7 };
+       KSS_K_POSE_APPLY = 4, KSS_K_GRID_NN = 5, KSS_K_GRID_BUILD = 6,
+       KSS_K_GRID_CHAIN = 7,        /* chained launches of the fused pass: one entry per launch (its whole duration) */
+       KSS_K_GRID_CHAIN_PASS = 8,   /* the same time, counted per ICP pass the launches ran */
+       KSS_K_COUNT = 9 };
 int kss_profile_enable(kss_ctx *ctx, int on);
 /* geometry of the last cell list built on this context (KSS_NN_GRID) and, when profiling is enabled, the
  * number of (source, target) distance evaluations of one search pass at the sources' initial positions:

@@ -64,7 +64,10 @@ struct kss_ctx {
     struct Gated {
         int supported = -1;                 // -1 unknown, 0 no, 1 yes
         bool want_next = false;             // set by the ICP loop: another regular iteration may follow this pass
-        bool pending = false;
+        bool pending = false;               // a pre-enqueued launch is waiting at its gate ...
+        bool chain = false;                 // ... it is a chained launch (more than one pass) ...
+        int steps_left = 0;                 // ... with this many passes still to be released (a chained launch runs several)
+        int max_steps = 1;                  // set by the ICP loop: regular iterations that may still follow this pass
         int slot = 0;
         unsigned long long seq = 0;
         int32_t stamp = 0;
@@ -153,8 +156,9 @@ static inline int ensure_pinned(kss_ctx* c, void*& p, size_t& cap, size_t bytes)
 
 struct ProfScope {   // records a start/stop event pair around a launch when profiling is on
     kss_ctx* c; int k; kss_ctx::EvPair ep; bool on;
-    ProfScope(kss_ctx* c_, int k_) : c(c_), k(k_), on(c_->prof > 0) {
-        if (on && c->prof > 1) on = (c->prof_tick[k]++ % (unsigned)c->prof) == 0;   // sampled: the events themselves cost ~3 us
+    // every: bracket this launch whenever profiling is on (a chained launch runs tens of passes: its two events are cheap)
+    ProfScope(kss_ctx* c_, int k_, bool every = false) : c(c_), k(k_), on(c_->prof > 0) {
+        if (on && c->prof > 1 && !every) on = (c->prof_tick[k]++ % (unsigned)c->prof) == 0;   // sampled: the events themselves cost ~3 us
         if (!on) return;
         if (!c->ev_pool.empty()) {
             ep = c->ev_pool.back();
@@ -176,7 +180,10 @@ static inline void prof_collect(kss_ctx* c) {
     for (int k = 0; k < KSS_K_COUNT; ++k) {
         for (auto& ep : c->ev[k]) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) { c->prof_ms[k] += ms; c->prof_n[k] += 1; }
+            if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
+                c->prof_ms[k] += ms; c->prof_n[k] += 1;
+                if (k == KSS_K_GRID_CHAIN) c->prof_ms[KSS_K_GRID_CHAIN_PASS] += ms;   // (its count: the passes released, kss_engine.hip)
+            }
             c->ev_pool.push_back(ep);
         }
         c->ev[k].clear();

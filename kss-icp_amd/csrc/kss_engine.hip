@@ -574,14 +574,24 @@ static void gated_release(kss_ctx* c, const PairState& st, int skip) {   // tran
             _mm_store_si128((__m128i*)(slot + 4 * g), v);
         }
         _mm_sfence();
-        c->gated.pending = false;
-        return;
+    } else {
+        PairState* rec = &c->h_xf[c->gated.slot];
+        for (int k = 0; k < 12; ++k) rec->m[k] = st.m[k];
+        rec->active = st.active; rec->apply = st.apply; rec->pad[0] = skip;
+        __atomic_store_n(&rec->pad[1], c->gated.stamp, __ATOMIC_RELEASE);   // the kernel accepts the record when it reads this stamp
     }
-    PairState* rec = &c->h_xf[c->gated.slot];
-    for (int k = 0; k < 12; ++k) rec->m[k] = st.m[k];
-    rec->active = st.active; rec->apply = st.apply; rec->pad[0] = skip;
-    __atomic_store_n(&rec->pad[1], c->gated.stamp, __ATOMIC_RELEASE);   // the kernel accepts the record when it reads this stamp
-    c->gated.pending = false;
+    kss_ctx::Gated& G = c->gated;
+    if (!skip && --G.steps_left > 0) {
+        // a chained launch: its next pass waits for the next stamp in the other record, publishes under the next sequence
+        // number and reads what this pass writes
+        G.slot ^= 1;
+        G.stamp += 1;                       // (the launch made sure the chain's stamps do not wrap)
+        G.seq += 1;
+        const void* in = G.d_out; G.d_out = const_cast<void*>(G.d_in); G.d_in = in;
+    } else {
+        G.pending = false;
+        G.steps_left = 0;
+    }
 }
 
 static void gated_cancel(kss_ctx* c) {
@@ -610,6 +620,7 @@ static PassArgs pass_args(kss_ctx* c, const IcpPlan& pl, const float4* d_in, flo
     a.nn_state = (float2*)c->g_nnst.p;
     static const float skin = getenv("KSS_SKIN") ? (float)atof(getenv("KSS_SKIN")) : 0.25f;   // KSS_SKIN=-1: every source searches in every pass
     a.skin = skin;
+    a.chain_len = 1;
     a.chained = d_in != (const float4*)c->src0.p ? 1 : 0;   // (the first pass and the fitness pass read the original cloud)
     a.keys = (unsigned long long*)c->keys.p;
     a.list = (int32_t*)c->g_list.p; a.list_count = (int32_t*)c->g_count.p;
@@ -665,6 +676,8 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
         if (G.pending && G.d_in == (const void*)d_in && G.d_out == (void*)d_out && G.fma == fma && G.full == full && G.max_d2 == max_d2 && plain_args) {
             // this pass was enqueued while the previous one ran: hand it its transform and open the gate
             want_seq = G.seq;
+            c->seq = std::max(c->seq, G.seq);   // (sequence numbers of a chain are taken as its passes are released)
+            if (G.chain && c->prof > 0) c->prof_n[KSS_K_GRID_CHAIN_PASS] += 1;
             gated_release(c, hs[0], 0);
         } else {
             gated_cancel(c);   // (a pre-enqueued kernel that does not fit this pass, e.g. before the fitness pass)
@@ -681,28 +694,45 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
         // HIP-event timing: a bracket behind the gate would also time the dispatch that follows the wait, so the launches
         // the profiler samples (every n-th) are plain launches; the others advance its tick here
         const bool next_sampled = c->prof == 1 || (c->prof > 1 && c->prof_tick[KSS_K_GRID_NN] % (unsigned)c->prof == 0);
-        if (G.want_next && !next_sampled && plain_args && gated_available(c)) {
-            if (c->prof > 1) ++c->prof_tick[KSS_K_GRID_NN];
+        // how many iterations a pre-enqueued launch may run: all that can still follow (KSS_CHAIN=0: one, the form of every
+        // system without a large BAR).  Chains need rows handed over as tagged granules (no ticket to re-arm between
+        // passes) or a single row.  A single gated launch stays out of the way of the launches the profiler samples; a
+        // chain is bracketed as a whole instead.
+        static const bool want_chain = getenv("KSS_CHAIN") == nullptr || atoi(getenv("KSS_CHAIN")) != 0;
+        int len = 1;
+        if (G.want_next && !G.pending && plain_args && gated_available(c) && want_chain && c->gate_bar && (a.tagged_rows || pl.total_rows == 1))
+            len = std::max(1, std::min(G.max_steps, 1 << 16));
+        if (G.want_next && !G.pending && plain_args && gated_available(c) && (len > 1 || !next_sampled)) {
+            if (c->prof > 1 && len == 1) ++c->prof_tick[KSS_K_GRID_NN];
             // enqueue the NEXT iteration behind the gate while this one runs: it reads what this pass writes (d_out) and
             // writes the other ping-pong buffer
             float4* nxt_out = d_out == (float4*)c->cur[0].p ? (float4*)c->cur[1].p : (float4*)c->cur[0].p;
             G.slot ^= 1;
             G.stamp = (G.stamp + 1) & 0x7fffffff;
-            if (G.stamp == 0) G.stamp = 1;   // (0 is what a fresh record holds)
+            if (G.stamp == 0 || G.stamp > 0x7fffffff - len - 1) G.stamp = 1;   // (0 is what a fresh record holds; a chain's stamps do not wrap)
             PassArgs n = pass_args(c, pl, d_out, nxt_out, max_d2, nullptr, nullptr);
             n.ps0 = hs[0];
             n.gate_seq = G.stamp;
             if (c->gate_bar) {   // the host writes the granules itself
                 n.state = nullptr;
-                n.gate_dev = c->gate_bar + 32 * G.slot;
+                n.gate_dev = c->gate_bar;    // two records, 128 bytes apart: pass k of the launch polls record (slot + k) & 1
+                n.gate_slot = G.slot;
+                n.chain_len = len;
+                n.src_alt = d_out;
             } else {             // workgroup 0 asks the host-mapped record and re-publishes
                 n.state = c->h_xf_dev + G.slot;
                 n.gate_dev = (unsigned int*)c->g_gate.p;
             }
-            n.seq = ++c->seq;
+            n.seq = c->seq + 1;          // (taken when the pass is released)
             if (stamps2) n.stamps = stamps2 + (size_t)(n.seq & 1) * nblk * 16;
-            launch_grid_pass(c->stream, fma, G.want_full, false, true, n);
-            G.pending = true; G.seq = c->seq; G.d_in = d_out; G.d_out = nxt_out; G.fma = fma; G.full = G.want_full; G.max_d2 = max_d2;
+            if (len > 1) {   // bracketed as a whole whenever profiling is on (KSS_K_GRID_CHAIN; per pass: KSS_K_GRID_CHAIN_PASS)
+                ProfScope ps(c, KSS_K_GRID_CHAIN, true);
+                launch_grid_pass(c->stream, fma, G.want_full, false, true, n);
+            } else {
+                launch_grid_pass(c->stream, fma, G.want_full, false, true, n);
+            }
+            G.chain = len > 1;
+            G.pending = true; G.steps_left = len; G.seq = n.seq; G.d_in = d_out; G.d_out = nxt_out; G.fma = fma; G.full = G.want_full; G.max_d2 = max_d2;
             if (hipGetLastError() != hipSuccess) { gated_cancel(c); G.supported = 0; }   // (if it did get queued it is answered; gating is given up)
         }
         const auto tl1 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
@@ -984,6 +1014,7 @@ static int icp_loop(kss_ctx* c, const IcpPlan& pl_in, const kss_icp_params& P, k
         // this stream BEHIND the polling kernel, whose transform depends on it)
         c->gated.want_next = plan->grid && !P.allreduce && it + 1 < P.max_iterations;
         c->gated.want_full = full;
+        c->gated.max_steps = P.max_iterations - (it + 1);
         // batched cell lists: every pair's sums are published as its last workgroup finishes, and the solve loop
         // picks the pairs up in that order while the rest of the launch is still running
         c->defer_wait = plan->gridb;

@@ -428,8 +428,9 @@ void launch_grid_build_pair(hipStream_t st, const float4* d_tgt, int nt, float4*
 #ifndef KSS_BATCH_WAVES
 #define KSS_BATCH_WAVES 6   // waves per SIMD the batched variant is compiled for (3 workgroups per CU; 8 spills)
 #endif
-template <bool FMA, bool FULL, bool BATCH, bool SEARCH>
+template <bool FMA, bool FULL, bool BATCH, bool SEARCH, bool CHAIN>
 __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pass_kernel(const PassArgs a) {
+    static_assert(!CHAIN || (!BATCH && SEARCH), "chained launches: single pair, search passes");
     // diagnostic stamps (100 MHz s_memrealtime): [block*16 + {0 start, 13 first loads in, 9 gate open, 14 phase A done,
     // 5 phase B entered, 8 answered, 15 phase B done, 1 searched, 2 row ready, 3 ticketed, 4 result stored (last
     // workgroup)}]; counts: 10 = distance evaluations of the r = 1 block, 11 = evaluation slots, 12 = walkers
@@ -485,12 +486,29 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
         // just written every source's winner.)
         if (!SEARCH || a.use_prev) { prevp = a.nn_win[i]; st = a.nn_state[i]; }
     }
+    // A CHAINED launch (a.chain_len > 1, single pair, kss_engine.hip) runs that many ICP iterations in this one kernel: every
+    // pass of the loop below waits for its own transform at the gate, and the source, its winner and its skip state stay in
+    // registers from one pass to the next.  What a chain saves is everything BETWEEN two launches -- the end-of-kernel
+    // cache write-back, the dispatch of the next kernel (~4 us together) and its first loads -- which is more than a
+    // third of an iteration at C2.  Buffers alternate (src_out <-> src_in, both work buffers then), stamps and sequence
+    // numbers count up with the pass.  Everything is still written to memory each pass: whoever continues after a chain
+    // (a plain launch after a fallback, the fitness pass) finds the same state a sequence of launches would have left.
+    for (int step = 0;; ++step) {
+    const bool last_step = !CHAIN || step + 1 >= a.chain_len;   // (CHAIN is a template parameter so that the profilers list the two forms apart)
+    const unsigned long long seq_k = a.seq + (unsigned long long)step;
+    const int gate_k = a.gate_seq != 0 ? a.gate_seq + step : 0;
+    unsigned int* const gate_ptr = a.gate_dev + 32 * ((a.gate_slot + step) & 1);
+    float4* const src_out_k = (step & 1) ? a.src_alt : a.src_out;
+    const bool chained_k = step > 0 || a.chained != 0;
     const bool has_prev = __float_as_uint(prevp.w) != ~0u;   // prevp = the last winner's coordinates, .w = its index in the pair's target
-    if (SEARCH && threadIdx.x == 0) s_nwalk = 0;
-    if constexpr (SEARCH) __syncthreads();
+    if constexpr (SEARCH) {
+        __syncthreads();                   // (the shared arrays of the previous pass are dead)
+        if (threadIdx.x == 0) s_nwalk = 0;
+        __syncthreads();
+    }
     KSS_STAMP(13);
     if constexpr (!BATCH && SEARCH) {
-        if (a.gate_seq != 0) {
+        if (gate_k != 0) {
             // GATED launch (kss_engine.hip): this kernel was enqueued while the previous iteration was still running, before
             // its transform existed.  It polls five self-validating 16-byte granules {3 words, stamp} in DEVICE memory (one
             // 80-byte request per poll and workgroup) until all carry this launch's stamp.  Who writes them: on a large-BAR
@@ -508,7 +526,7 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
                 bool ok = true;
                 for (;;) {
                     v = __hip_atomic_load(w32 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    if (__shfl(v, 15, 64) == a.gate_seq) break;      // word 15 = pad[1], written last by the host
+                    if (__shfl(v, 15, 64) == gate_k) break;      // word 15 = pad[1], written last by the host
                     __builtin_amdgcn_s_sleep(1);
                     if (++n > (1 << 21)) { ok = false; break; }
                 }
@@ -520,25 +538,25 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
                     const int w0 = __shfl(v, min(3 * g, 15), 64), w1 = __shfl(v, min(3 * g + 1, 15), 64), w2 = __shfl(v, min(3 * g + 2, 15), 64);
                     if (g < 5) {
                         u32x4 o;
-                        o.x = (unsigned)w0; o.y = (unsigned)w1; o.z = (unsigned)w2; o.w = (unsigned)a.gate_seq;
-                        unsigned int* dst = a.gate_dev + 4 * g;
+                        o.x = (unsigned)w0; o.y = (unsigned)w1; o.z = (unsigned)w2; o.w = (unsigned)gate_k;
+                        unsigned int* dst = gate_ptr + 4 * g;
                         asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(o) : "memory");
                     }
                 }
             }
             if (threadIdx.x < 8) {         // every workgroup: lanes 0-4 poll the five granules (one 80-byte request per poll)
-                const unsigned int* src = a.gate_dev + 4 * min((int)threadIdx.x, 4);
+                const unsigned int* src = gate_ptr + 4 * min((int)threadIdx.x, 4);
                 u32x4 v;
                 int n = 0;
                 bool ok = true;
                 for (;;) {
                     asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(src) : "memory");   // system scope: the writer may be the host
-                    if (__builtin_amdgcn_ballot_w64((int)v.w == a.gate_seq) == 0xffull) break;
+                    if (__builtin_amdgcn_ballot_w64((int)v.w == gate_k) == 0xffull) break;
                     __builtin_amdgcn_s_sleep(1);
                     if (++n > (1 << 22)) { ok = false; break; }
                 }
                 if (threadIdx.x < 5) { sh_ps[3 * threadIdx.x] = (int)v.x; sh_ps[3 * threadIdx.x + 1] = (int)v.y; sh_ps[3 * threadIdx.x + 2] = (int)v.z; }
-                if (threadIdx.x == 0) { sh_ps[15] = a.gate_seq; s_last = ok ? 1 : 0; }
+                if (threadIdx.x == 0) { sh_ps[15] = gate_k; s_last = ok ? 1 : 0; }
             }
             __syncthreads();
             if (!s_last) return;
@@ -570,7 +588,7 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
                 p.y = ((ps.m[4] * x + ps.m[5] * y) + ps.m[6] * z) + ps.m[7];
                 p.z = ((ps.m[8] * x + ps.m[9] * y) + ps.m[10] * z) + ps.m[11];
             }
-            a.src_out[i] = p;
+            src_out_k[i] = p;
         }
         qx = p.x; qy = p.y; qz = p.z;
         // a non-finite query matches nothing (its distances are NaN; as an integer key NaN bits would beat every real one)
@@ -589,6 +607,7 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
     }
     if constexpr (SEARCH) {
         bool walker = false;
+        float acc_keep = 0.f;
         {
             const bool qok = valid && (qx - qx) == 0.f && (qy - qy) == 0.f && (qz - qz) == 0.f;
             int kpos = -1;
@@ -604,16 +623,17 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
                     const float moved = __builtin_amdgcn_sqrtf((mx * mx + my * my) + mz * mz);
                     const float acc = (st.y + moved) * 1.00001f;
                     const float room = st.x - acc;
-                    if (a.chained && a.skin >= 0.f && room > 1e-10f && (room * room) * 0.99999f > d0) {
+                    if (chained_k && a.skin >= 0.f && room > 1e-10f && (room * room) * 0.99999f > d0) {
                         walker = false;            // w again
                         fl = 1u;
+                        acc_keep = acc;
                         a.nn_state[i] = make_float2(st.x, acc);
                     } else {
                         // the walk prunes with the winner's distance grown by a skin (a fraction of the cell edge): what it
                         // then proves about the other targets leaves room for the next passes.  A source that is still
                         // moving by more than a quarter of the skin per pass would not profit: plain radius.
                         const float skin = fmaxf(a.skin, 0.f) * gp.h, grown = __builtin_amdgcn_sqrtf(d0) + skin;
-                        rho = !a.chained || moved * 4.f <= skin ? fmaxf(d0, grown * grown) : d0;
+                        rho = !chained_k || moved * 4.f <= skin ? fmaxf(d0, grown * grown) : d0;
                     }
                 }
             } else if (valid) {
@@ -774,6 +794,7 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
                 s_ent[WK_X][owner] = __float_as_uint(ww.x); s_ent[WK_Y][owner] = __float_as_uint(ww.y); s_ent[WK_Z][owner] = __float_as_uint(ww.z);
                 s_ent[WK_IDX][owner] = (unsigned)wkey; s_ent[WK_D2][owner] = (unsigned)(wkey >> 32);
                 s_ent[WK_FL][owner] = (whave ? 1u : 0u) | (wfell ? 2u : 0u);
+                s_ent[WK_R][owner] = __float_as_uint(wfell ? 0.f : bnew);
             }
             KSS_STAMP(8);
             if (a.stamps) {   // slot 10: evaluations, 11: evaluation slots issued (slowest lane, rounded up to 8, x 64)
@@ -794,10 +815,21 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
             have = (fl & 1u) != 0u; fell_back = (fl & 2u) != 0u;
             win = make_float4(__uint_as_float(s_ent[WK_X][threadIdx.x]), __uint_as_float(s_ent[WK_Y][threadIdx.x]), __uint_as_float(s_ent[WK_Z][threadIdx.x]), 0.f);
             key = ((unsigned long long)s_ent[WK_D2][threadIdx.x] << 32) | (unsigned long long)s_ent[WK_IDX][threadIdx.x];
+            if (CHAIN && !last_step) {     // chained launch: what the next pass would otherwise load
+                if (walker) {
+                    prevp = make_float4(win.x, win.y, win.z, __uint_as_float(have ? (unsigned)key : ~0u));
+                    st = make_float2(__uint_as_float(s_ent[WK_R][threadIdx.x]), 0.f);
+                } else if (have) {
+                    st.y = acc_keep;       // (a kept winner: same point, same bound, more distance covered)
+                } else {
+                    prevp.w = __uint_as_float(~0u);
+                    st = make_float2(0.f, 0.f);
+                }
+            }
         }
         if constexpr (BATCH) {   // (the query comes back from memory rather than staying in registers across the search)
             p = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid) p = a.src_out[i];
+            if (valid) p = src_out_k[i];
             qx = p.x; qy = p.y; qz = p.z;
         }
     }
@@ -855,11 +887,14 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
         if (threadIdx.x < NSUMS) {
             const unsigned long long rb = (unsigned long long)__double_as_longlong(r);
             u32x4 o;
-            o.x = (unsigned)rb; o.y = (unsigned)(rb >> 32); o.z = (unsigned)a.seq; o.w = (unsigned)(a.seq >> 32);
+            o.x = (unsigned)rb; o.y = (unsigned)(rb >> 32); o.z = (unsigned)seq_k; o.w = (unsigned)(seq_k >> 32);
             unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.rows) + 2 * ((int64_t)w * NSUMS + threadIdx.x);
             asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(o) : "memory");
         }
-        if (w != pr.row_base) return;      // uniform
+        if (w != pr.row_base) {            // uniform
+            if (last_step) return;
+            continue;
+        }
         KSS_STAMP(3);
         if (threadIdx.x == 0) s_last = 1;
         __syncthreads();
@@ -884,7 +919,7 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
                             : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
                             : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
                             : "memory");
-                        const unsigned lo = (unsigned)a.seq, hi = (unsigned)(a.seq >> 32);
+                        const unsigned lo = (unsigned)seq_k, hi = (unsigned)(seq_k >> 32);
                         const bool ok = t0.z == lo && t0.w == hi && t1.z == lo && t1.w == hi && t2.z == lo && t2.w == hi && t3.z == lo && t3.w == hi &&
                                         t4.z == lo && t4.w == hi && t5.z == lo && t5.w == hi && t6.z == lo && t6.w == hi && t7.z == lo && t7.w == hi;
                         if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;      // wave-uniform: the loads stay convergent
@@ -945,11 +980,13 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
         // write-acknowledge round trip over PCIe) and no L2 write-back fence is needed
         const unsigned long long vb = (unsigned long long)__double_as_longlong(v);
         u32x4 o;
-        o.x = (unsigned)vb; o.y = (unsigned)(vb >> 32); o.z = (unsigned)a.seq; o.w = (unsigned)(a.seq >> 32);
+        o.x = (unsigned)vb; o.y = (unsigned)(vb >> 32); o.z = (unsigned)seq_k; o.w = (unsigned)(seq_k >> 32);
         unsigned long long* dst = a.pub + 2 * ((int64_t)pi * NSUMS + threadIdx.x);
         asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(o) : "memory");
         KSS_STAMP(4);
     }
+    if (last_step) break;
+    }   // passes of a chained launch
 #undef KSS_STAMP
 }
 
@@ -1255,17 +1292,22 @@ int grid_pass_blocks(int total_rows) { return (total_rows + 7) / 8 * 8; }   // m
 void launch_grid_pass(hipStream_t st, bool fma, bool full, bool batch, bool search, const PassArgs& a) {
     if (a.total_rows <= 0) return;
     const dim3 grid(grid_pass_blocks(a.total_rows)), block(PASS_BS);
-#define KSS_PASS(F, U, B, S) hipLaunchKernelGGL((grid_pass_kernel<F, U, B, S>), grid, block, 0, st, a)
+#define KSS_PASS(F, U, B, S) hipLaunchKernelGGL((grid_pass_kernel<F, U, B, S, false>), grid, block, 0, st, a)
+#define KSS_CHAIN(F, U) hipLaunchKernelGGL((grid_pass_kernel<F, U, false, true, true>), grid, block, 0, st, a)
     if (!search) {   // sums-only relaunch after the list pass: single pair, all 20 sums
         if (fma) KSS_PASS(true, true, false, false); else KSS_PASS(false, true, false, false);
     } else if (batch) {
         if (fma) { if (full) KSS_PASS(true, true, true, true); else KSS_PASS(true, false, true, true); }
         else     { if (full) KSS_PASS(false, true, true, true); else KSS_PASS(false, false, true, true); }
+    } else if (a.chain_len > 1) {
+        if (fma) { if (full) KSS_CHAIN(true, true); else KSS_CHAIN(true, false); }
+        else     { if (full) KSS_CHAIN(false, true); else KSS_CHAIN(false, false); }
     } else {
         if (fma) { if (full) KSS_PASS(true, true, false, true); else KSS_PASS(true, false, false, true); }
         else     { if (full) KSS_PASS(false, true, false, true); else KSS_PASS(false, false, false, true); }
     }
 #undef KSS_PASS
+#undef KSS_CHAIN
 }
 
 }  // namespace kss
