@@ -81,6 +81,7 @@ struct kss_ctx {
     bool ws_dirty = false;
     bool defer_wait = false;   // batched fused pass: the ICP loop polls the pairs' result slots itself
     PairState* h_xf = nullptr; PairState* h_xf_dev = nullptr;
+    bool fit_last = false;            // the fitness pass: PairState::pad[0] names the buffer of each pair's last pass
     bool nn_have = false;             // the cell-list pass has written nn_win / nn_state for the current lists
     PairState* bar_state = nullptr; int bar_state_cap = 0; bool bar_state_failed = false;   // batched pass: per-pair states, same kind of memory
     unsigned int* gate_bar = nullptr;   // fine-grained device memory the host stores into through the BAR (large-BAR systems)

@@ -621,7 +621,8 @@ static PassArgs pass_args(kss_ctx* c, const IcpPlan& pl, const float4* d_in, flo
     static const float skin = getenv("KSS_SKIN") ? (float)atof(getenv("KSS_SKIN")) : 0.25f;   // KSS_SKIN=-1: every source searches in every pass
     a.skin = skin;
     a.chain_len = 1;
-    a.chained = d_in != (const float4*)c->src0.p ? 1 : 0;   // (the first pass and the fitness pass read the original cloud)
+    a.chained = d_in != (const float4*)c->src0.p ? 1 : c->fit_last ? 2 : 0;   // (the first pass and the fitness pass read the original cloud)
+    a.src_last0 = (const float4*)c->cur[0].p; a.src_last1 = (const float4*)c->cur[1].p;
     a.keys = (unsigned long long*)c->keys.p;
     a.list = (int32_t*)c->g_list.p; a.list_count = (int32_t*)c->g_count.p;
     a.total_rows = pl.total_rows;
@@ -1064,7 +1065,16 @@ static int icp_loop(kss_ctx* c, const IcpPlan& pl_in, const kss_icp_params& P, k
     }
     if (P.compute_fitness) {
         // getFitnessScore(): NN of final * ORIGINAL input, mean d2 over all source points
-        for (int p = 0; p < np; ++p) { set_state(hs[p], &fin[(size_t)p * 16], 1, 1); mirror_state(bar, p, hs[p]); }
+        // (pad[0]: which work buffer holds the positions of the pair's last pass -- pass k writes cur[k & 1] -- so that the
+        // cell-list pass can measure how far each source is from where its skip state was last brought up to date)
+        const bool cell_lists = plan->grid || plan->gridb;
+        for (int p = 0; p < np; ++p) {
+            set_state(hs[p], &fin[(size_t)p * 16], 1, 1);
+            if (cell_lists && plan == &pl_in && iters[p] >= 1) hs[p].pad[0] = 1 + ((iters[p] - 1) & 1);
+            mirror_state(bar, p, hs[p]);
+        }
+        c->fit_last = cell_lists && plan == &pl_in;
+        struct FitGuard { kss_ctx* c; ~FitGuard() { c->fit_last = false; } } fit_guard{c};
         c->gated.want_next = false;
         int32_t* d_idx = nullptr;
         float* d_d2 = nullptr;

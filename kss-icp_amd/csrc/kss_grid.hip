@@ -328,7 +328,7 @@ __device__ __forceinline__ int block_walk(const GridParams& gp, const int32_t* _
 // walker, lanes 0-8 of the group take rows 0-8).  Same pruning rule and the same m1 / m2 bookkeeping as block_walk, but no
 // range queue and -- for the usual row of <= 8 points -- a single step: the serial instruction count of a search, which is
 // what a lone wave pays for, drops to less than half.
-template <bool FMA>
+template <bool FMA, int U>
 __device__ __forceinline__ void row_walk(const GridParams& gp, const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
                                          float qx, float qy, float qz, int cx, int cy, int cz, float rho, int t,
                                          unsigned long long& key, int& kpos, float& m1, float& m2) {
@@ -347,15 +347,15 @@ __device__ __forceinline__ void row_walk(const GridParams& gp, const int32_t* __
     if (rho < g2 * 0.999999f) return;
     const bool left = !(rho < (g2 + exl * exl) * 0.999999f), right = !(rho < (g2 + exr * exr) * 0.999999f);
     const int lo = left ? s0 : s1, hi = right ? s3 : s2;
-    for (int k = lo; k < hi; k += 8) {
-        int at[8];
-        float4 pt[8];
+    for (int k = lo; k < hi; k += U) {
+        int at[U];
+        float4 pt[U];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) at[j] = min(k + j, hi - 1);
+        for (int j = 0; j < U; ++j) at[j] = min(k + j, hi - 1);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pt[j] = sorted[at[j]];
+        for (int j = 0; j < U; ++j) pt[j] = sorted[at[j]];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < U; ++j) {
             const unsigned long long kk = point_key<FMA>(pt[j], qx, qy, qz);
             if (kk < key) { key = kk; kpos = at[j]; }
             const float dd = k + j < hi ? __uint_as_float((unsigned)(kk >> 32)) : __builtin_inff();
@@ -499,7 +499,11 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
     const int gate_k = a.gate_seq != 0 ? a.gate_seq + step : 0;
     unsigned int* const gate_ptr = a.gate_dev + 32 * ((a.gate_slot + step) & 1);
     float4* const src_out_k = (step & 1) ? a.src_alt : a.src_out;
-    const bool chained_k = step > 0 || a.chained != 0;
+    // where the source was when its skip state was last brought up to date: the buffer this pass reads (chained == 1), or --
+    // the fitness pass, which starts over from the original cloud -- the work buffer the pair's last pass wrote, named by the
+    // host in the pair's state (chained == 2, pad[0] = 1 + buffer; 0: unknown)
+    const bool last_known = a.chained == 2 && ps.pad[0] > 0;
+    const bool chained_k = step > 0 || a.chained == 1 || last_known;
     const bool has_prev = __float_as_uint(prevp.w) != ~0u;   // prevp = the last winner's coordinates, .w = its index in the pair's target
     if constexpr (SEARCH) {
         __syncthreads();                   // (the shared arrays of the previous pass are dead)
@@ -579,7 +583,11 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
     // Lanes that cannot skip ("walkers") are compacted into the first waves of the workgroup (phase B): near convergence
     // ~8 % of the sources walk, so ONE wave per workgroup pays for the walk instead of eight (the pass is VALU-bound).
     unsigned long long key = ~0ull;
-    const float pold_x = p.x, pold_y = p.y, pold_z = p.z;   // where the source was in the last pass
+    float pold_x = p.x, pold_y = p.y, pold_z = p.z;   // where the source was in the last pass
+    if (SEARCH && last_known && valid) {
+        const float4 pl = (ps.pad[0] == 1 ? a.src_last0 : a.src_last1)[i];
+        pold_x = pl.x; pold_y = pl.y; pold_z = pl.z;
+    }
     if (valid) {
         if constexpr (SEARCH) {
             if (ps.apply) {   // pcl transformCloud with the previous iteration's Matrix4f, Eigen order, float, no fma
@@ -664,7 +672,7 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
         // L = 8 or 4 lanes share one: each walks its own rows of the 3x3x3 block (disjoint, so "distinct points" still
         // holds) and the group merges key / position / the two smallest distances by DPP -- the dependent chain of a
         // search drops from ~4 walk steps to ~1, on lanes the compaction has left idle anyway.
-        const bool row16 = !BATCH && 16 * nwalk <= BS;   // single pair, few walkers: one row per lane (row_walk)
+        const bool row16 = 16 * nwalk <= BS;             // few walkers: one row per lane (row_walk)
         const int L = row16 ? 16 : 8 * nwalk <= WQ ? 8 : 4 * nwalk <= WQ ? 4 : 1;
         const int nserve = row16 ? BS : WQ;              // lanes that search (block_walk's range queue has WQ columns)
         for (int rb = 0; rb < nwalk; rb += nserve / L)
@@ -694,7 +702,7 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
                 // ---- r = 1: the 3x3x3 block, pruned by rho ----
                 KSS_STAMP(5);
                 float m1, m2;
-                if (row16) row_walk<FMA>(gp, cs, sorted, wx, wy, wz, cx, cy, cz, wrho, sub, wkey, wpos, m1, m2);
+                if (row16) row_walk<FMA, BATCH ? 4 : 8>(gp, cs, sorted, wx, wy, wz, cx, cy, cz, wrho, sub, wkey, wpos, m1, m2);
                 else evl = block_walk<FMA, WQ, BATCH ? 4 : 8>(gp, cs, sorted, wx, wy, wz, cx, cy, cz, wrho, rowmask, rowq, wkey, wpos, m1, m2);
                 if (L > 1) {   // (uniform) all lanes of a group are walkers of the same source: merge by DPP
 #define KSS_GROUP_MERGE(X)                                                                                                          \

@@ -90,7 +90,9 @@ struct PassArgs {
     const float4* tgt4;                         // targets in original order (fallback sweep, SEARCH = false gathers)
     float4* nn_win;                             // per source: its last winner {x, y, z, index in the pair's target}; .w = ~0: none
     float2* nn_state;                           // per source: {B, acc} of the skip test (grid_pass_kernel, phase A)
-    int32_t chained;                            // src_in is what the previous search pass wrote (its queries): displacements are measurable
+    int32_t chained;                            // 1: src_in is what the previous search pass wrote (its queries): displacements are measurable;
+                                                // 2: the pair's state names the work buffer its last pass wrote (fitness pass)
+    const float4* src_last0; const float4* src_last1;   // ... the two work buffers
     float skin;                                 // pruning radius grows by skin * cell edge; < 0: never skip (A/B switch)
     unsigned long long* keys;                   // single pair: key of the sources left to the list pass
     int32_t* list; int32_t* list_count;         // single pair: those sources
