@@ -500,6 +500,9 @@ def main():
             # walked (the kernel counts its distance evaluations in an untimed diagnostic step)
             req = n_src * (16.0 + 16.0 + 8.0 + 9 * 16.0) + ev * 16.0
             traffic = read_traffic("grid_pass")
+            if chained:   # PMC bytes of a chained launch / the passes it ran (the profiled command runs the same chains)
+                ct = read_traffic("grid_pass_chain")
+                traffic = ct / (cpasses / cn) if ct else None
             out["roofline"] = {
                 "kernel": "grid_pass_kernel<.., CHAIN = true>" if chained else "grid_pass_kernel", "bound": "latency",
                 "bound_note": "skip test / cell-list search of the few sources that need one / correspondence sums / pair reduction; "

@@ -67,6 +67,9 @@ def main():
         wa = sum(wv) / len(wv) if wv else 0.0
         rb, wb = fa * 1024 * 2, wa * 1024
         key = k.split("<")[0].replace("_kernel", "")
+        targs = [t.strip() for t in k[k.find("<") + 1:k.rfind(">")].split(",")] if "<" in k else []
+        if key == "grid_pass" and len(targs) == 5 and targs[4] == "true":
+            key = "grid_pass_chain"   # chained launches: one launch = many ICP passes (bench.py divides by its passes per launch)
         if key in summary and summary[key].get("launches", 0) > len(fv):
             continue   # template variants share a key: keep the one launched most (the ICP-iteration form)
         summary[key] = {"kernel": k, "launches": len(fv), "fetch_size_kib_raw": fa, "read_bytes_corrected": rb,
