@@ -330,9 +330,11 @@ static int grid_setup(kss_ctx* c, IcpPlan& pl) {
         size_t bad = 0, first = 0;
         for (size_t k = 0; k < h.size(); ++k)
             if (h[k] != 0) { if (!bad) first = k; ++bad; }
-        std::fprintf(stderr, "[kss] counts check: %zu cells x 2 (%d x %d x %d), buffer %zu bytes, %zu non-zero counters%s", ncells, gp.gx, gp.gy, gp.gz,
-                     c->g_counts.cap, bad, bad ? "" : "\n");
-        if (bad) { std::fprintf(stderr, ", first at %zu = %d\n", first, h[first]); return set_err(c, KSS_ERR_HIP, "cell counters not zero at rest"); }
+        if (bad) {
+            std::fprintf(stderr, "[kss] counts check: %zu cells x 2 (%d x %d x %d), buffer %zu bytes, %zu non-zero counters, first at %zu = %d\n", ncells,
+                         gp.gx, gp.gy, gp.gz, c->g_counts.cap, bad, first, h[first]);
+            return set_err(c, KSS_ERR_HIP, "cell counters not zero at rest");
+        }
     }
     pl.gpairs[0].gp = gp;
     pl.gpairs[0].cell_base = 0;

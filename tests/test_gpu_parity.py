@@ -446,10 +446,11 @@ def test_register_batch_equals_one_by_one(ctx, pkg, ref_pairs):
 
 
 def test_gated_launches_give_the_same_registration(ctx, pkg):
-    """Gated launches (the default on a context that owns its stream; KSS_GATED=0 switches them off): the next iteration's
-    fused kernel is enqueued while the current one runs and polls for its transform (workgroup 0 asks the host-mapped
-    record, re-publishes it in device memory).  Same registration, bit for bit, including a run that converges early (the
-    pre-enqueued kernel is cancelled) and one that needs the brute-force fallback."""
+    """The mechanisms that only move work around must not move a bit: gated launches (KSS_GATED=0 off), host stores into
+    device memory (KSS_GATE_BAR=0 off: the re-publishing gate), chained launches (KSS_CHAIN=0: one launch per pass) and
+    the skip test of the fused pass (KSS_SKIN=-1: every source searches in every pass; 0.05 / 1.0: other skins).  Same
+    registration, bit for bit, including runs that converge early (the waiting kernel is cancelled), fixed-length
+    runs, a pair that needs the brute-force fallback, and a 100k pair (196 workgroups: the chained form of C2)."""
     import subprocess, sys, json
     code = r"""
 import sys, json, numpy as np
@@ -457,17 +458,45 @@ sys.path.insert(0, %r)
 import __graft_entry__ as g
 pkg = g.load_package(); S = pkg.synth; ctx = pkg.Context(0)
 out = []
-for seed, n, deg, t in ((81, 30000, 8.0, (0.01, 0.0, 0.0)), (82, 12000, 25.0, (0.3, -0.2, 0.1))):
+for seed, n, deg, t in ((81, 30000, 8.0, (0.01, 0.0, 0.0)), (82, 12000, 25.0, (0.3, -0.2, 0.1)), (83, 100000, 10.0, (0.0, 0.0, 0.0))):
     src, tgt = S.make_pair(seed, n, R=S.rot_axis_angle([0.2, 0.1, 1.0], np.deg2rad(deg)), t=t, shape="bumpy")
-    for kw in (dict(), dict(max_iterations=9, fixed_iterations=1)):
+    for kw in (dict(), dict(max_iterations=9, fixed_iterations=1), dict(max_iterations=30, fixed_iterations=1)):
         r = ctx.icp(src, tgt, ctx.icp_params(nn_mode=pkg.NN_GRID, **kw))
-        out.append([r["T"].tolist(), r["iterations"], r["fitness"]])
+        out.append([r["T"].tolist(), r["iterations"], r["fitness"], r["last_mse"]])
 print("RESULT" + json.dumps(out))
 """ % ROOT
     res = {}
-    for gated in ("0", "1"):
-        env = dict(os.environ, KSS_GATED=gated)
+    variants = {"default": {}, "ungated": {"KSS_GATED": "0"}, "no_bar": {"KSS_GATE_BAR": "0"}, "unchained": {"KSS_CHAIN": "0"},
+                "no_skip": {"KSS_SKIN": "-1"}, "thin_skin": {"KSS_SKIN": "0.05"}, "thick_skin": {"KSS_SKIN": "1.0"}}
+    for name, extra in variants.items():
+        env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
-        assert r.returncode == 0, r.stdout + r.stderr
-        res[gated] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT")][0][6:])
-    assert res["0"] == res["1"]
+        assert r.returncode == 0, name + r.stdout + r.stderr
+        res[name] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT")][0][6:])
+    for name in variants:
+        assert res[name] == res["default"], name
+
+
+def test_growing_registrations_on_one_context(pkg):
+    """Work buffers that are zero at rest (cell counters, tickets, the fallback list's length) across registrations of
+    growing and shrinking size on ONE context -- the sequence that once left the tail of a re-allocated counter buffer
+    uninitialised (DESIGN.md, incidents).  KSS_COUNTS_CHECK makes the library verify the counters before every build;
+    every result must equal the same registration on a fresh context."""
+    S = pkg.synth
+    os.environ["KSS_COUNTS_CHECK"] = "1"
+    try:
+        ctx = pkg.Context(0)
+        sizes = [(700, 1500), (2400, 4300), (900, 1100), (5200, 9000), (3000, 3100), (12000, 20000), (600, 700), (30000, 41000)]
+        shapes = ["bumpy", "sphere", "bumpy", "sphere", "bumpy", "bumpy", "sphere", "bumpy"]
+        got = []
+        for k, ((ns, nt), shape) in enumerate(zip(sizes, shapes)):
+            src, tgt = S.make_pair(500 + k, nt, R=S.rot_axis_angle([0.3, 1.0, 0.2], np.deg2rad(6.0 + 3 * k)), t=(0.02 * k, 0.0, -0.01), shape=shape, n_src=ns)
+            got.append((src, tgt, ctx.icp(src, tgt, ctx.icp_params(nn_mode=pkg.NN_GRID))))
+        ctx.close()
+        for src, tgt, r in got:
+            fresh = pkg.Context(0)
+            one = fresh.icp(src, tgt, fresh.icp_params(nn_mode=pkg.NN_GRID))
+            fresh.close()
+            assert np.array_equal(r["T"], one["T"]) and r["iterations"] == one["iterations"] and r["fitness"] == one["fitness"]
+    finally:
+        del os.environ["KSS_COUNTS_CHECK"]
