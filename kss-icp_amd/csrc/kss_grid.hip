@@ -579,7 +579,8 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
     // By the triangle inequality every other target is now at true distance >= B - acc, so its COMPUTED squared distance
     // (5 roundings: relative error < 6 * 2^-24) exceeds (B - acc)^2 * 0.99999.  If the winner's computed distance is
     // below that, w wins again, strictly -- no tie to break -- and the lane is done: exactly the key a search would
-    // return.  (1e-10: below it, float underflow in the displacement could matter; such a lane searches.)
+    // return.  (1e-7: a displacement component below 1.1e-19 squares to zero; over a million passes that is 2e-13 unaccounted for,
+    // 2e-6 of the smallest room accepted -- inside the 1e-5 margin.  A lane with less room searches.)
     // Lanes that cannot skip ("walkers") are compacted into the first waves of the workgroup (phase B): near convergence
     // ~8 % of the sources walk, so ONE wave per workgroup pays for the walk instead of eight (the pass is VALU-bound).
     unsigned long long key = ~0ull;
@@ -631,7 +632,7 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
                     const float moved = __builtin_amdgcn_sqrtf((mx * mx + my * my) + mz * mz);
                     const float acc = (st.y + moved) * 1.00001f;
                     const float room = st.x - acc;
-                    if (chained_k && a.skin >= 0.f && room > 1e-10f && (room * room) * 0.99999f > d0) {
+                    if (chained_k && a.skin >= 0.f && room > 1e-7f && (room * room) * 0.99999f > d0) {
                         walker = false;            // w again
                         fl = 1u;
                         acc_keep = acc;
