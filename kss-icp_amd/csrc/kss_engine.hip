@@ -475,7 +475,9 @@ static int wait_pair(kss_ctx* c, int p, unsigned long long want) {
     return KSS_ERR_HIP;   // the caller synchronizes (only one thread may) and retries
 }
 
-static int wait_seq(kss_ctx* c, int npairs = 1, unsigned long long want = 0, const int* active = nullptr) {
+// not_published (optional): set when the stream drained without error and the slots still do not carry `want` -- the caller
+// may know how to go on (a gated launch that gave up waiting for a stalled host thread has not touched anything)
+static int wait_seq(kss_ctx* c, int npairs = 1, unsigned long long want = 0, const int* active = nullptr, bool* not_published = nullptr) {
     if (!want) want = c->seq;
     bool slow = false;
     for (int p = npairs - 1; p >= 0; --p) {
@@ -486,7 +488,10 @@ static int wait_seq(kss_ctx* c, int npairs = 1, unsigned long long want = 0, con
             HIPCHK(c, hipStreamSynchronize(c->stream));
             slow = true;
         }
-        if (!collect_pair(c, p, want)) return set_err(c, KSS_ERR_HIP, "kernel finished without publishing its result");
+        if (!collect_pair(c, p, want)) {
+            if (not_published) *not_published = true;
+            return set_err(c, KSS_ERR_HIP, "kernel finished without publishing its result");
+        }
     }
     return KSS_OK;
 }
@@ -623,6 +628,8 @@ static PassArgs pass_args(kss_ctx* c, const IcpPlan& pl, const float4* d_in, flo
     static const float skin = getenv("KSS_SKIN") ? (float)atof(getenv("KSS_SKIN")) : 0.25f;   // KSS_SKIN=-1: every source searches in every pass
     a.skin = skin;
     a.chain_len = 1;
+    static const int gate_polls = getenv("KSS_GATE_POLLS") ? atoi(getenv("KSS_GATE_POLLS")) : (1 << 22);   // bound of a waiting kernel's poll (~1 us each)
+    a.gate_polls = gate_polls;
     a.chained = d_in != (const float4*)c->src0.p ? 1 : c->fit_last ? 2 : 0;   // (the first pass and the fitness pass read the original cloud)
     a.src_last0 = (const float4*)c->cur[0].p; a.src_last1 = (const float4*)c->cur[1].p;
     a.keys = (unsigned long long*)c->keys.p;
@@ -674,6 +681,7 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
         }
         const auto tl0 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
         unsigned long long want_seq = 0;
+        bool via_gate = false;
         kss_ctx::Gated& G = c->gated;
         const bool plain_args = !a.stamps && !d_idx_out && !d_d2_out;
         if (G.pending && G.d_in == (const void*)d_in && G.d_out == (void*)d_out && G.fma == fma && G.full == full && G.max_d2 == max_d2 && plain_args) {
@@ -681,7 +689,13 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
             want_seq = G.seq;
             c->seq = std::max(c->seq, G.seq);   // (sequence numbers of a chain are taken as its passes are released)
             if (G.chain && c->prof > 0) c->prof_n[KSS_K_GRID_CHAIN_PASS] += 1;
-            gated_release(c, hs[0], 0);
+            via_gate = true;
+            // (test hook: the n-th answer is never written -- a host thread that stalls for longer than the kernel's bounded
+            // poll.  The waiting kernel gives up at the gate, having touched nothing, and the pass is launched again below.)
+            static const long drop_at = getenv("KSS_TEST_DROP_GATE") ? atol(getenv("KSS_TEST_DROP_GATE")) : -1;
+            static long releases = 0;
+            if (++releases == drop_at) { G.pending = false; G.steps_left = 0; }
+            else gated_release(c, hs[0], 0);
         } else {
             gated_cancel(c);   // (a pre-enqueued kernel that does not fit this pass, e.g. before the fitness pass)
             ProfScope ps(c, KSS_K_GRID_NN);
@@ -739,7 +753,25 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
             if (hipGetLastError() != hipSuccess) { gated_cancel(c); G.supported = 0; }   // (if it did get queued it is answered; gating is given up)
         }
         const auto tl1 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-        KCHK(wait_seq(c, 1, want_seq));
+        {
+            bool not_published = false;
+            int rcw = wait_seq(c, 1, want_seq, nullptr, &not_published);
+            if (rcw != KSS_OK && via_gate && not_published) {
+                // The waiting kernel left at its gate (bounded poll: this thread was stalled, or the answer never arrived) and
+                // the stream has drained.  Nothing of this pass has been written: launch it as a plain pass.
+                G.pending = false; G.steps_left = 0;
+                c->err.clear();
+                std::fprintf(stderr, "[kss] a waiting kernel was not answered in time and left; the pass is launched again\n");
+                ProfScope ps(c, KSS_K_GRID_NN);
+                a.ps0 = hs[0];
+                a.seq = ++c->seq;
+                launch_grid_pass(c->stream, fma, full, false, true, a);
+                HIPCHK(c, hipGetLastError());
+                want_seq = c->seq;
+                rcw = wait_seq(c, 1, want_seq);
+            }
+            KCHK(rcw);
+        }
         if (stamps2) c->stamps_seq = want_seq;
         if (c->timing) {
             const auto tl2 = std::chrono::steady_clock::now();

@@ -532,7 +532,7 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
                     v = __hip_atomic_load(w32 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     if (__shfl(v, 15, 64) == gate_k) break;      // word 15 = pad[1], written last by the host
                     __builtin_amdgcn_s_sleep(1);
-                    if (++n > (1 << 21)) { ok = false; break; }
+                    if (++n > a.gate_polls / 2) { ok = false; break; }
                 }
                 if (ok) {
                     // hand it to the other workgroups through device memory as five self-validating 16-byte granules
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
                     asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(src) : "memory");   // system scope: the writer may be the host
                     if (__builtin_amdgcn_ballot_w64((int)v.w == gate_k) == 0xffull) break;
                     __builtin_amdgcn_s_sleep(1);
-                    if (++n > (1 << 22)) { ok = false; break; }
+                    if (++n > a.gate_polls) { ok = false; break; }
                 }
                 if (threadIdx.x < 5) { sh_ps[3 * threadIdx.x] = (int)v.x; sh_ps[3 * threadIdx.x + 1] = (int)v.y; sh_ps[3 * threadIdx.x + 2] = (int)v.z; }
                 if (threadIdx.x == 0) { sh_ps[15] = gate_k; s_last = ok ? 1 : 0; }

@@ -101,6 +101,7 @@ struct PassArgs {
     const PairState* state;                     // BATCH: per-pair transforms; single pair: host-mapped transform of a gated launch or null
     GridPairDev pair0; PairState ps0;           // single pair: by value (no upload per iteration)
     int32_t total_rows, use_prev;
+    int32_t gate_polls;                         // bound of the gate's poll loop (a kernel nobody answers leaves without touching anything)
     int32_t chain_len, gate_slot;               // chained launch: passes run by this one launch (1: a plain launch); first of the two gate records
     float4* src_alt;                            // chained launch: the other work buffer (== src_in), written by every second pass
     int32_t gate_seq, tagged_rows;              // gated single-pair launch: the stamp `state->pad[1]` must carry; rows as tagged granules

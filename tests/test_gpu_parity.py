@@ -448,7 +448,8 @@ def test_register_batch_equals_one_by_one(ctx, pkg, ref_pairs):
 def test_gated_launches_give_the_same_registration(ctx, pkg):
     """The mechanisms that only move work around must not move a bit: gated launches (KSS_GATED=0 off), host stores into
     device memory (KSS_GATE_BAR=0 off: the re-publishing gate), chained launches (KSS_CHAIN=0: one launch per pass) and
-    the skip test of the fused pass (KSS_SKIN=-1: every source searches in every pass; 0.05 / 1.0: other skins).  Same
+    the skip test of the fused pass (KSS_SKIN=-1: every source searches in every pass; 0.05 / 1.0: other skins); nor may a
+    lost answer (the waiting kernel gives up, the pass is launched again).  Same
     registration, bit for bit, including runs that converge early (the waiting kernel is cancelled), fixed-length
     runs, a pair that needs the brute-force fallback, and a 100k pair (196 workgroups: the chained form of C2)."""
     import subprocess, sys, json
@@ -467,12 +468,17 @@ print("RESULT" + json.dumps(out))
 """ % ROOT
     res = {}
     variants = {"default": {}, "ungated": {"KSS_GATED": "0"}, "no_bar": {"KSS_GATE_BAR": "0"}, "unchained": {"KSS_CHAIN": "0"},
-                "no_skip": {"KSS_SKIN": "-1"}, "thin_skin": {"KSS_SKIN": "0.05"}, "thick_skin": {"KSS_SKIN": "1.0"}}
+                "no_skip": {"KSS_SKIN": "-1"}, "thin_skin": {"KSS_SKIN": "0.05"}, "thick_skin": {"KSS_SKIN": "1.0"},
+                # an answer that never arrives (a stalled host thread): the waiting kernel's bounded poll runs out, it leaves
+                # without having touched anything, and the pass is launched again as a plain one
+                "lost_answer": {"KSS_TEST_DROP_GATE": "7", "KSS_GATE_POLLS": "20000"},
+                "lost_answer_unchained": {"KSS_TEST_DROP_GATE": "5", "KSS_GATE_POLLS": "20000", "KSS_CHAIN": "0"}}
     for name, extra in variants.items():
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode == 0, name + r.stdout + r.stderr
         res[name] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT")][0][6:])
+        assert ("launched again" in r.stderr) == name.startswith("lost_answer"), name   # (the hook did fire, and only there)
     for name in variants:
         assert res[name] == res["default"], name
 
