@@ -324,19 +324,16 @@ __device__ __forceinline__ int block_walk(const GridParams& gp, const int32_t* _
     return total;
 }
 
-// One ROW of the 3x3x3 block per lane (phase B of grid_pass_kernel when a workgroup has few walkers: 16 lanes share a
-// walker, lanes 0-8 of the group take rows 0-8).  Same pruning rule and the same m1 / m2 bookkeeping as block_walk, but no
-// range queue and -- for the usual row of <= 8 points -- a single step: the serial instruction count of a search, which is
-// what a lone wave pays for, drops to less than half.
-template <bool FMA, int U>
-__device__ __forceinline__ void row_walk(const GridParams& gp, const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
-                                         float qx, float qy, float qz, int cx, int cy, int cz, float rho, int t,
-                                         unsigned long long& key, int& kpos, float& m1, float& m2) {
-    m1 = __builtin_inff();
-    m2 = __builtin_inff();
+// One ROW of the 3x3x3 block per lane -- or two (phase B of the fused pass when a workgroup has few walkers: 16 lanes share
+// a walker and lanes 0-8 of the group take rows 0-8, or 8 lanes share one and lane 0 also takes row 8).  Same pruning rule
+// and the same m1 / m2 bookkeeping as block_walk, but no range queue and -- for the usual <= U points -- a single step: the
+// serial instruction count of a search, which is what a lone wave pays for, drops to less than half.  t1 < 0: one row.
+__device__ __forceinline__ void row_range(const GridParams& gp, const int32_t* __restrict__ cell_start, float qx, float qy, float qz,
+                                          int cx, int cy, int cz, float rho, int t, int& lo, int& hi) {
+    lo = hi = 0;
     const int tz = t / 3, ty = t - 3 * tz;
     const int z = cz + tz - 1, y = cy + ty - 1;
-    if (!(t < 9 && z >= 0 && z < gp.gz && y >= 0 && y < gp.gy)) return;
+    if (!(t >= 0 && t < 9 && z >= 0 && z < gp.gz && y >= 0 && y < gp.gy)) return;
     const int4u v = *(const int4u*)(cell_start + (z * gp.gy + y) * gp.gx + cx - 1);
     const int s0 = cx > 0 ? v.x : v.y, s1 = v.y, s2 = v.z, s3 = cx + 1 < gp.gx ? v.w : v.z;
     const float exl = fmaxf((qx - (gp.ox + (float)cx * gp.h)) - gp.eps, 0.f), exr = fmaxf(((gp.ox + (float)(cx + 1) * gp.h) - qx) - gp.eps, 0.f);
@@ -346,19 +343,38 @@ __device__ __forceinline__ void row_walk(const GridParams& gp, const int32_t* __
     const float g2 = ey2 + ez2;
     if (rho < g2 * 0.999999f) return;
     const bool left = !(rho < (g2 + exl * exl) * 0.999999f), right = !(rho < (g2 + exr * exr) * 0.999999f);
-    const int lo = left ? s0 : s1, hi = right ? s3 : s2;
-    for (int k = lo; k < hi; k += U) {
+    lo = left ? s0 : s1;
+    hi = right ? s3 : s2;
+    if (hi < lo) hi = lo;
+}
+
+template <bool FMA, int U, bool TWO>
+__device__ __forceinline__ void row_walk(const GridParams& gp, const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
+                                         float qx, float qy, float qz, int cx, int cy, int cz, float rho, int t0, int t1,
+                                         unsigned long long& key, int& kpos, float& m1, float& m2) {
+    m1 = __builtin_inff();
+    m2 = __builtin_inff();
+    int lo0, hi0, lo1 = 0, hi1 = 0;
+    row_range(gp, cell_start, qx, qy, qz, cx, cy, cz, rho, t0, lo0, hi0);   // (both bound loads are issued before either is used)
+    if constexpr (TWO) row_range(gp, cell_start, qx, qy, qz, cx, cy, cz, rho, t1, lo1, hi1);
+    const int n0 = hi0 - lo0, total = n0 + (hi1 - lo1);
+    const int last = hi1 > lo1 ? hi1 - 1 : hi0 - 1;   // the point an exhausted slot repeats (masked below)
+    for (int e = 0; e < total; e += U) {
         int at[U];
         float4 pt[U];
 #pragma unroll
-        for (int j = 0; j < U; ++j) at[j] = min(k + j, hi - 1);
+        for (int j = 0; j < U; ++j) {
+            const int f = e + j;
+            if constexpr (TWO) at[j] = f >= total ? last : f < n0 ? lo0 + f : lo1 + (f - n0);
+            else at[j] = min(lo0 + f, hi0 - 1);
+        }
 #pragma unroll
         for (int j = 0; j < U; ++j) pt[j] = sorted[at[j]];
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const unsigned long long kk = point_key<FMA>(pt[j], qx, qy, qz);
             if (kk < key) { key = kk; kpos = at[j]; }
-            const float dd = k + j < hi ? __uint_as_float((unsigned)(kk >> 32)) : __builtin_inff();
+            const float dd = e + j < total ? __uint_as_float((unsigned)(kk >> 32)) : __builtin_inff();
             m2 = __builtin_amdgcn_fmed3f(m1, m2, dd);
             m1 = fminf(m1, dd);
         }
@@ -400,6 +416,167 @@ void launch_grid_build_pair(hipStream_t st, const float4* d_tgt, int nt, float4*
                        (const int32_t*)d_start, d_sorted, d_tmp);
     hipLaunchKernelGGL(grid_rank_fix_kernel, dim3(nbs), dim3(256), 0, st, (const float4*)d_tmp, ns, gp, (const int32_t*)d_start + ncells, nt,
                        d_src);
+}
+
+// Phase B of the fused pass (grid_pass_kernel, gridb_pass_kernel): the first lanes of the workgroup serve the `nwalk`
+// walkers whose lane numbers are in s_wl and whose requests are in their hand-over columns (s_ent), and overwrite every
+// column with the answer.  NT = threads of the workgroup, WQ = columns of the range queue.
+template <bool FMA, bool BATCH, int WQ, int NT>
+__device__ __forceinline__ void serve_walkers(const PassArgs& a, const GridPairDev& pr, const int32_t* __restrict__ cs,
+                                              const float4* __restrict__ sorted, int w, int nwalk, int2 (*rowq)[WQ],
+                                              unsigned (*s_ent)[PASS_BS], const unsigned short* s_wl) {
+#define KSS_STAMP(k) do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    enum { WK_X, WK_Y, WK_Z, WK_IDX, WK_D2, WK_R, WK_POS, WK_FL = WK_POS, WK_COLS };   // (position code in the request, flags in the answer: one column)
+    const GridParams& gp = pr.gp;
+    const int lane = threadIdx.x & 63;
+    // The lanes that serve share the walkers: each group of L lanes walks disjoint rows of one walker's 3x3x3 block (so
+    // "distinct points" still holds) and merges key / position / the two smallest distances by DPP -- the dependent chain of
+    // a search drops from ~4 walk steps to ~1, on lanes the compaction has left idle anyway.
+    // few walkers: one row per lane (16 lanes per walker) or one or two (8 lanes per walker, lane 0 also row 8): row_walk, no
+    // range queue; more walkers: 4 lanes or one lane per walker through block_walk and its WQ queue columns
+    const bool row16 = 16 * nwalk <= NT, row8 = !row16 && 8 * nwalk <= NT, rows = row16 || row8;
+    const int L = row16 ? 16 : row8 ? 8 : 4 * nwalk <= WQ ? 4 : 1;
+    const int nserve = rows ? NT : (WQ < NT ? WQ : NT);   // lanes that search
+    for (int rb = 0; rb < nwalk; rb += nserve / L)
+    if ((int)threadIdx.x < nserve && (int)(threadIdx.x & ~63u) < (nwalk - rb) * L) {   // wave-uniform
+        const int sub = (int)threadIdx.x & (L - 1);
+        const int wj = rb + (L == 16 ? (int)threadIdx.x >> 4 : L == 8 ? (int)threadIdx.x >> 3 : L == 4 ? (int)threadIdx.x >> 2 : (int)threadIdx.x);
+        const bool wk = wj < nwalk;
+        // rows by lane of a quad: {0, 2, 8}, {4, 6}, {1, 7}, {3, 5} (the corner rows 0, 2, 6, 8 are the ones most often pruned)
+        const unsigned rowmask = L == 1 ? 0x1ffu : sub == 0 ? 0x105u : sub == 1 ? 0x050u : sub == 2 ? 0x082u : 0x028u;
+        float wx = 0.f, wy = 0.f, wz = 0.f, wrho = __builtin_inff(), bnew = 0.f;
+        unsigned long long wkey = ~0ull;
+        int wpos = -1, owner = 0, evl = 0, rfin = 0;   // rfin: the shell the search ended with (0: it did not)
+        bool done = true, wfell = false;
+        if (wk) {
+            owner = (int)s_wl[wj];
+            wx = __uint_as_float(s_ent[WK_X][owner]); wy = __uint_as_float(s_ent[WK_Y][owner]); wz = __uint_as_float(s_ent[WK_Z][owner]);
+            wkey = ((unsigned long long)s_ent[WK_D2][owner] << 32) | (unsigned long long)s_ent[WK_IDX][owner];
+            wpos = (int)s_ent[WK_POS][owner];
+            wrho = __uint_as_float(s_ent[WK_R][owner]);
+            done = false;
+        }
+        if (wk) {
+            const int cx = cell_coord(wx, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(wy, gp.oy, gp.inv_h, gp.gy),
+                      cz = cell_coord(wz, gp.oz, gp.inv_h, gp.gz);
+            // ---- r = 1: the 3x3x3 block, pruned by rho ----
+            KSS_STAMP(5);
+            float m1, m2;
+            if (row16) row_walk<FMA, BATCH ? 4 : 8, false>(gp, cs, sorted, wx, wy, wz, cx, cy, cz, wrho, sub < 9 ? sub : -1, -1, wkey, wpos, m1, m2);
+            else if (row8) row_walk<FMA, BATCH ? 4 : 8, true>(gp, cs, sorted, wx, wy, wz, cx, cy, cz, wrho, sub, sub == 0 ? 8 : -1, wkey, wpos, m1, m2);
+            else evl = block_walk<FMA, WQ, BATCH ? 4 : 8>(gp, cs, sorted, wx, wy, wz, cx, cy, cz, wrho, rowmask, rowq, wkey, wpos, m1, m2);
+            if (L > 1) {   // (uniform) all lanes of a group are walkers of the same source: merge by DPP
+#define KSS_GROUP_MERGE(X)                                                                                                          \
+do {                                                                                                                            \
+    const unsigned olo = (unsigned)X((int)(unsigned)wkey), ohi = (unsigned)X((int)(unsigned)(wkey >> 32));                      \
+    const int opos = X(wpos);                                                                                                   \
+    const float o1 = __int_as_float(X(__float_as_int(m1))), o2 = __int_as_float(X(__float_as_int(m2)));                         \
+    const unsigned long long okey = ((unsigned long long)ohi << 32) | olo;                                                      \
+    if (okey < wkey) { wkey = okey; wpos = opos; }                                                                            \
+    m2 = fminf(fmaxf(m1, o1), fminf(m2, o2)); /* two smallest of the union of two sorted pairs */                               \
+    m1 = fminf(m1, o1);                                                                                                         \
+} while (0)
+                auto x1 = [](int v) { return __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, false); };   // quad_perm [1,0,3,2]
+                auto x2 = [](int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4e, 0xf, 0xf, false); };   // quad_perm [2,3,0,1]
+                // lane ^ 4: row_shl:4 into the lanes with bit 2 clear, row_shr:4 into the others; lane ^ 8: row_ror:8
+                auto x4 = [](int v) { const int r = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xf, 0x5, false); return __builtin_amdgcn_update_dpp(r, v, 0x114, 0xf, 0xa, false); };
+                auto x8 = [](int v) { return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false); };
+                KSS_GROUP_MERGE(x1);
+                KSS_GROUP_MERGE(x2);
+                if (L >= 8) KSS_GROUP_MERGE(x4);
+                if (L == 16) KSS_GROUP_MERGE(x8);
+#undef KSS_GROUP_MERGE
+            }
+            float face2 = __builtin_inff();    // squared distance to the faces of the block the search ended with
+            for (int r = 1; r <= gp.rcap; ++r) {
+                if (r > 1) {   // shell r: (2r+1)^2 rows
+                    const int wd = 2 * r + 1;
+                    const int x0 = max(cx - r, 0), x1 = min(cx + r, gp.gx - 1);
+                    for (int t = 0; t < wd * wd; ++t) {
+                        const int dz = t / wd - r, dy = t % wd - r;
+                        const int z = cz + dz, y = cy + dy;
+                        if (z < 0 || z >= gp.gz || y < 0 || y >= gp.gy) continue;
+                        const int row = (z * gp.gy + y) * gp.gx;
+                        if (dz == -r || dz == r || dy == -r || dy == r) {
+                            // a row on the shell's y/z faces: the whole x extent is new
+                            scan_range<FMA>(sorted, cs[row + x0], cs[row + x1 + 1], wx, wy, wz, wkey, wpos);
+                        } else {
+                            // interior row of shell r: only its two x end cells are new
+                            if (cx - r >= 0) scan_range<FMA>(sorted, cs[row + cx - r], cs[row + cx - r + 1], wx, wy, wz, wkey, wpos);
+                            if (cx + r < gp.gx) scan_range<FMA>(sorted, cs[row + cx + r], cs[row + cx + r + 1], wx, wy, wz, wkey, wpos);
+                        }
+                    }
+                }
+                const float best = __uint_as_float((unsigned)(wkey >> 32));
+                // distance from the query to the faces of the visited block; faces on the grid border are open
+                float b = __builtin_inff();
+                if (cx - r > 0) b = fminf(b, wx - (gp.ox + (float)(cx - r) * gp.h));
+                if (cx + r < gp.gx - 1) b = fminf(b, (gp.ox + (float)(cx + r + 1) * gp.h) - wx);
+                if (cy - r > 0) b = fminf(b, wy - (gp.oy + (float)(cy - r) * gp.h));
+                if (cy + r < gp.gy - 1) b = fminf(b, (gp.oy + (float)(cy + r + 1) * gp.h) - wy);
+                if (cz - r > 0) b = fminf(b, wz - (gp.oz + (float)(cz - r) * gp.h));
+                if (cz + r < gp.gz - 1) b = fminf(b, (gp.oz + (float)(cz + r + 1) * gp.h) - wz);
+                const float bs = b - gp.eps;
+                if (b == __builtin_inff()) done = true;                              // the whole grid has been visited
+                else if (bs > 0.f && best < bs * bs * 0.999999f) { done = true; face2 = bs * bs; }   // every unvisited point is strictly farther
+                if (done) { rfin = r; break; }
+            }
+            // What the r = 1 walk has proven about every target but the winner: walked ones are at computed distance >= m2,
+            // pruned ones beyond rho, unvisited ones beyond the block's faces.  (Shells r > 1 are not tracked: B = 0.)
+            if (done && rfin == 1 && wkey != ~0ull)
+                bnew = fminf(__builtin_amdgcn_sqrtf(fminf(fminf(m2, wrho), face2) * 0.99999f) * 0.999999f, 1e30f);
+        }
+        if constexpr (BATCH) {
+            // bounded fallback: brute force over the pair's targets for the lanes the shells did not resolve
+            if (__builtin_amdgcn_ballot_w64(!done) != 0ull) {              // wave-uniform
+                const float4* __restrict__ tp = a.tgt4 + pr.tgt_base;      // original order; uniform addresses below
+                for (int j = 0; j < pr.tgt_n; ++j) {
+                    const float4 q = tp[j];
+                    const float dx = wx - q.x, dy = wy - q.y, dz = wz - q.z;
+                    float d;
+                    if constexpr (FMA) d = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+                    else d = (dx * dx + dy * dy) + dz * dz;
+                    const unsigned long long kk = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(unsigned)j;
+                    if (!done && kk < wkey) { wkey = kk; wpos = -1; }   // (no position in `sorted` known: no warm start next time)
+                }
+                wfell = !done;
+                done = true;
+            }
+        }
+        if (wk && sub == 0) {              // (the lanes of a group agree on everything from the merge on)
+            bool whave = false;
+            float4 ww = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int io = pr.src_base + (w - pr.row_base) * PASS_BS + owner;
+            if (done) {
+                whave = wkey != ~0ull;
+                // the winner's coordinates: carried through the r = 1 walk (the shells beyond do not carry them: read back; after
+                // the in-wave sweep: read from the pair's target in original order)
+                if (whave) ww = wpos >= 0 ? sorted[wpos] : wpos == -2 ? a.nn_win[io] : a.tgt4[pr.tgt_base + (int)(unsigned)(wkey & 0xffffffffull)];
+            } else {   // single pair: resolved by the brute-force list pass through atomicMin, sums by the SEARCH = false launch
+                a.keys[io] = ~0ull;
+                const int ls = atomicAdd(a.list_count, 1);
+                a.list[ls] = io;
+                wfell = true;   // counted in column 19 of the row, as the batch counts its in-wave fallbacks
+            }
+            a.nn_win[io] = make_float4(ww.x, ww.y, ww.z, __uint_as_float(whave ? (unsigned)wkey : ~0u));
+            a.nn_state[io] = make_float2(wfell ? 0.f : bnew, 0.f);
+            s_ent[WK_X][owner] = __float_as_uint(ww.x); s_ent[WK_Y][owner] = __float_as_uint(ww.y); s_ent[WK_Z][owner] = __float_as_uint(ww.z);
+            s_ent[WK_IDX][owner] = (unsigned)wkey; s_ent[WK_D2][owner] = (unsigned)(wkey >> 32);
+            s_ent[WK_FL][owner] = (whave ? 1u : 0u) | (wfell ? 2u : 0u);
+            s_ent[WK_R][owner] = __float_as_uint(wfell ? 0.f : bnew);
+        }
+        KSS_STAMP(8);
+        if (a.stamps) {   // slot 10: evaluations, 11: evaluation slots issued (slowest lane, rounded up to 8, x 64)
+            int evs = evl, mx = evl;
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) { evs += __shfl_xor(evs, m, 64); mx = max(mx, __shfl_xor(mx, m, 64)); }
+            if (lane == 0) {
+                atomicAdd(&a.stamps[(size_t)blockIdx.x * 16 + 10], (unsigned long long)evs);
+                atomicAdd(&a.stamps[(size_t)blockIdx.x * 16 + 11], (unsigned long long)(((mx + 7) / 8) * 8 * 64));
+            }
+        }
+    }
+#undef KSS_STAMP
 }
 
 // =============================================================================================
@@ -461,9 +638,9 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
     // in its own column and its lane number in s_wl; the lanes of phase B overwrite the column with the answer {winner, key,
     // flags}.  A lane that keeps its winner writes the answer itself.  (Through LDS rather than registers: nothing but the
     // lane's identity stays live across the search, which is what lets four workgroups share a CU.)
-    __shared__ unsigned s_ent[8][BS];
+    __shared__ unsigned s_ent[7][BS];
     __shared__ unsigned short s_wl[BS];
-    enum { WK_X, WK_Y, WK_Z, WK_IDX, WK_D2, WK_POS, WK_R, WK_FL };
+    enum { WK_X, WK_Y, WK_Z, WK_IDX, WK_D2, WK_R, WK_POS, WK_FL = WK_POS, WK_COLS };   // (position code in the request, flags in the answer: one column)
     static_assert(sizeof(PairState) == 64, "the gated launch reads the transform record as 16 dwords");
     double (*shf)[NSUMS] = reinterpret_cast<double (*)[NSUMS]>(&rowq[0][0]);   // the last workgroup's group totals: rowq is dead by then (two barriers later)
     static_assert(sizeof(double) * PASS_FG * NSUMS <= sizeof(int2) * 9 * WQ, "shf must fit inside rowq");
@@ -653,9 +830,8 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
             const float4 c4 = walker ? make_float4(qx, qy, qz, 0.f) : prevp;
             s_ent[WK_X][threadIdx.x] = __float_as_uint(c4.x); s_ent[WK_Y][threadIdx.x] = __float_as_uint(c4.y); s_ent[WK_Z][threadIdx.x] = __float_as_uint(c4.z);
             s_ent[WK_IDX][threadIdx.x] = (unsigned)key; s_ent[WK_D2][threadIdx.x] = (unsigned)(key >> 32);
-            s_ent[WK_POS][threadIdx.x] = (unsigned)kpos;
+            s_ent[WK_POS][threadIdx.x] = walker ? (unsigned)kpos : fl;   // (a walker: where its last winner is; the others: their flags)
             s_ent[WK_R][threadIdx.x] = __float_as_uint(rho);
-            s_ent[WK_FL][threadIdx.x] = fl;
         }
         // compaction: walkers take consecutive slots (wave by wave in arrival order, lane order inside a wave)
         const unsigned long long wm = __builtin_amdgcn_ballot_w64(walker);
@@ -669,153 +845,7 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
         __syncthreads();
         const int nwalk = s_nwalk;
         if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + 12] = (unsigned long long)nwalk;
-        // Phase B: the first WQ lanes of the workgroup search for the walkers, WQ / L of them per round.  With few walkers
-        // L = 8 or 4 lanes share one: each walks its own rows of the 3x3x3 block (disjoint, so "distinct points" still
-        // holds) and the group merges key / position / the two smallest distances by DPP -- the dependent chain of a
-        // search drops from ~4 walk steps to ~1, on lanes the compaction has left idle anyway.
-        const bool row16 = 16 * nwalk <= BS;             // few walkers: one row per lane (row_walk)
-        const int L = row16 ? 16 : 8 * nwalk <= WQ ? 8 : 4 * nwalk <= WQ ? 4 : 1;
-        const int nserve = row16 ? BS : WQ;              // lanes that search (block_walk's range queue has WQ columns)
-        for (int rb = 0; rb < nwalk; rb += nserve / L)
-        if ((int)threadIdx.x < nserve && (int)(threadIdx.x & ~63u) < (nwalk - rb) * L) {   // wave-uniform
-            const int sub = (int)threadIdx.x & (L - 1);
-            const int wj = rb + (L == 16 ? (int)threadIdx.x >> 4 : L == 8 ? (int)threadIdx.x >> 3 : L == 4 ? (int)threadIdx.x >> 2 : (int)threadIdx.x);
-            const bool wk = wj < nwalk;
-            // rows by lane of a group of 8: row `sub`, lane 0 also row 8; of a quad: {0, 2, 8}, {4, 6}, {1, 7}, {3, 5} (the
-            // corner rows 0, 2, 6, 8 are the ones most often pruned)
-            const unsigned rowmask = L == 1 ? 0x1ffu : L == 8 ? (1u << sub) | (sub == 0 ? 0x100u : 0u)
-                                                     : sub == 0 ? 0x105u : sub == 1 ? 0x050u : sub == 2 ? 0x082u : 0x028u;
-            float wx = 0.f, wy = 0.f, wz = 0.f, wrho = __builtin_inff(), bnew = 0.f;
-            unsigned long long wkey = ~0ull;
-            int wpos = -1, owner = 0, evl = 0, rfin = 0;   // rfin: the shell the search ended with (0: it did not)
-            bool done = true, wfell = false;
-            if (wk) {
-                owner = (int)s_wl[wj];
-                wx = __uint_as_float(s_ent[WK_X][owner]); wy = __uint_as_float(s_ent[WK_Y][owner]); wz = __uint_as_float(s_ent[WK_Z][owner]);
-                wkey = ((unsigned long long)s_ent[WK_D2][owner] << 32) | (unsigned long long)s_ent[WK_IDX][owner];
-                wpos = (int)s_ent[WK_POS][owner];
-                wrho = __uint_as_float(s_ent[WK_R][owner]);
-                done = false;
-            }
-            if (wk) {
-                const int cx = cell_coord(wx, gp.ox, gp.inv_h, gp.gx), cy = cell_coord(wy, gp.oy, gp.inv_h, gp.gy),
-                          cz = cell_coord(wz, gp.oz, gp.inv_h, gp.gz);
-                // ---- r = 1: the 3x3x3 block, pruned by rho ----
-                KSS_STAMP(5);
-                float m1, m2;
-                if (row16) row_walk<FMA, BATCH ? 4 : 8>(gp, cs, sorted, wx, wy, wz, cx, cy, cz, wrho, sub, wkey, wpos, m1, m2);
-                else evl = block_walk<FMA, WQ, BATCH ? 4 : 8>(gp, cs, sorted, wx, wy, wz, cx, cy, cz, wrho, rowmask, rowq, wkey, wpos, m1, m2);
-                if (L > 1) {   // (uniform) all lanes of a group are walkers of the same source: merge by DPP
-#define KSS_GROUP_MERGE(X)                                                                                                          \
-    do {                                                                                                                            \
-        const unsigned olo = (unsigned)X((int)(unsigned)wkey), ohi = (unsigned)X((int)(unsigned)(wkey >> 32));                      \
-        const int opos = X(wpos);                                                                                                   \
-        const float o1 = __int_as_float(X(__float_as_int(m1))), o2 = __int_as_float(X(__float_as_int(m2)));                         \
-        const unsigned long long okey = ((unsigned long long)ohi << 32) | olo;                                                      \
-        if (okey < wkey) { wkey = okey; wpos = opos; }                                                                            \
-        m2 = fminf(fmaxf(m1, o1), fminf(m2, o2)); /* two smallest of the union of two sorted pairs */                               \
-        m1 = fminf(m1, o1);                                                                                                         \
-    } while (0)
-                    auto x1 = [](int v) { return __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, false); };   // quad_perm [1,0,3,2]
-                    auto x2 = [](int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4e, 0xf, 0xf, false); };   // quad_perm [2,3,0,1]
-                    // lane ^ 4: row_shl:4 into the lanes with bit 2 clear, row_shr:4 into the others; lane ^ 8: row_ror:8
-                    auto x4 = [](int v) { const int r = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xf, 0x5, false); return __builtin_amdgcn_update_dpp(r, v, 0x114, 0xf, 0xa, false); };
-                    auto x8 = [](int v) { return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false); };
-                    KSS_GROUP_MERGE(x1);
-                    KSS_GROUP_MERGE(x2);
-                    if (L >= 8) KSS_GROUP_MERGE(x4);
-                    if (L == 16) KSS_GROUP_MERGE(x8);
-#undef KSS_GROUP_MERGE
-                }
-                float face2 = __builtin_inff();    // squared distance to the faces of the block the search ended with
-                for (int r = 1; r <= gp.rcap; ++r) {
-                    if (r > 1) {   // shell r: (2r+1)^2 rows
-                        const int wd = 2 * r + 1;
-                        const int x0 = max(cx - r, 0), x1 = min(cx + r, gp.gx - 1);
-                        for (int t = 0; t < wd * wd; ++t) {
-                            const int dz = t / wd - r, dy = t % wd - r;
-                            const int z = cz + dz, y = cy + dy;
-                            if (z < 0 || z >= gp.gz || y < 0 || y >= gp.gy) continue;
-                            const int row = (z * gp.gy + y) * gp.gx;
-                            if (dz == -r || dz == r || dy == -r || dy == r) {
-                                // a row on the shell's y/z faces: the whole x extent is new
-                                scan_range<FMA>(sorted, cs[row + x0], cs[row + x1 + 1], wx, wy, wz, wkey, wpos);
-                            } else {
-                                // interior row of shell r: only its two x end cells are new
-                                if (cx - r >= 0) scan_range<FMA>(sorted, cs[row + cx - r], cs[row + cx - r + 1], wx, wy, wz, wkey, wpos);
-                                if (cx + r < gp.gx) scan_range<FMA>(sorted, cs[row + cx + r], cs[row + cx + r + 1], wx, wy, wz, wkey, wpos);
-                            }
-                        }
-                    }
-                    const float best = __uint_as_float((unsigned)(wkey >> 32));
-                    // distance from the query to the faces of the visited block; faces on the grid border are open
-                    float b = __builtin_inff();
-                    if (cx - r > 0) b = fminf(b, wx - (gp.ox + (float)(cx - r) * gp.h));
-                    if (cx + r < gp.gx - 1) b = fminf(b, (gp.ox + (float)(cx + r + 1) * gp.h) - wx);
-                    if (cy - r > 0) b = fminf(b, wy - (gp.oy + (float)(cy - r) * gp.h));
-                    if (cy + r < gp.gy - 1) b = fminf(b, (gp.oy + (float)(cy + r + 1) * gp.h) - wy);
-                    if (cz - r > 0) b = fminf(b, wz - (gp.oz + (float)(cz - r) * gp.h));
-                    if (cz + r < gp.gz - 1) b = fminf(b, (gp.oz + (float)(cz + r + 1) * gp.h) - wz);
-                    const float bs = b - gp.eps;
-                    if (b == __builtin_inff()) done = true;                              // the whole grid has been visited
-                    else if (bs > 0.f && best < bs * bs * 0.999999f) { done = true; face2 = bs * bs; }   // every unvisited point is strictly farther
-                    if (done) { rfin = r; break; }
-                }
-                // What the r = 1 walk has proven about every target but the winner: walked ones are at computed distance >= m2,
-                // pruned ones beyond rho, unvisited ones beyond the block's faces.  (Shells r > 1 are not tracked: B = 0.)
-                if (done && rfin == 1 && wkey != ~0ull)
-                    bnew = fminf(__builtin_amdgcn_sqrtf(fminf(fminf(m2, wrho), face2) * 0.99999f) * 0.999999f, 1e30f);
-            }
-            if constexpr (BATCH) {
-                // bounded fallback: brute force over the pair's targets for the lanes the shells did not resolve
-                if (__builtin_amdgcn_ballot_w64(!done) != 0ull) {              // wave-uniform
-                    const float4* __restrict__ tp = a.tgt4 + pr.tgt_base;      // original order; uniform addresses below
-                    for (int j = 0; j < pr.tgt_n; ++j) {
-                        const float4 q = tp[j];
-                        const float dx = wx - q.x, dy = wy - q.y, dz = wz - q.z;
-                        float d;
-                        if constexpr (FMA) d = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
-                        else d = (dx * dx + dy * dy) + dz * dz;
-                        const unsigned long long kk = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(unsigned)j;
-                        if (!done && kk < wkey) { wkey = kk; wpos = -1; }   // (no position in `sorted` known: no warm start next time)
-                    }
-                    wfell = !done;
-                    done = true;
-                }
-            }
-            if (wk && sub == 0) {              // (the lanes of a group agree on everything from the merge on)
-                bool whave = false;
-                float4 ww = make_float4(0.f, 0.f, 0.f, 0.f);
-                const int io = pr.src_base + (w - pr.row_base) * BS + owner;
-                if (done) {
-                    whave = wkey != ~0ull;
-                    // the winner's coordinates: carried through the r = 1 walk (the shells beyond do not carry them: read back; after
-                    // the in-wave sweep: read from the pair's target in original order)
-                    if (whave) ww = wpos >= 0 ? sorted[wpos] : wpos == -2 ? a.nn_win[io] : a.tgt4[pr.tgt_base + (int)(unsigned)(wkey & 0xffffffffull)];
-                } else {   // single pair: resolved by the brute-force list pass through atomicMin, sums by the SEARCH = false launch
-                    a.keys[io] = ~0ull;
-                    const int ls = atomicAdd(a.list_count, 1);
-                    a.list[ls] = io;
-                    wfell = true;   // counted in column 19 of the row, as the batch counts its in-wave fallbacks
-                }
-                a.nn_win[io] = make_float4(ww.x, ww.y, ww.z, __uint_as_float(whave ? (unsigned)wkey : ~0u));
-                a.nn_state[io] = make_float2(wfell ? 0.f : bnew, 0.f);
-                s_ent[WK_X][owner] = __float_as_uint(ww.x); s_ent[WK_Y][owner] = __float_as_uint(ww.y); s_ent[WK_Z][owner] = __float_as_uint(ww.z);
-                s_ent[WK_IDX][owner] = (unsigned)wkey; s_ent[WK_D2][owner] = (unsigned)(wkey >> 32);
-                s_ent[WK_FL][owner] = (whave ? 1u : 0u) | (wfell ? 2u : 0u);
-                s_ent[WK_R][owner] = __float_as_uint(wfell ? 0.f : bnew);
-            }
-            KSS_STAMP(8);
-            if (a.stamps) {   // slot 10: evaluations, 11: evaluation slots issued (slowest lane, rounded up to 8, x 64)
-                int evs = evl, mx = evl;
-#pragma unroll
-                for (int m = 32; m > 0; m >>= 1) { evs += __shfl_xor(evs, m, 64); mx = max(mx, __shfl_xor(mx, m, 64)); }
-                if (lane == 0) {
-                    atomicAdd(&a.stamps[(size_t)blockIdx.x * 16 + 10], (unsigned long long)evs);
-                    atomicAdd(&a.stamps[(size_t)blockIdx.x * 16 + 11], (unsigned long long)(((mx + 7) / 8) * 8 * 64));
-                }
-            }
-        }
+        serve_walkers<FMA, BATCH, WQ, BS>(a, pr, cs, sorted, w, nwalk, rowq, s_ent, s_wl);
         KSS_STAMP(15);
         __syncthreads();
         // Phase C: every lane reads its column
@@ -996,6 +1026,240 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
     }
     if (last_step) break;
     }   // passes of a chained launch
+#undef KSS_STAMP
+}
+
+// =============================================================================================
+// The batched form of the fused pass with TWO sources per lane: a workgroup of 256 threads (4 waves) serves the same
+// row of 512 sources as a 512-thread workgroup of grid_pass_kernel<BATCH = true>, same phases, same hand-over columns, same
+// sums in the same order -- lane l of wave v holds the sources that lane l of "waves" v and v + 4 hold there, and the wave
+// tree runs once per half -- so every bit of the result is the same.  Why: the batched pass is RESIDENCY-bound (a
+// workgroup's life is a chain of dependent memory round trips, ~12 us, while its instructions fit in ~1.5 us); with half
+// the waves per row twice as many rows are in flight per CU for the same registers.  WQ = columns of the range queue:
+// 256 for the first pass of a registration (every source searches), 128 afterwards (a few per cent do), which is what
+// lets five workgroups share a CU's LDS.
+// =============================================================================================
+#ifndef KSS_BATCH2_WAVES
+#define KSS_BATCH2_WAVES 5   // workgroups of 256 per CU the two-sources-per-lane form is compiled for (6: 80 VGPRs, 4 spilled: no faster)
+#endif
+template <bool FMA, bool FULL, int WQ>
+__global__ __launch_bounds__(256, KSS_BATCH2_WAVES) void gridb_pass_kernel(const PassArgs a) {
+#define KSS_STAMP(k) do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    KSS_STAMP(0);
+    constexpr int BS = PASS_BS, NT = 256, SPL = BS / NT;
+    static_assert(SPL == 2 && WQ <= NT, "two sources per lane");
+    const int per_xcd = (int)gridDim.x / 8;
+    const int w = ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8;
+    if (w >= a.total_rows) return;
+    const int pi = a.row_pair[w];
+    const GridPairDev pr = a.pairs[pi];
+    const PairState ps = a.state[pi];
+    if (!ps.active) return;
+    const GridParams& gp = pr.gp;
+    const int32_t* __restrict__ cs = a.cell_start + pr.cell_base;
+    const float4* __restrict__ sorted = a.sorted;
+    __shared__ int2 rowq[9][WQ];
+    __shared__ double shw[BS / 64][NSUMS];
+    __shared__ int s_last;
+    __shared__ int s_nwalk;
+    __shared__ unsigned s_ent[7][BS];
+    __shared__ unsigned short s_wl[BS];
+    enum { WK_X, WK_Y, WK_Z, WK_IDX, WK_D2, WK_R, WK_POS, WK_FL = WK_POS, WK_COLS };   // (position code in the request, flags in the answer: one column)
+    constexpr int SHF_ROWS = (int)(sizeof(int2) * 9 * WQ / (sizeof(double) * NSUMS));
+    static_assert(SHF_ROWS >= PASS_FG, "shf must fit inside rowq");
+    double (*shf)[NSUMS] = reinterpret_cast<double (*)[NSUMS]>(&rowq[0][0]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    bool valid[SPL];
+    int idx[SPL];
+    float4 p[SPL], prevp[SPL];
+    float2 st[SPL];
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+        const int slot = k * NT + (int)threadIdx.x;
+        const int local = (w - pr.row_base) * BS + slot;
+        valid[k] = local < pr.src_n;
+        idx[k] = pr.src_base + local;
+        p[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        prevp[k] = make_float4(0.f, 0.f, 0.f, __uint_as_float(~0u));
+        st[k] = make_float2(0.f, 0.f);
+        if (valid[k]) {
+            p[k] = a.src_in[idx[k]];
+            if (a.use_prev) { prevp[k] = a.nn_win[idx[k]]; st[k] = a.nn_state[idx[k]]; }
+        }
+    }
+    if (threadIdx.x == 0) s_nwalk = 0;
+    __syncthreads();
+    KSS_STAMP(13);
+    const bool last_known = a.chained == 2 && ps.pad[0] > 0;
+    const bool chained_k = a.chained == 1 || last_known;
+    // ---- phase A (see grid_pass_kernel) ----
+    bool walker[SPL];
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+        const int slot = k * NT + (int)threadIdx.x;
+        const int i = idx[k];
+        float pold_x = p[k].x, pold_y = p[k].y, pold_z = p[k].z;
+        if (last_known && valid[k]) {
+            const float4 pl = (ps.pad[0] == 1 ? a.src_last0 : a.src_last1)[i];
+            pold_x = pl.x; pold_y = pl.y; pold_z = pl.z;
+        }
+        if (valid[k]) {
+            if (ps.apply) {   // pcl transformCloud with the previous iteration's Matrix4f, Eigen order, float, no fma
+                const float x = p[k].x, y = p[k].y, z = p[k].z;
+                p[k].x = ((ps.m[0] * x + ps.m[1] * y) + ps.m[2] * z) + ps.m[3];
+                p[k].y = ((ps.m[4] * x + ps.m[5] * y) + ps.m[6] * z) + ps.m[7];
+                p[k].z = ((ps.m[8] * x + ps.m[9] * y) + ps.m[10] * z) + ps.m[11];
+            }
+            a.src_out[i] = p[k];
+        }
+        const float qx = p[k].x, qy = p[k].y, qz = p[k].z;
+        const bool qok = valid[k] && (qx - qx) == 0.f && (qy - qy) == 0.f && (qz - qz) == 0.f;
+        const bool has_prev = __float_as_uint(prevp[k].w) != ~0u;
+        unsigned long long key = ~0ull;
+        int kpos = -1;
+        float rho = __builtin_inff();
+        unsigned fl = 0u;
+        walker[k] = false;
+        if (qok) {
+            walker[k] = true;
+            if (has_prev) {
+                key = point_key<FMA>(prevp[k], qx, qy, qz);
+                kpos = -2;
+                const float d0 = __uint_as_float((unsigned)(key >> 32));
+                const float mx = qx - pold_x, my = qy - pold_y, mz = qz - pold_z;
+                const float moved = __builtin_amdgcn_sqrtf((mx * mx + my * my) + mz * mz);
+                const float acc = (st[k].y + moved) * 1.00001f;
+                const float room = st[k].x - acc;
+                if (chained_k && a.skin >= 0.f && room > 1e-7f && (room * room) * 0.99999f > d0) {
+                    walker[k] = false;
+                    fl = 1u;
+                    a.nn_state[i] = make_float2(st[k].x, acc);
+                } else {
+                    const float skin = fmaxf(a.skin, 0.f) * gp.h, grown = __builtin_amdgcn_sqrtf(d0) + skin;
+                    rho = !chained_k || moved * 4.f <= skin ? fmaxf(d0, grown * grown) : d0;
+                }
+            }
+        } else if (valid[k]) {
+            a.nn_win[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(~0u));
+            a.nn_state[i] = make_float2(0.f, 0.f);
+        }
+        const float4 c4 = walker[k] ? make_float4(qx, qy, qz, 0.f) : prevp[k];
+        s_ent[WK_X][slot] = __float_as_uint(c4.x); s_ent[WK_Y][slot] = __float_as_uint(c4.y); s_ent[WK_Z][slot] = __float_as_uint(c4.z);
+        s_ent[WK_IDX][slot] = (unsigned)key; s_ent[WK_D2][slot] = (unsigned)(key >> 32);
+        s_ent[WK_POS][slot] = walker[k] ? (unsigned)kpos : fl;
+        s_ent[WK_R][slot] = __float_as_uint(rho);
+        const unsigned long long wm = __builtin_amdgcn_ballot_w64(walker[k]);
+        if (wm != 0ull) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_nwalk, (int)__builtin_popcountll(wm));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (walker[k]) s_wl[base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(wm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)wm, 0u))] = (unsigned short)slot;
+        }
+    }
+    KSS_STAMP(14);
+    __syncthreads();
+    const int nwalk = s_nwalk;
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + 12] = (unsigned long long)nwalk;
+    serve_walkers<FMA, true, WQ, NT>(a, pr, cs, sorted, w, nwalk, rowq, s_ent, s_wl);
+    KSS_STAMP(15);
+    __syncthreads();
+    // ---- phase C + the row of this chunk in the canonical order: half k of the lanes plays waves 4k .. 4k + 3 ----
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+        const int slot = k * NT + (int)threadIdx.x;
+        const unsigned fl = s_ent[WK_FL][slot];
+        const bool have = (fl & 1u) != 0u, fell_back = (fl & 2u) != 0u;
+        const float4 win = make_float4(__uint_as_float(s_ent[WK_X][slot]), __uint_as_float(s_ent[WK_Y][slot]), __uint_as_float(s_ent[WK_Z][slot]), 0.f);
+        const unsigned long long key = ((unsigned long long)s_ent[WK_D2][slot] << 32) | (unsigned long long)s_ent[WK_IDX][slot];
+        const float qx = p[k].x, qy = p[k].y, qz = p[k].z;
+        float d2 = 0.f;
+        if (valid[k] && have) {
+            d2 = __uint_as_float((unsigned)(key >> 32));
+            const int oi = __float_as_int(p[k].w);
+            if (a.idx_out) a.idx_out[oi] = (int)(unsigned)(key & 0xffffffffull);
+            if (a.d2_out) a.d2_out[oi] = d2;
+        }
+        const double d2d = have ? (double)d2 : 0.0;
+        const bool kept = have && !(d2d > a.max_d2);
+        double col[16];
+        {
+            const double px = kept ? (double)qx : 0.0, py = kept ? (double)qy : 0.0, pz = kept ? (double)qz : 0.0;
+            const double tx = kept ? (double)win.x : 0.0, ty = kept ? (double)win.y : 0.0, tz = kept ? (double)win.z : 0.0;
+            col[0] = px; col[1] = py; col[2] = pz; col[3] = tx; col[4] = ty; col[5] = tz;
+            col[6] = px * tx; col[7] = px * ty; col[8] = px * tz;
+            col[9] = py * tx; col[10] = py * ty; col[11] = py * tz;
+            col[12] = pz * tx; col[13] = pz * ty; col[14] = pz * tz;
+            col[15] = kept ? d2d : 0.0;
+        }
+        wave_tree16(col);
+        const unsigned long long mk = __builtin_amdgcn_ballot_w64(kept), mf = __builtin_amdgcn_ballot_w64(fell_back);
+        double extra = 0.0;
+        if constexpr (FULL) extra = wave_tree2(d2d, have ? sqrt(d2d) : 0.0);
+        const int vw = k * (NT / 64) + wave;   // the wave this half plays
+        if ((lane & 15) == 0) {
+            const int q = lane >> 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) shw[vw][1 + 4 * q + j] = col[j];
+            if (lane == 0) {
+                shw[vw][0] = (double)__builtin_popcountll(mk);
+                shw[vw][NSUMS - 1] = (double)__builtin_popcountll(mf);
+                shw[vw][17] = extra;
+            }
+            if (lane == 32) shw[vw][18] = extra;
+        }
+    }
+    KSS_STAMP(1);
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x < NSUMS)
+#pragma unroll
+        for (int ww = 0; ww < BS / 64; ++ww) r += shw[ww][threadIdx.x];
+    KSS_STAMP(2);
+    double v = 0.0 + r;
+    if (pr.n_rows > 1) {
+        if (threadIdx.x < NSUMS) {
+            __hip_atomic_store(&a.rows[(int64_t)w * NSUMS + threadIdx.x], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = atomicAdd(&a.tickets[pi], 1) == pr.n_rows - 1;
+        __syncthreads();
+        KSS_STAMP(3);
+        if (!s_last) return;
+        // pair total as in grid_pass_kernel: (group g, column c) adds rows g, g + 25, ...; the 25 group totals in order
+        {
+            const double* __restrict__ rows = a.rows + (int64_t)pr.row_base * NSUMS;
+            for (int t = (int)threadIdx.x; t < PASS_FG * NSUMS; t += NT) {
+                const int g = t / NSUMS, c = t % NSUMS;
+                double acc = 0.0;
+                for (int k = g; k < pr.n_rows; k += 8 * PASS_FG) {
+                    double tt[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        tt[j] = k + j * PASS_FG < pr.n_rows ? __hip_atomic_load(&rows[(int64_t)(k + j * PASS_FG) * NSUMS + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc += tt[j];
+                }
+                shf[g][c] = acc;
+            }
+        }
+        __syncthreads();
+        v = 0.0;
+        if (threadIdx.x < NSUMS)
+            for (int gg = 0; gg < PASS_FG; ++gg) v += shf[gg][threadIdx.x];
+        if (threadIdx.x == 0) a.tickets[pi] = 0;
+    }
+    if (threadIdx.x < NSUMS) {
+        if (!FULL && (threadIdx.x == 17 || threadIdx.x == 18)) v = 0.0;
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const unsigned long long vb = (unsigned long long)__double_as_longlong(v);
+        u32x4 o;
+        o.x = (unsigned)vb; o.y = (unsigned)(vb >> 32); o.z = (unsigned)a.seq; o.w = (unsigned)(a.seq >> 32);
+        unsigned long long* dst = a.pub + 2 * ((int64_t)pi * NSUMS + threadIdx.x);
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(o) : "memory");
+        KSS_STAMP(4);
+    }
 #undef KSS_STAMP
 }
 
@@ -1306,8 +1570,24 @@ void launch_grid_pass(hipStream_t st, bool fma, bool full, bool batch, bool sear
     if (!search) {   // sums-only relaunch after the list pass: single pair, all 20 sums
         if (fma) KSS_PASS(true, true, false, false); else KSS_PASS(false, true, false, false);
     } else if (batch) {
-        if (fma) { if (full) KSS_PASS(true, true, true, true); else KSS_PASS(true, false, true, true); }
-        else     { if (full) KSS_PASS(false, true, true, true); else KSS_PASS(false, false, true, true); }
+        // two sources per lane (gridb_pass_kernel); the first pass of a registration (every source searches) with the wide
+        // range queue.  KSS_BATCH_OLD: the one-source-per-lane form of grid_pass_kernel (A/B; same bits).
+        static const bool old_form = getenv("KSS_BATCH_OLD") != nullptr;
+        if (old_form) {
+            if (fma) { if (full) KSS_PASS(true, true, true, true); else KSS_PASS(true, false, true, true); }
+            else     { if (full) KSS_PASS(false, true, true, true); else KSS_PASS(false, false, true, true); }
+        } else {
+            const dim3 block2(256);
+#define KSS_PASSB(F, U, Q) hipLaunchKernelGGL((gridb_pass_kernel<F, U, Q>), grid, block2, 0, st, a)
+            if (!a.use_prev) {
+                if (fma) { if (full) KSS_PASSB(true, true, 256); else KSS_PASSB(true, false, 256); }
+                else     { if (full) KSS_PASSB(false, true, 256); else KSS_PASSB(false, false, 256); }
+            } else {
+                if (fma) { if (full) KSS_PASSB(true, true, 128); else KSS_PASSB(true, false, 128); }
+                else     { if (full) KSS_PASSB(false, true, 128); else KSS_PASSB(false, false, 128); }
+            }
+#undef KSS_PASSB
+        }
     } else if (a.chain_len > 1) {
         if (fma) { if (full) KSS_CHAIN(true, true); else KSS_CHAIN(true, false); }
         else     { if (full) KSS_CHAIN(false, true); else KSS_CHAIN(false, false); }

@@ -7,7 +7,7 @@ seq=[(int(r["Start_Timestamp"]),int(r["End_Timestamp"]),r["Kernel_Name"][:50]) f
 out=[]
 prev=None
 for s,e,k in seq:
-    if "grid_pass_kernel" in k:
+    if "grid_pass_kernel" in k or "gridb_pass_kernel" in k:
         if prev is not None: out.append(((s-prev)/1e3,(e-s)/1e3))
         prev=e
     else:

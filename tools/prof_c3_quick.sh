@@ -6,7 +6,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/pc3
 python3 - <<'PY'
 import csv, glob
 f = glob.glob('gpurun_out/pc3q/**/*kernel_trace.csv', recursive=True)[0]
-rows = [r for r in csv.DictReader(open(f)) if 'grid_pass' in r['Kernel_Name']]
+rows = [r for r in csv.DictReader(open(f)) if 'grid_pass' in r['Kernel_Name'] or 'gridb_pass' in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 d = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1000 for r in rows]
 print("grid_pass launches:", len(d))
