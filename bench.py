@@ -246,9 +246,12 @@ def secondary_legs(pkg, ctx, torch, np):
     out["c3"] = {"workload": "C3: %d independent %dx%d pairs in one kss_icp_batch_dev call, %d fixed ICP iterations + fitness pass, setup included" % (npairs, n, n, iters),
                  "ms_per_batch": dt * 1e3, "pair_iterations_per_sec": npairs * iters / dt, "registrations_per_sec": npairs / dt,
                  "correspondences_per_sec": npairs * n * (iters + 1) / dt,
-                 "kernel": "grid_pass_kernel (batch)", "avg_launch_ms": kms, "launches": kn, "bound": "vector-memory pipe / L2 latency",
+                 "kernel": "gridb_pass_kernel", "avg_launch_ms": kms, "launches": kn,
+                 "bound": "residency / HBM (64 B of traffic per source and pass: float4 source in and out, winner, skip state)",
                  "queries_per_sec_in_kernel": npairs * n / (kms * 1e-3) if kms else None,
                  "compulsory_bytes_per_launch": comp, "frac_of_hbm_peak": comp / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if kms else None,
+                 "traffic": read_traffic("gridb_pass"),
+                 "frac_by_pmc_traffic": (read_traffic("gridb_pass") / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (kms and read_traffic("gridb_pass")) else None,
                  "result_iterations": int(res[0].iterations)}
     del d_src, d_tgt, src, tgt
 
