@@ -434,7 +434,9 @@ __device__ __forceinline__ void serve_walkers(const PassArgs& a, const GridPairD
     // a search drops from ~4 walk steps to ~1, on lanes the compaction has left idle anyway.
     // few walkers: one row per lane (16 lanes per walker) or one or two (8 lanes per walker, lane 0 also row 8): row_walk, no
     // range queue; more walkers: 4 lanes or one lane per walker through block_walk and its WQ queue columns
-    const bool row16 = 16 * nwalk <= NT, row8 = !row16 && 8 * nwalk <= NT, rows = row16 || row8;
+    // (the 8-lane row form only in the batch kernels: inlined into the single-pair kernels as a third walk body it cost C2 5 %
+    // -- 78.1k vs 74.0k iterations/s on one box -- for a case, 33-64 walkers in a workgroup, that C2 never sees)
+    const bool row16 = 16 * nwalk <= NT, row8 = BATCH && !row16 && 8 * nwalk <= NT, rows = row16 || row8;
     const int L = row16 ? 16 : row8 ? 8 : 4 * nwalk <= WQ ? 4 : 1;
     const int nserve = rows ? NT : (WQ < NT ? WQ : NT);   // lanes that search
     for (int rb = 0; rb < nwalk; rb += nserve / L)
@@ -463,7 +465,7 @@ __device__ __forceinline__ void serve_walkers(const PassArgs& a, const GridPairD
             KSS_STAMP(5);
             float m1, m2;
             if (row16) row_walk<FMA, BATCH ? 4 : 8, false>(gp, cs, sorted, wx, wy, wz, cx, cy, cz, wrho, sub < 9 ? sub : -1, -1, wkey, wpos, m1, m2);
-            else if (row8) row_walk<FMA, BATCH ? 4 : 8, true>(gp, cs, sorted, wx, wy, wz, cx, cy, cz, wrho, sub, sub == 0 ? 8 : -1, wkey, wpos, m1, m2);
+            else if (BATCH && row8) row_walk<FMA, BATCH ? 4 : 8, true>(gp, cs, sorted, wx, wy, wz, cx, cy, cz, wrho, sub, sub == 0 ? 8 : -1, wkey, wpos, m1, m2);
             else evl = block_walk<FMA, WQ, BATCH ? 4 : 8>(gp, cs, sorted, wx, wy, wz, cx, cy, cz, wrho, rowmask, rowq, wkey, wpos, m1, m2);
             if (L > 1) {   // (uniform) all lanes of a group are walkers of the same source: merge by DPP
 #define KSS_GROUP_MERGE(X)                                                                                                          \
