@@ -421,7 +421,7 @@ void launch_grid_build_pair(hipStream_t st, const float4* d_tgt, int nt, float4*
 // Phase B of the fused pass (grid_pass_kernel, gridb_pass_kernel): the first lanes of the workgroup serve the `nwalk`
 // walkers whose lane numbers are in s_wl and whose requests are in their hand-over columns (s_ent), and overwrite every
 // column with the answer.  NT = threads of the workgroup, WQ = columns of the range queue.
-template <bool FMA, bool BATCH, int WQ, int NT>
+template <bool FMA, bool BATCH, int WQ, int NT, int U>
 __device__ __forceinline__ void serve_walkers(const PassArgs& a, const GridPairDev& pr, const int32_t* __restrict__ cs,
                                               const float4* __restrict__ sorted, int w, int nwalk, int2 (*rowq)[WQ],
                                               unsigned (*s_ent)[PASS_BS], const unsigned short* s_wl) {
@@ -464,9 +464,9 @@ __device__ __forceinline__ void serve_walkers(const PassArgs& a, const GridPairD
             // ---- r = 1: the 3x3x3 block, pruned by rho ----
             KSS_STAMP(5);
             float m1, m2;
-            if (row16) row_walk<FMA, BATCH ? 4 : 8, false>(gp, cs, sorted, wx, wy, wz, cx, cy, cz, wrho, sub < 9 ? sub : -1, -1, wkey, wpos, m1, m2);
-            else if (BATCH && row8) row_walk<FMA, BATCH ? 4 : 8, true>(gp, cs, sorted, wx, wy, wz, cx, cy, cz, wrho, sub, sub == 0 ? 8 : -1, wkey, wpos, m1, m2);
-            else evl = block_walk<FMA, WQ, BATCH ? 4 : 8>(gp, cs, sorted, wx, wy, wz, cx, cy, cz, wrho, rowmask, rowq, wkey, wpos, m1, m2);
+            if (row16) row_walk<FMA, U, false>(gp, cs, sorted, wx, wy, wz, cx, cy, cz, wrho, sub < 9 ? sub : -1, -1, wkey, wpos, m1, m2);
+            else if (BATCH && row8) row_walk<FMA, U, true>(gp, cs, sorted, wx, wy, wz, cx, cy, cz, wrho, sub, sub == 0 ? 8 : -1, wkey, wpos, m1, m2);
+            else evl = block_walk<FMA, WQ, U>(gp, cs, sorted, wx, wy, wz, cx, cy, cz, wrho, rowmask, rowq, wkey, wpos, m1, m2);
             if (L > 1) {   // (uniform) all lanes of a group are walkers of the same source: merge by DPP
 #define KSS_GROUP_MERGE(X)                                                                                                          \
 do {                                                                                                                            \
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
         __syncthreads();
         const int nwalk = s_nwalk;
         if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + 12] = (unsigned long long)nwalk;
-        serve_walkers<FMA, BATCH, WQ, BS>(a, pr, cs, sorted, w, nwalk, rowq, s_ent, s_wl);
+        serve_walkers<FMA, BATCH, WQ, BS, BATCH ? 4 : 8>(a, pr, cs, sorted, w, nwalk, rowq, s_ent, s_wl);
         KSS_STAMP(15);
         __syncthreads();
         // Phase C: every lane reads its column
@@ -1163,7 +1163,8 @@ __global__ __launch_bounds__(256, KSS_BATCH2_WAVES) void gridb_pass_kernel(const
     __syncthreads();
     const int nwalk = s_nwalk;
     if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + 12] = (unsigned long long)nwalk;
-    serve_walkers<FMA, true, WQ, NT>(a, pr, cs, sorted, w, nwalk, rowq, s_ent, s_wl);
+    // (points in flight per walk step: 8 in the first pass, whose wide range queue leaves four workgroups per CU anyway)
+    serve_walkers<FMA, true, WQ, NT, WQ == 256 ? 8 : 4>(a, pr, cs, sorted, w, nwalk, rowq, s_ent, s_wl);
     KSS_STAMP(15);
     __syncthreads();
     // ---- phase C + the row of this chunk in the canonical order: half k of the lanes plays waves 4k .. 4k + 3 ----
