@@ -639,7 +639,7 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
     // per-lane hand-over columns.  A walker leaves its request {query, key and position of the last winner, pruning radius}
     // in its own column and its lane number in s_wl; the lanes of phase B overwrite the column with the answer {winner, key,
     // flags}.  A lane that keeps its winner writes the answer itself.  (Through LDS rather than registers: nothing but the
-    // lane's identity stays live across the search, which is what lets four workgroups share a CU.)
+    // lane's identity stays live across the search: registers are what limits how many workgroups share a CU.)
     __shared__ unsigned s_ent[7][BS];
     __shared__ unsigned short s_wl[BS];
     enum { WK_X, WK_Y, WK_Z, WK_IDX, WK_D2, WK_R, WK_POS, WK_FL = WK_POS, WK_COLS };   // (position code in the request, flags in the answer: one column)
