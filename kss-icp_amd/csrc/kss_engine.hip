@@ -400,10 +400,14 @@ static int grid_setup_batch(kss_ctx* c, IcpPlan& pl) {
     KCHK(ensure(c, c->g_rowpair, pl.row_pair.size() * sizeof(int32_t)));
     HIPCHK(c, hipMemcpyAsync(c->g_rowpair.p, pl.row_pair.data(), pl.row_pair.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     static const bool no_lds = getenv("KSS_GRIDB_NOLDS") != nullptr;   // A/B switch: always the global-atomic build
-    if (most_cells <= gridb_lds_max_cells() && !no_lds) {
+    bool half = true;   // 16-bit counters: counts and in-pair positions of every pair fit
+    for (int p = 0; p < np; ++p) half = half && pl.g[p].nt < 65536 && pl.g[p].ns < 65536;
+    static const bool no_half = getenv("KSS_GRIDB_NOHALF") != nullptr;   // A/B switch: 32-bit counters
+    if (no_half) half = false;
+    if (most_cells <= gridb_lds_max_cells(half) && !no_lds) {
         // every pair's counters fit a CU's LDS: one workgroup per pair builds both of its lists (kss_grid.hip)
         launch_gridb_build_lds(c->stream, (const float4*)c->tgt4.p, (float4*)c->src0.p, (float4*)c->cur[0].p, (const GridPairDev*)c->g_pairs.p, np,
-                               (int32_t*)c->g_start.p + 1, (float4*)c->g_sorted.p);
+                               (int32_t*)c->g_start.p + 1, (float4*)c->g_sorted.p, (int)most_cells, half);
     } else {
         // (zero at rest, as the single-pair build expects of this buffer: a plain ensure() here once left the slack behind
         // `cells` uninitialised, and a later single pair with more cells scanned garbage counts -- see DESIGN.md, incidents)

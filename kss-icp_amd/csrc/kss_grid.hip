@@ -1398,16 +1398,38 @@ void launch_gridb_sort_sources(hipStream_t st, const float4* d_src, int total_sr
 constexpr int GB_THREADS = 1024;
 constexpr int GB_MAX_CELLS = 36 * 1024;   // 144 KB of counters (+ the scan's wave totals): one workgroup per CU
 
-int gridb_lds_max_cells() { return GB_MAX_CELLS; }
+int gridb_lds_max_cells(bool half) { return half ? 2 * GB_MAX_CELLS : GB_MAX_CELLS; }   // (half: 16-bit counters, CellCounters)
 
-// exclusive scan of cnt[0 .. n) in place by the whole workgroup; returns the total in every thread.
+// The per-pair counters of gridb_build_pair_kernel, in dynamic LDS sized for the batch's largest grid.  HALF: 16-bit
+// counters (every pair of the batch has fewer than 65536 targets and sources, so counts and positions fit) -- half the LDS,
+// two workgroups per CU at C3 instead of one.  Plain reads and writes address the halves directly (ds_read_u16 /
+// ds_write_b16); the atomics go through the containing 32-bit word (no carry: a half never reaches 65536).
+template <bool HALF>
+struct CellCounters {
+    unsigned int* w;
+    __device__ __forceinline__ int get(int c) const { return HALF ? (int)reinterpret_cast<const unsigned short*>(w)[c] : (int)w[c]; }
+    __device__ __forceinline__ void set(int c, int v) const {
+        if (HALF) reinterpret_cast<unsigned short*>(w)[c] = (unsigned short)v; else w[c] = (unsigned)v;
+    }
+    __device__ __forceinline__ int add1(int c) const {   // returns the value before
+        if (HALF) { const int sh = 16 * (c & 1); return (int)((atomicAdd(&w[c >> 1], 1u << sh) >> sh) & 0xffffu); }
+        return (int)atomicAdd(&w[c], 1u);
+    }
+    __device__ __forceinline__ void zero(int ncells) const {
+        const int nw = HALF ? (ncells + 1) / 2 : ncells;
+        for (int c = threadIdx.x; c < nw; c += GB_THREADS) w[c] = 0u;
+    }
+};
+
+// exclusive scan of the counters [0 .. n) in place by the whole workgroup; returns the total in every thread.
 // store_global != nullptr: also writes base + start to store_global[c] and base + total to store_global[n].
-__device__ __forceinline__ int lds_exclusive_scan(int32_t* cnt, int n, int32_t* wave_tot, int32_t* __restrict__ store_global, int base) {
+template <bool HALF>
+__device__ __forceinline__ int lds_exclusive_scan(const CellCounters<HALF>& cnt, int n, int32_t* wave_tot, int32_t* __restrict__ store_global, int base) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int chunk = (n + GB_THREADS - 1) / GB_THREADS;
+    const int chunk = ((n + GB_THREADS - 1) / GB_THREADS + 1) & ~1;   // even: a thread owns whole words of 16-bit counters
     const int lo = min(tid * chunk, n), hi = min(lo + chunk, n);
     int s = 0;
-    for (int c = lo; c < hi; ++c) s += cnt[c];
+    for (int c = lo; c < hi; ++c) s += cnt.get(c);
     int incl = s;   // inclusive scan of the per-thread totals inside the wave
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -1424,8 +1446,8 @@ __device__ __forceinline__ int lds_exclusive_scan(int32_t* cnt, int n, int32_t* 
     }
     int run = woff + incl - s;
     for (int c = lo; c < hi; ++c) {
-        const int v = cnt[c];
-        cnt[c] = run;
+        const int v = cnt.get(c);
+        cnt.set(c, run);
         if (store_global) store_global[c] = base + run;
         run += v;
     }
@@ -1434,11 +1456,13 @@ __device__ __forceinline__ int lds_exclusive_scan(int32_t* cnt, int n, int32_t* 
     return total;
 }
 
+template <bool HALF>
 __global__ __launch_bounds__(GB_THREADS) void gridb_build_pair_kernel(const float4* __restrict__ tgt4, const float4* src_in, float4* src_tmp,
                                                                       float4* src_out, const GridPairDev* __restrict__ pairs,
                                                                       int32_t* __restrict__ cell_start, float4* __restrict__ sorted) {
-    __shared__ int32_t cnt[GB_MAX_CELLS];
+    extern __shared__ unsigned int gb_dyn[];
     __shared__ int32_t wave_tot[GB_THREADS / 64];
+    const CellCounters<HALF> cnt{gb_dyn};
     const GridPairDev pr = pairs[blockIdx.x];
     const GridParams& gp = pr.gp;
     const int ncells = gp.gx * gp.gy * gp.gz;
@@ -1450,7 +1474,7 @@ __global__ __launch_bounds__(GB_THREADS) void gridb_build_pair_kernel(const floa
     // atomics follow (one load, one atomic per trip was a chain of ~10 memory round trips per pass, 130 us per pair).
     constexpr int GB_U = 8;
     // ---- targets ----
-    for (int c = tid; c < ncells; c += GB_THREADS) cnt[c] = 0;
+    cnt.zero(ncells);
     __syncthreads();
     const float4* __restrict__ tp = tgt4 + pr.tgt_base;
     for (int k0 = tid; k0 < pr.tgt_n; k0 += GB_THREADS * GB_U) {
@@ -1459,10 +1483,10 @@ __global__ __launch_bounds__(GB_THREADS) void gridb_build_pair_kernel(const floa
         for (int u = 0; u < GB_U; ++u) p[u] = tp[min(k0 + u * GB_THREADS, pr.tgt_n - 1)];
 #pragma unroll
         for (int u = 0; u < GB_U; ++u)
-            if (k0 + u * GB_THREADS < pr.tgt_n) atomicAdd(&cnt[cell_of(p[u])], 1);
+            if (k0 + u * GB_THREADS < pr.tgt_n) cnt.add1(cell_of(p[u]));
     }
     __syncthreads();
-    lds_exclusive_scan(cnt, ncells, wave_tot, cell_start + pr.cell_base, pr.sorted_base);
+    lds_exclusive_scan<HALF>(cnt, ncells, wave_tot, cell_start + pr.cell_base, pr.sorted_base);
     float4* __restrict__ so = sorted + pr.sorted_base;
     for (int k0 = tid; k0 < pr.tgt_n; k0 += GB_THREADS * GB_U) {
         float4 p[GB_U];
@@ -1472,7 +1496,7 @@ __global__ __launch_bounds__(GB_THREADS) void gridb_build_pair_kernel(const floa
         for (int u = 0; u < GB_U; ++u) {
             const int k = k0 + u * GB_THREADS;
             if (k < pr.tgt_n) {
-                const int pos = atomicAdd(&cnt[cell_of(p[u])], 1);   // the start array doubles as the cursor
+                const int pos = cnt.add1(cell_of(p[u]));   // the start array doubles as the cursor
                 p[u].w = __int_as_float(k);
                 so[pos] = p[u];
             }
@@ -1480,7 +1504,7 @@ __global__ __launch_bounds__(GB_THREADS) void gridb_build_pair_kernel(const floa
     }
     __syncthreads();
     // ---- sources: same cells ----
-    for (int c = tid; c < ncells; c += GB_THREADS) cnt[c] = 0;
+    cnt.zero(ncells);
     __syncthreads();
     const float4* sp = src_in + pr.src_base;
     for (int k0 = tid; k0 < pr.src_n; k0 += GB_THREADS * GB_U) {
@@ -1489,10 +1513,10 @@ __global__ __launch_bounds__(GB_THREADS) void gridb_build_pair_kernel(const floa
         for (int u = 0; u < GB_U; ++u) p[u] = sp[min(k0 + u * GB_THREADS, pr.src_n - 1)];
 #pragma unroll
         for (int u = 0; u < GB_U; ++u)
-            if (k0 + u * GB_THREADS < pr.src_n) atomicAdd(&cnt[cell_of(p[u])], 1);
+            if (k0 + u * GB_THREADS < pr.src_n) cnt.add1(cell_of(p[u]));
     }
     __syncthreads();
-    lds_exclusive_scan(cnt, ncells, wave_tot, nullptr, 0);
+    lds_exclusive_scan<HALF>(cnt, ncells, wave_tot, nullptr, 0);
     float4* tmp = src_tmp + pr.src_base;
     for (int k0 = tid; k0 < pr.src_n; k0 += GB_THREADS * GB_U) {
         float4 p[GB_U];
@@ -1502,7 +1526,7 @@ __global__ __launch_bounds__(GB_THREADS) void gridb_build_pair_kernel(const floa
         for (int u = 0; u < GB_U; ++u) {
             const int k = k0 + u * GB_THREADS;
             if (k < pr.src_n) {
-                const int pos = atomicAdd(&cnt[cell_of(p[u])], 1);   // afterwards cnt[c] = END of cell c = start of cell c + 1
+                const int pos = cnt.add1(cell_of(p[u]));   // afterwards the counter of cell c = END of cell c = start of cell c + 1
                 p[u].w = __int_as_float(pr.src_base + k);
                 tmp[pos] = p[u];
             }
@@ -1519,7 +1543,7 @@ __global__ __launch_bounds__(GB_THREADS) void gridb_build_pair_kernel(const floa
         for (int u = 0; u < GB_U; ++u) {
             if (j0 + u * GB_THREADS >= pr.src_n) continue;
             const int c = cell_of(p[u]);
-            const int lo = c > 0 ? cnt[c - 1] : 0, hi = cnt[c];
+            const int lo = c > 0 ? cnt.get(c - 1) : 0, hi = cnt.get(c);
             const int me = __float_as_int(p[u].w);
             int rank = 0;
             for (int k = lo; k < hi; ++k) rank += __float_as_int(tmp[k].w) < me ? 1 : 0;
@@ -1528,10 +1552,24 @@ __global__ __launch_bounds__(GB_THREADS) void gridb_build_pair_kernel(const floa
     }
 }
 
+// max_cells: the largest grid of the batch; half: no pair has 65536 or more targets or sources
 void launch_gridb_build_lds(hipStream_t st, const float4* d_tgt4, float4* d_src, float4* d_tmp, const GridPairDev* d_pairs, int npairs,
-                            int32_t* d_cell_start, float4* d_sorted) {
-    hipLaunchKernelGGL(gridb_build_pair_kernel, dim3(npairs), dim3(GB_THREADS), 0, st, d_tgt4, (const float4*)d_src, d_tmp, d_src, d_pairs,
-                       d_cell_start, d_sorted);
+                            int32_t* d_cell_start, float4* d_sorted, int max_cells, bool half) {
+    const size_t bytes = half ? (size_t)((max_cells + 1) / 2) * 4 : (size_t)max_cells * 4;
+    static const bool attr_set = [] {   // dynamic LDS beyond 64 KB has to be allowed once per kernel
+        const int most = GB_MAX_CELLS * 4;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gridb_build_pair_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gridb_build_pair_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
+        (void)hipGetLastError();
+        return true;
+    }();
+    (void)attr_set;
+    if (half)
+        hipLaunchKernelGGL(gridb_build_pair_kernel<true>, dim3(npairs), dim3(GB_THREADS), bytes, st, d_tgt4, (const float4*)d_src, d_tmp, d_src, d_pairs,
+                           d_cell_start, d_sorted);
+    else
+        hipLaunchKernelGGL(gridb_build_pair_kernel<false>, dim3(npairs), dim3(GB_THREADS), bytes, st, d_tgt4, (const float4*)d_src, d_tmp, d_src, d_pairs,
+                           d_cell_start, d_sorted);
 }
 
 // statistics for the roofline statement: evaluations of one r = 1 pass and occupied cells (profiling only)

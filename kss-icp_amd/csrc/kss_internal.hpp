@@ -185,10 +185,11 @@ void launch_gridb_build_targets(hipStream_t st, const float4* d_tgt, int total_t
                                 int total_cells, int32_t* d_counts, int32_t* d_start, int32_t* d_block_sums, float4* d_sorted);
 void launch_gridb_sort_sources(hipStream_t st, const float4* d_src, int total_src, const GridPairDev* d_pairs, int npairs,
                                int total_cells, int32_t* d_counts, int32_t* d_start, int32_t* d_block_sums, float4* d_tmp, float4* d_out);
-int gridb_lds_max_cells();
-// all of a batch's cell lists, one workgroup per pair, counters in LDS (every pair must have <= gridb_lds_max_cells() cells)
+int gridb_lds_max_cells(bool half);
+// all of a batch's cell lists, one workgroup per pair, counters in LDS sized for the largest grid of the batch (max_cells <=
+// gridb_lds_max_cells(half)); half: 16-bit counters, allowed when no pair has 65536 or more targets or sources
 void launch_gridb_build_lds(hipStream_t st, const float4* d_tgt4, float4* d_src, float4* d_tmp, const GridPairDev* d_pairs, int npairs,
-                            int32_t* d_cell_start, float4* d_sorted);
+                            int32_t* d_cell_start, float4* d_sorted, int max_cells, bool half);
 void launch_grid_stats(hipStream_t st, const float4* d_src, int ns, const GridParams& gp, const int32_t* d_cell_start,
                        unsigned long long* d_out /* [0] evaluations of the 3x3x3 block, [1] occupied cells */);
 
