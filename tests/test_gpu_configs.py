@@ -202,3 +202,22 @@ def test_c4_icp_iterations_at_1m(ctx, O, pkg, c4):
     assert got["iterations"] == 3 and np.array_equal(got["trace_sums"][:, 0], ref["trace_sums"][:, 0])
     assert np.allclose(got["trace_sums"], ref["trace_sums"], rtol=1e-9, atol=1e-12)
     assert np.abs(got["T"] - ref["T"]).max() < 1e-5 and abs(got["fitness"] - ref["fitness"]) < 1e-10
+
+
+def test_batch_builds_with_wide_and_narrow_counters(ctx, pkg):
+    """The per-pair cell-list build in LDS: 16-bit counters when no pair has 65536 points (grids up to 73k cells stay in
+    LDS), 32-bit otherwise, the global-atomic path beyond.  Three batches that take the three routes; every record must
+    equal the one-pair path bit for bit."""
+    S = pkg.synth
+    def batch(sizes, seed):
+        pairs = [S.make_pair(seed + i, n, R=S.rot_axis_angle([0.3, 0.5, 1.0], np.deg2rad(4.0 + i)), t=(0.01 * i, 0.0, 0.005), shape="bumpy", n_src=n - 37 * (i + 1))
+                 for i, n in enumerate(sizes)]
+        src_all, so, tgt_all, to = _batch_arrays(pairs)
+        p = ctx.icp_params(nn_mode=pkg.NN_GRID, max_iterations=6, fixed_iterations=1)
+        res = ctx.icp_batch(src_all, so, tgt_all, to, p)
+        for i, (s, t) in enumerate(pairs):
+            one = ctx.icp(s, t, p)
+            assert np.array_equal(res[i].matrix(), one["T"]) and res[i].fitness == one["fitness"] and res[i].last_mse == one["last_mse"], (sizes, i)
+    batch([15000, 9000, 14000, 3000], 900)          # ~48k cells: LDS only with 16-bit counters
+    batch([6000, 70000, 5000], 910)                 # a pair of >= 65536 points: 32-bit counters are not enough either -> global path
+    batch([2500, 4000, 8000, 1200, 600], 920)       # small grids: LDS, 16-bit
