@@ -208,3 +208,15 @@ def test_batch_of_badly_posed_pairs_switches_engine_without_changing_results(ctx
         assert a[i].iterations == b[i].iterations == c[i].iterations == 12
         assert np.abs(a[i].matrix() - c[i].matrix()).max() < 1e-5 and np.abs(b[i].matrix() - c[i].matrix()).max() < 1e-5
         assert abs(a[i].fitness - c[i].fitness) < 1e-9 * max(1.0, c[i].fitness) and abs(b[i].fitness - c[i].fitness) < 1e-9 * max(1.0, c[i].fitness)
+
+
+def test_soak_tools_short_run():
+    """tools/soak_grid.py (the cell-list engine's per-source correspondences vs the brute-force engine over random shapes, sizes,
+    poses and iteration counts: skip test, walks, fallbacks) and tools/soak_batch.py (every record of random ragged batches vs
+    the one-pair path, bit for bit): a short run of each with fixed seeds; the tools exit non-zero on any mismatch."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    for tool, args in (("soak_grid.py", ["60", "2024"]), ("soak_batch.py", ["12", "2025"])):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)] + args, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, tool + "\n" + r.stdout[-2000:] + r.stderr[-2000:]
+        assert "Memory access fault" not in r.stdout + r.stderr
