@@ -997,13 +997,16 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
             const double* __restrict__ rows = a.rows + (int64_t)pr.row_base * NSUMS;
             if (g < PASS_FG) {
                 double acc = 0.0;
-                for (int k = g; k < pr.n_rows; k += 8 * PASS_FG) {
-                    double t[8];
+                // (rows in flight per batch: a 1M-point pair has 1954 rows, 78 per lane -- at eight per batch the pair's last
+                // workgroup spent ten dependent round trips here, a fifth of the iteration; the order of the additions is the same)
+                constexpr int RB = BATCH ? 8 : 32;
+                for (int k = g; k < pr.n_rows; k += RB * PASS_FG) {
+                    double t[RB];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
+                    for (int j = 0; j < RB; ++j)
                         t[j] = k + j * PASS_FG < pr.n_rows ? __hip_atomic_load(&rows[(int64_t)(k + j * PASS_FG) * NSUMS + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc += t[j];
+                    for (int j = 0; j < RB; ++j) acc += t[j];
                 }
                 shf[g][c] = acc;
             }
