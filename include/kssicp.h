@@ -69,7 +69,9 @@ enum { KSS_K_NN_SWEEP = 0, KSS_K_CORR_REDUCE = 1, KSS_K_PRESHAPE = 2, KSS_K_ROT_
        KSS_K_POSE_APPLY = 4, KSS_K_GRID_NN = 5, KSS_K_GRID_BUILD = 6,
        KSS_K_GRID_CHAIN = 7,        /* chained launches of the fused pass: one entry per launch (its whole duration) */
        KSS_K_GRID_CHAIN_PASS = 8,   /* the same time, counted per ICP pass the launches ran */
-       KSS_K_COUNT = 9 };
+       KSS_K_RESIDENT = 9,          /* pair-resident batch kernel: one entry per launch (all passes of every pair of the batch) */
+       KSS_K_RESIDENT_PASS = 10,    /* the same time, counted per (pair, pass) the launches ran */
+       KSS_K_COUNT = 11 };
 int kss_profile_enable(kss_ctx *ctx, int on);
 /* geometry of the last cell list built on this context (KSS_NN_GRID) and, when profiling is enabled, the
  * number of (source, target) distance evaluations of one search pass at the sources' initial positions:

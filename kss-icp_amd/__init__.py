@@ -9,7 +9,7 @@ The directory name contains a hyphen, so import it through `__graft_entry__.load
 (module name `kss_icp_amd`).
 """
 from .binding import (KssError, Context, IcpParams, IcpResult, RegisterResult, Pose, lib_path, load_library,
-                      exported_symbols, NSUMS, K_NN_SWEEP, K_CORR_REDUCE, K_PRESHAPE, K_ROT_SEARCH, K_POSE_APPLY, K_GRID_NN, K_GRID_BUILD, K_GRID_CHAIN, K_GRID_CHAIN_PASS, NN_AUTO, NN_BRUTE, NN_GRID,
+                      exported_symbols, NSUMS, K_NN_SWEEP, K_CORR_REDUCE, K_PRESHAPE, K_ROT_SEARCH, K_POSE_APPLY, K_GRID_NN, K_GRID_BUILD, K_GRID_CHAIN, K_GRID_CHAIN_PASS, K_RESIDENT, K_RESIDENT_PASS, NN_AUTO, NN_BRUTE, NN_GRID,
                       grid_angles, rotation_candidates, rigid_from_sums, build_library)
 from . import synth
 from . import shard

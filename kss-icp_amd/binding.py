@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 NSUMS = 20
-K_NN_SWEEP, K_CORR_REDUCE, K_PRESHAPE, K_ROT_SEARCH, K_POSE_APPLY, K_GRID_NN, K_GRID_BUILD, K_GRID_CHAIN, K_GRID_CHAIN_PASS = range(9)
+K_NN_SWEEP, K_CORR_REDUCE, K_PRESHAPE, K_ROT_SEARCH, K_POSE_APPLY, K_GRID_NN, K_GRID_BUILD, K_GRID_CHAIN, K_GRID_CHAIN_PASS, K_RESIDENT, K_RESIDENT_PASS = range(11)
 NN_AUTO, NN_BRUTE, NN_GRID = 0, 1, 2
 F32, F64 = 0, 1
 

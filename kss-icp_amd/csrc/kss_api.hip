@@ -42,6 +42,10 @@ static int ctx_create_common(int device_id, void* stream, bool borrow, kss_ctx**
         c->own_stream = true;
     }
     kss_live_contexts().fetch_add(1);
+    // launch sequence numbers are unique per PROCESS, not per context: rows handed over as {bits, number} granules are taken
+    // on the number alone, and a freed workspace block can come back to the next context with the old context's rows in it
+    static std::atomic<unsigned long long> ctx_serial{0};
+    c->seq = (ctx_serial.fetch_add(1) + 1ull) << 40;
     *out = c;
     return KSS_OK;
 }
@@ -68,6 +72,7 @@ int kss_ctx_destroy(kss_ctx* c) {
     if (c->h_seq) hipHostFree(c->h_seq);
     if (c->h_xf) hipHostFree(c->h_xf);
     if (c->gate_bar) hipFree(c->gate_bar);
+    if (c->res_gate) hipFree(c->res_gate);
     if (c->bar_state) hipFree(c->bar_state);
     if (c->h_state) hipHostFree(c->h_state);
     for (kss_ctx* w : c->workers) kss_ctx_destroy(w);

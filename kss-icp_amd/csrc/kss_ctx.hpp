@@ -85,6 +85,9 @@ struct kss_ctx {
     bool nn_have = false;             // the cell-list pass has written nn_win / nn_state for the current lists
     PairState* bar_state = nullptr; int bar_state_cap = 0; bool bar_state_failed = false;   // batched pass: per-pair states, same kind of memory
     unsigned int* gate_bar = nullptr;   // fine-grained device memory the host stores into through the BAR (large-BAR systems)
+    unsigned int* res_gate = nullptr; int res_gate_cap = 0; bool res_gate_failed = false;   // pair-resident engine: one 128-byte gate record per pair, same kind of memory
+    unsigned res_launches = 0;          // ... its launches so far (every launch has its own range of gate stamps)
+    double res_passes = 0.0;            // ... (pair, pass) units its profiled launches ran
     unsigned long long seq = 0;
     void* h_state = nullptr; size_t h_state_cap = 0;
 
@@ -184,6 +187,7 @@ static inline void prof_collect(kss_ctx* c) {
             if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
                 c->prof_ms[k] += ms; c->prof_n[k] += 1;
                 if (k == KSS_K_GRID_CHAIN) c->prof_ms[KSS_K_GRID_CHAIN_PASS] += ms;   // (its count: the passes released, kss_engine.hip)
+                if (k == KSS_K_RESIDENT) c->prof_ms[KSS_K_RESIDENT_PASS] += ms;       // (its count: the (pair, pass) units run)
             }
             c->ev_pool.push_back(ep);
         }

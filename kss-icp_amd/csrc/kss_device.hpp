@@ -16,6 +16,13 @@ __device__ __forceinline__ float dist2(float sx, float sy, float sz, float tx, f
     }
 }
 
+// cell of a coordinate in a uniform grid (clamped to the grid: queries outside the bbox belong to the border cells)
+__device__ __forceinline__ int cell_coord(float v, float o, float inv_h, int g) {
+    int c = (int)floorf((v - o) * inv_h);
+    c = c < 0 ? 0 : c;
+    return c >= g ? g - 1 : c;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -92,30 +99,33 @@ __device__ __forceinline__ double dpp_f64(double x, F f) {
     return __hiloint2double(hi, lo);
 }
 // value of lane (l ^ d) for d = 8, 4, 2, 1 (inside a row of 16 lanes: DPP, no LDS)
-__device__ __forceinline__ double xor8(double x) { return dpp_f64(x, [](int v) { return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false); }); }   // row_ror:8
+// (every lane is written: no "old" value to keep -- with one, the compiler copies the register first, two moves per exchange)
+__device__ __forceinline__ double xor8(double x) { return dpp_f64(x, [](int v) { return __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, false); }); }   // row_ror:8
 __device__ __forceinline__ double xor4(double x) {
     return dpp_f64(x, [](int v) {
-        int r = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xf, 0x5, false);   // row_shl:4 into banks 0, 2 (lanes with bit 2 clear)
+        int r = __builtin_amdgcn_mov_dpp(v, 0x104, 0xf, 0x5, false);         // row_shl:4 into banks 0, 2 (lanes with bit 2 clear)
         return __builtin_amdgcn_update_dpp(r, v, 0x114, 0xf, 0xa, false);    // row_shr:4 into banks 1, 3
     });
 }
-__device__ __forceinline__ double xor2(double x) { return dpp_f64(x, [](int v) { return __builtin_amdgcn_update_dpp(v, v, 0x4e, 0xf, 0xf, false); }); }    // quad_perm [2,3,0,1]
-__device__ __forceinline__ double xor1(double x) { return dpp_f64(x, [](int v) { return __builtin_amdgcn_update_dpp(v, v, 0xb1, 0xf, 0xf, false); }); }    // quad_perm [1,0,3,2]
+__device__ __forceinline__ double xor2(double x) { return dpp_f64(x, [](int v) { return __builtin_amdgcn_mov_dpp(v, 0x4e, 0xf, 0xf, false); }); }    // quad_perm [2,3,0,1]
+__device__ __forceinline__ double xor1(double x) { return dpp_f64(x, [](int v) { return __builtin_amdgcn_mov_dpp(v, 0xb1, 0xf, 0xf, false); }); }    // quad_perm [1,0,3,2]
 
 // a: lanes with the distance bit clear keep a (and receive the partner's a); b: lanes with the bit set keep b.
 // Returns a_own + a_partner in the "clear" lanes and b_partner + b_own in the "set" lanes: one tree level of TWO
 // columns for the price of one (v_permlane32_swap / v_permlane16_swap exchange half-waves / odd-even rows in place).
+// (the swaps work IN PLACE on the two registers: written as asm with read-write operands -- the builtin returns a pair and
+// the compiler copied both inputs first, two moves per swap, fifty-six per tree)
 __device__ __forceinline__ double level32(double a, double b) {
     unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a), blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
-    const auto r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
-    const auto r1 = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
-    return __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
+    asm("v_permlane32_swap_b32 %0, %1" : "+v"(alo), "+v"(blo));
+    asm("v_permlane32_swap_b32 %0, %1" : "+v"(ahi), "+v"(bhi));
+    return __hiloint2double((int)ahi, (int)alo) + __hiloint2double((int)bhi, (int)blo);
 }
 __device__ __forceinline__ double level16(double a, double b) {
     unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a), blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
-    const auto r0 = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
-    const auto r1 = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
-    return __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
+    asm("v_permlane16_swap_b32 %0, %1" : "+v"(alo), "+v"(blo));
+    asm("v_permlane16_swap_b32 %0, %1" : "+v"(ahi), "+v"(bhi));
+    return __hiloint2double((int)ahi, (int)alo) + __hiloint2double((int)bhi, (int)blo);
 }
 __device__ __forceinline__ double tree_low4(double x) {   // levels 8, 4, 2, 1: every lane of a 16-lane row ends with the row total
     x += xor8(x); x += xor4(x); x += xor2(x); x += xor1(x);

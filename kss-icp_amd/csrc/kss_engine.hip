@@ -217,7 +217,7 @@ static int stage_plan(kss_ctx* c, const IcpPlan& pl) {
     KCHK(ensure(c, c->cur[0], (size_t)pl.total_src * sizeof(float4)));
     KCHK(ensure(c, c->cur[1], (size_t)pl.total_src * sizeof(float4)));
     KCHK(ensure(c, c->keys, (size_t)pl.total_keys * sizeof(unsigned long long)));
-    KCHK(ensure(c, c->partials, std::max<size_t>(pl.red.size(), 2 * (size_t)pl.total_rows) * NSUMS * sizeof(double)));   // (x2: rows as 16-byte granules)
+    KCHK(ensure_zeroed(c, c->partials, std::max<size_t>(pl.red.size(), 2 * (size_t)pl.total_rows) * NSUMS * sizeof(double)));   // (x2: rows as 16-byte granules; zeroed when (re)allocated: no stale {bits, number} granule of an earlier owner of the block)
     KCHK(ensure(c, c->sums, (size_t)pl.npairs * NSUMS * sizeof(double)));
     KCHK(ensure(c, c->nn_work, pl.nn_count * sizeof(NNWork)));
     KCHK(ensure(c, c->red_work, pl.red.size() * sizeof(RedWork)));
@@ -940,8 +940,255 @@ static inline void mirror_state(PairState* bar, int p, const PairState& s) {
     for (int k = 0; k < 4; ++k) _mm_store_si128(d + k, _mm_loadu_si128(v + k));
 }
 
+// ---- the pair-resident engine (kss_resident.hip), host side ------------------------------------------------------------
+// One launch runs every registration of the batch, one workgroup per pair; the host's part of an ICP iteration -- 20 sums in,
+// 3x3 SVD, convergence tests, transform out -- is served per PAIR as its sums land, by a few threads that each own an
+// interleaved share of the pairs (workgroups start roughly in pair order, so the pairs in flight spread over all threads).
+// Every pair is solved by exactly one thread with the code of the launch-per-pass loop: same results.
+// Gate records live in fine-grained device memory the host stores into through the BAR (large-BAR systems only; otherwise
+// the launch-per-pass engine runs).  KSS_RESIDENT=0 switches the engine off (A/B; the engines agree bit for bit).
+static bool resident_capacities(const IcpPlan& pl, int* ntc_out, int* tabc_out) {
+    int64_t max_nt = 0;
+    for (int p = 0; p < pl.npairs; ++p) {
+        if (pl.g[p].ns > (int64_t)RES_SMAX * RES_THREADS || pl.g[p].nt > 65534) return false;   // (positions are 16 bits, 0xffff: none)
+        max_nt = std::max(max_nt, pl.g[p].nt);
+    }
+    const int ntc = (int)((max_nt + 3 + 63) / 64 * 64);   // (+3: an evaluation step reads four points)
+    const int64_t avail = ((int64_t)RES_LDS_MAX - (int64_t)resident_lds_bytes(ntc, 0)) / 2 / 8 * 8;   // table entries that still fit
+    if (avail < 16) return false;
+    int64_t want = 16;
+    for (int p = 0; p < pl.npairs; ++p) {
+        const GridParams& gp = pl.gpairs[p].gp;
+        const int64_t rows = (int64_t)gp.gy * gp.gz;
+        int xs = 0;
+        while (xs <= 8 && rows * (((gp.gx + (1 << xs) - 1) >> xs) + 1) > avail) ++xs;   // x resolution of the table halves until it fits
+        if (xs > 8) return false;
+        want = std::max(want, rows * (((gp.gx + (1 << xs) - 1) >> xs) + 1));
+    }
+    *ntc_out = ntc;
+    *tabc_out = (int)((want + 7) / 8 * 8);
+    return true;
+}
+
+static unsigned int* resident_gate(kss_ctx* c, int npairs) {
+    static const bool want_bar = getenv("KSS_GATE_BAR") == nullptr || atoi(getenv("KSS_GATE_BAR")) != 0;
+    if (!want_bar || c->res_gate_failed) return nullptr;
+    if (c->res_gate && c->res_gate_cap >= npairs) return c->res_gate;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess || !prop.isLargeBar) { c->res_gate_failed = true; return nullptr; }
+    if (c->res_gate) { hipStreamSynchronize(c->stream); hipFree(c->res_gate); c->res_gate = nullptr; c->res_gate_cap = 0; }
+    void* p = nullptr;
+    const int cap = npairs + npairs / 4 + 64;
+    if (hipExtMallocWithFlags(&p, (size_t)cap * 128, hipDeviceMallocFinegrained) != hipSuccess || !p || hipMemset(p, 0, (size_t)cap * 128) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess) {
+        (void)hipGetLastError();
+        if (p) hipFree(p);
+        c->res_gate_failed = true;
+        return nullptr;
+    }
+    c->res_gate = (unsigned int*)p; c->res_gate_cap = cap;
+    return c->res_gate;
+}
+
+// the 20 sums of pair p under sequence number `want` (low 32 bits + check word, kss_resident.hip), if they have all landed
+static inline bool resident_collect(const unsigned long long* h_seq, int p, unsigned long long want, double* out) {
+    const unsigned long long* sl = h_seq + (size_t)2 * NSUMS * p;
+    for (int k = NSUMS - 1; k >= 0; --k) {
+        const unsigned long long w = __atomic_load_n(&sl[2 * k + 1], __ATOMIC_ACQUIRE);
+        if ((unsigned)w != (unsigned)want) return false;
+        const unsigned long long bits = __atomic_load_n(&sl[2 * k], __ATOMIC_RELAXED);
+        if ((unsigned)(w >> 32) != kss_mix3((unsigned)bits, (unsigned)(bits >> 32), (unsigned)w)) return false;   // seen torn: look again
+        std::memcpy(&out[k], &bits, sizeof(double));
+    }
+    return true;
+}
+
+// *handled = false with KSS_OK: the plan does not qualify (or the engine gave up before touching any result): the caller
+// runs the launch-per-pass loop
+static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P, kss_icp_result* results, bool* handled) {
+    *handled = false;
+    static const bool want = getenv("KSS_RESIDENT") == nullptr || atoi(getenv("KSS_RESIDENT")) != 0;
+    if (!want || !pl.gridb || P.allreduce || P.max_iterations < 1 || P.max_iterations > 4000) return KSS_OK;
+    int ntc = 0, tabc = 0;
+    if (!resident_capacities(pl, &ntc, &tabc)) return KSS_OK;
+    unsigned int* gate = resident_gate(c, pl.npairs);
+    if (!gate) return KSS_OK;
+    const int np = pl.npairs;
+    ResArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.pairs = (const GridPairDev*)c->g_pairs.p;
+    a.cell_start = (const int32_t*)c->g_start.p + 1;
+    a.sorted = (const float4*)c->g_sorted.p;
+    a.src0 = (const float4*)c->src0.p;
+    a.gate = gate;
+    a.pub = c->h_seq_dev;
+    a.max_passes = P.max_iterations + 2;
+    a.seq0 = c->seq + 1;
+    c->seq += (unsigned long long)a.max_passes + 1;
+    c->res_launches = c->res_launches % 500000u + 1u;
+    a.stamp0 = c->res_launches * 4096u;          // every launch has its own 4096 stamps: a record of an earlier launch never matches
+    a.max_d2 = P.max_corr_dist * P.max_corr_dist;
+    static const float skin = getenv("KSS_SKIN") ? (float)atof(getenv("KSS_SKIN")) : 0.25f;
+    a.skin = skin;
+    static const int gate_polls = getenv("KSS_GATE_POLLS") ? atoi(getenv("KSS_GATE_POLLS")) : (1 << 22);
+    a.gate_polls = gate_polls;
+    a.full_always = P.trace_sums != nullptr ? 1 : 0;
+    a.ntc = ntc; a.tabc = tabc;
+    if (P.compute_fitness && (P.fitness_idx || P.fitness_d2)) {
+        KCHK(ensure(c, c->stage_idx, (size_t)pl.total_src * sizeof(int32_t)));
+        KCHK(ensure(c, c->stage_d2, (size_t)pl.total_src * sizeof(float)));
+        a.idx_out = (int32_t*)c->stage_idx.p; a.d2_out = (float*)c->stage_d2.p;
+    }
+    static const bool stamps_on = getenv("KSS_GRID_STAMPS") != nullptr;   // diagnostic timeline (tools/resident_stamps.py)
+    if (stamps_on) {
+        KCHK(ensure(c, c->g_stamps, (size_t)np * 16 * sizeof(unsigned long long)));
+        HIPCHK(c, hipMemsetAsync(c->g_stamps.p, 0, (size_t)np * 16 * sizeof(unsigned long long), c->stream));
+        a.stamps = (unsigned long long*)c->g_stamps.p;
+    }
+    {
+        ProfScope ps(c, KSS_K_RESIDENT, true);
+        std::string lerr;
+        const int rc = launch_resident(c->stream, P.nn_fma != 0, np, a, lerr);
+        if (rc != KSS_OK) { (void)hipGetLastError(); return KSS_OK; }   // (not launched: nothing touched, the other engine runs)
+    }
+
+    // ---- per-pair host state (what icp_loop keeps in its vectors) ----
+    enum { PH_ITER = 0, PH_FIT = 1, PH_DONE = 2 };
+    struct PairHost { Convergence cv; float fin[16]; int iters = 0, converged = 0, state = 0, k = 0, phase = PH_ITER; double last_mse = 0.0, fitness = 0.0; };
+    std::vector<PairHost> H((size_t)np);
+    for (int p = 0; p < np; ++p) {
+        Convergence& cv = H[p].cv;
+        cv.max_iterations = P.max_iterations;
+        cv.rotation_threshold = 1.0 - P.transformation_epsilon;
+        cv.translation_threshold = P.transformation_epsilon;
+        cv.mse_rel = P.euclidean_fitness_epsilon;
+        cv.mse_abs = P.abs_mse_epsilon;
+        cv.fixed_iterations = P.fixed_iterations != 0;
+        mat4_identity(H[p].fin);
+    }
+    if (P.trace_n) *P.trace_n = 0;
+    std::atomic<int> failed{0}, kernel_done{0};
+    std::atomic<long long> units{0};
+    const unsigned long long* h_seq = c->h_seq;
+    auto send = [&](int p, const float* T, int apply, int mode) {   // the gate record of pair p's NEXT pass (number H[p].k + 1)
+        unsigned w[15];
+        if (T) std::memcpy(w, T, 12 * sizeof(float)); else std::memset(w, 0, 12 * sizeof(float));
+        w[12] = 1u; w[13] = (unsigned)apply; w[14] = (unsigned)mode;
+        const unsigned stamp = a.stamp0 + (unsigned)(H[p].k + 1);
+        unsigned int* slot = gate + (size_t)p * 32;
+        for (int g = 0; g < 5; ++g) {
+            const unsigned tag = stamp + kss_mix3(w[3 * g], w[3 * g + 1], w[3 * g + 2]);
+            _mm_store_si128((__m128i*)(slot + 4 * g), _mm_set_epi32((int)tag, (int)w[3 * g + 2], (int)w[3 * g + 1], (int)w[3 * g]));
+        }
+        _mm_sfence();
+    };
+    auto serve = [&](int t, int nt) {
+        int remaining = 0;
+        for (int p = t; p < np; p += nt) ++remaining;
+        long idle = 0;
+        double s[NSUMS];
+        long long my_units = 0;
+        while (remaining > 0 && !failed.load(std::memory_order_relaxed)) {
+            bool progress = false;
+            for (int p = t; p < np; p += nt) {
+                PairHost& h = H[p];
+                if (h.phase == PH_DONE) continue;
+                if (!resident_collect(h_seq, p, a.seq0 + (unsigned long long)h.k, s)) continue;
+                progress = true;
+                ++my_units;
+                if (h.phase == PH_FIT) {   // getFitnessScore(): mean d2 over ALL source points
+                    h.fitness = s[17] / (double)pl.g[p].ns;
+                    h.phase = PH_DONE; --remaining;
+                    continue;
+                }
+                bool finished = false;
+                float tk[16];
+                if ((int)s[0] < P.min_correspondences) {   // PCL: "Not enough correspondences found"
+                    h.state = KSS_STATE_NO_CORRESPONDENCES; h.converged = 0; finished = true;
+                } else {
+                    rigid_from_sums(s, tk);
+                    mat4_mul(tk, h.fin, h.fin);            // final = transformation_ * final
+                    ++h.iters;
+                    const double mse = s[16] / s[0];
+                    h.last_mse = mse;
+                    if (p == 0 && P.trace_n && *P.trace_n < P.trace_cap) {
+                        if (P.trace_sums) std::memcpy(P.trace_sums + (size_t)(*P.trace_n) * NSUMS, s, NSUMS * sizeof(double));
+                        if (P.trace_Tk) std::memcpy(P.trace_Tk + (size_t)(*P.trace_n) * 16, tk, 16 * sizeof(float));
+                        ++*P.trace_n;
+                    }
+                    const bool done = h.cv.has_converged(h.iters, tk, mse);
+                    h.state = h.cv.state;
+                    if (done) { h.converged = 1; finished = true; }
+                }
+                if (!finished) {
+                    send(p, tk, 1, 0);                     // the next pass applies T_k on load (transformCloud)
+                    ++h.k;
+                } else if (P.compute_fitness) {
+                    send(p, h.fin, 1, 1);                  // final * original input, all 20 sums
+                    ++h.k;
+                    h.phase = PH_FIT;
+                } else {
+                    send(p, nullptr, 0, 2);
+                    h.phase = PH_DONE; --remaining;
+                }
+            }
+            if (progress) { idle = 0; continue; }
+            __builtin_ia32_pause();
+            if (++idle % 4096 == 0) {
+                // nothing for a while: has the kernel gone?  (Only the calling thread talks to HIP.)  A workgroup that was not
+                // answered within its bounded poll has left; its pair will never publish
+                if (t == 0 && !kernel_done.load() && hipStreamQuery(c->stream) != hipErrorNotReady) kernel_done.store(1);
+                if (kernel_done.load() && idle > (1 << 16)) failed.store(1);   // (a few more rounds: results already on their way over PCIe)
+            }
+        }
+        units.fetch_add(my_units);
+    };
+    static const int res_threads = [] {
+        int v = (int)std::thread::hardware_concurrency();
+        v = std::max(1, std::min(v, 12));
+        if (const char* e = getenv("KSS_HOST_THREADS")) { const int u = atoi(e); if (u >= 1 && u <= 64) v = u; }
+        return v;
+    }();
+    const int nthreads = std::max(1, std::min(res_threads, (np + 7) / 8));
+    c->pool.run_threads(nthreads, serve);
+    if (failed.load()) {
+        // let every workgroup that still waits (or has not started yet) leave, then report: the caller starts over on the
+        // launch-per-pass engine (the resident kernel has written nothing but its result slots)
+        for (int p = 0; p < np; ++p)
+            if (H[p].phase != PH_DONE) send(p, nullptr, 0, 2);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::fprintf(stderr, "[kss] the pair-resident kernel left before every pair was finished (a stalled host thread?); running the launch-per-pass engine\n");
+        return KSS_OK;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // every workgroup has left (its last act was the publication just consumed)
+    if (c->prof > 0) { c->prof_n[KSS_K_RESIDENT_PASS] += units.load(); }
+    for (int p = 0; p < np; ++p) {
+        kss_icp_result& r = results[p];
+        std::memcpy(r.T, H[p].fin, 16 * sizeof(float));
+        r.iterations = H[p].iters; r.converged = H[p].converged; r.state = H[p].state;
+        r.last_mse = H[p].last_mse; r.fitness = P.compute_fitness ? H[p].fitness : 0.0; r.pair_id = p;
+    }
+    if (a.idx_out) {
+        const size_t n0 = (size_t)pl.g[0].ns;
+        if (P.fitness_idx) HIPCHK(c, hipMemcpyAsync(P.fitness_idx, a.idx_out, n0 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        if (P.fitness_d2) HIPCHK(c, hipMemcpyAsync(P.fitness_d2, a.d2_out, n0 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (stamps_on) {
+        c->last_stamps.resize((size_t)np * 16);
+        HIPCHK(c, hipMemcpy(c->last_stamps.data(), a.stamps, c->last_stamps.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    }
+    *handled = true;
+    return KSS_OK;
+}
+
 // The ICP loop over a packed workspace (src0/tgt4 already filled).
 static int icp_loop(kss_ctx* c, const IcpPlan& pl_in, const kss_icp_params& P, kss_icp_result* results) {
+    if (pl_in.gridb) {   // batches whose pairs fit a CU each: one launch, every pair resident for its whole registration
+        bool handled = false;
+        KCHK(resident_loop(c, pl_in, P, results, &handled));
+        if (handled) return KSS_OK;
+    }
     const IcpPlan* plan = &pl_in;   // may change to the brute-force plan below
     IcpPlan brute_plan;
     const int np = pl_in.npairs;

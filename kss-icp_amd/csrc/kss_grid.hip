@@ -38,12 +38,6 @@
 
 namespace kss {
 
-__device__ __forceinline__ int cell_coord(float v, float o, float inv_h, int g) {
-    int c = (int)floorf((v - o) * inv_h);
-    c = c < 0 ? 0 : c;
-    return c >= g ? g - 1 : c;
-}
-
 // ---- counting sort into cell order: target AND source of a pair by the same launches ---------------------------
 // counts / starts are ONE array of 2 * ncells entries: [0, ncells) the target's cells, [ncells, 2 ncells) the source's.
 // One exclusive scan over the whole array gives the target's starts directly (and start[ncells] = nt is their end

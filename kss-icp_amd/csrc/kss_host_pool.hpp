@@ -45,6 +45,24 @@ public:
         fn_ = nullptr;
     }
 
+    // fn(t, nt) on nt threads at once (t = 0 is the caller): for loops in which every thread serves an interleaved share of
+    // a set of pairs for as long as the whole set is in flight (the pair-resident engine)
+    void run_threads(int nt, const std::function<void(int, int)>& fn) {
+        if (nt <= 1) { fn(0, 1); return; }
+        const std::function<void(int, int)> chunk = [&](int b, int) { fn(b, nt); };
+        start_workers(nt - 1);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &chunk; n_ = nt; chunk_ = 1; nchunks_ = nt; pending_ = nt - 1; ++gen_;
+        }
+        cv_.notify_all();
+        fn(0, nt);
+        for (int spin = 0; spin < 200000 && pending_.load(std::memory_order_acquire) != 0; ++spin) __builtin_ia32_pause();
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&] { return pending_.load(std::memory_order_acquire) == 0; });
+        fn_ = nullptr;
+    }
+
     static int threads() {
         static const int t = [] {
             int v = (int)std::thread::hardware_concurrency();

@@ -55,6 +55,19 @@ struct PairRed {            // final reduce: rows [first, first+count) of partia
     int32_t count;
 };
 
+// 32-bit check word of three data words: folded into the stamp / sequence word of every 16-byte granule that crosses
+// between host and device without a flag (gate records, result slots), so that a granule seen TORN -- some words of the
+// previous write, some of the new one -- fails the check and is simply polled again instead of being taken for data.
+__host__ __device__ inline unsigned kss_mix3(unsigned a, unsigned b, unsigned c) {
+    unsigned h = (a + 0x9E3779B1u) * 0x85EBCA77u;
+    h ^= h >> 15;
+    h = (h ^ (b + 0x7F4A7C15u)) * 0xC2B2AE3Du;
+    h ^= h >> 13;
+    h = (h ^ (c + 0x165667B1u)) * 0x27D4EB2Fu;
+    h ^= h >> 16;
+    return h;
+}
+
 // Uniform cell list over the target's bounding box (kss_grid.hip)
 struct GridParams {
     float ox, oy, oz;   // bbox minimum
@@ -113,6 +126,31 @@ struct PassArgs {
     unsigned long long* stamps;                 // diagnostics (null in production): see KSS_STAMP below
 };
 
+// ---- the pair-resident ICP kernel (kss_resident.hip) ---------------------------------------------------------------
+constexpr int RES_THREADS = 1024;     // lanes of the workgroup that holds one pair
+constexpr int RES_SMAX = 10;          // sources per lane: a pair of up to 10240 sources lives in registers
+constexpr int RES_NQ = 640;           // search requests queued per round (the rest is queued again, or searched by its own lane)
+constexpr int RES_QW = 4;             // words per request {query, pruning radius}; answered in place {winner | runner-up << 16, bound, fell back}
+constexpr int RES_G = 4;              // source slots whose wave totals are in LDS at a time
+constexpr int RES_LDS_MAX = 160 * 1024 - 256;   // dynamic LDS of a workgroup (the rest: its few static words)
+struct ResArgs {
+    const GridPairDev* pairs;                   // per-pair table (cell grid, segments, rows)
+    const int32_t* cell_start;                  // exclusive prefix of the cell counts (global positions in `sorted`)
+    const float4* sorted;                       // targets in cell order, .w = index within the pair's target
+    const float4* src0;                         // sources in cell order, .w = global source index
+    unsigned int* gate;                         // per pair 32 words of fine-grained device memory the host stores into (BAR)
+    unsigned long long* pub;                    // host-mapped result slots: per pair NSUMS x {bits, seq | check << 32}
+    unsigned long long seq0;                    // pass k of a pair publishes under seq0 + k
+    unsigned int stamp0;                        // ... and then waits for the gate record stamped stamp0 + k + 1
+    double max_d2;
+    float skin;                                 // pruning radius grows by skin * cell edge; < 0: never skip (A/B switch)
+    int32_t gate_polls, max_passes, full_always;
+    int32_t ntc, tabc;                          // LDS capacities of this launch: targets (multiple of 64), table entries (multiple of 8)
+    int32_t* idx_out; float* d2_out;            // fitness pass: per-source correspondences (null: not wanted)
+    unsigned long long* stamps;                 // diagnostics (null in production)
+};
+size_t resident_lds_bytes(int ntc, int tabc);
+int launch_resident(hipStream_t st, bool fma, int npairs, const ResArgs& a, std::string& err);
 
 // PCL's octree bounding cube (kss_octree.hip; replayed on the host by oct_first_point / oct_adopt)
 struct OctBox {
