@@ -21,7 +21,10 @@ Two NN engines produce bit-identical correspondences (tests/test_gpu_grid.py):
   * --mode brute: the north star's LDS-tiled source x target sweep              -> `brute_force` object
     (always measured too, on a few steps, because it is the kernel graded against the FP32 VALU roofline)
 `secondary` (N = 1): GPU-only legs of the other BASELINE configs -- C3 (1024 x 10k x 10k batch), C4 (1M x 1M: pre-shape,
-one NN pass, 10 iterations) and the pre-shape kernels streaming 64M points -- each with its kernel's launch time.
+one NN pass, 10 iterations), the pre-shape kernels streaming 64M points -- each with its kernel's launch time -- and
+`register`: the reference's one live entry point (KSSICP_Registration on <= 2000-point samples) with the oracle's one-core
+time beside it.  N > 1: `secondary.c5` -- every rank registers its 1024-pair shard in one batch call, ONE all-gather of the
+records (BASELINE config 5; KSS_BENCH_FORCE_DIST=1 runs the same code on one rank over a real RCCL group).
 
 Prints ONE JSON line on rank 0.
 """
@@ -53,7 +56,9 @@ def parse_args(argv=None):
     ap.add_argument("--mode", default="auto", choices=["auto", "brute", "grid"], help="NN engine of the timed path")
     ap.add_argument("--brute-steps", type=int, default=3, help="steps of the secondary brute-force measurement (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the C3 / C4 / streaming legs")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C3 / C4 / streaming / register / C5 legs")
+    ap.add_argument("--legs", default="c3,c4,stream,register,c5", help="secondary legs to run (comma separated; c5 needs N > 1 or KSS_BENCH_FORCE_DIST=1)")
+    ap.add_argument("--c5-pairs", type=int, default=1024, help="pairs per rank of the C5 leg (N > 1 ranks: 1024 = BASELINE config 5 at N = 8)")
     ap.add_argument("--split-source", action="store_true",
                     help="N > 1: ONE registration, its source rows split over the ranks (target replicated), one RCCL "
                          "all-reduce of the 20 sums per iteration (SURVEY 8e alternative; strong scaling).  Default: one "
@@ -198,6 +203,23 @@ def dry_run(a, world, rank):
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # the C5 leg's protocol with stand-in records: every rank's shard of a.c5_pairs records, ONE gather, ids in global order
+    c5 = None
+    if world > 1 and "c5" in a.legs.split(","):
+        shard = (pkg.IcpResult * a.c5_pairs)()
+        for i in range(a.c5_pairs):
+            shard[i].fitness = float(rank * a.c5_pairs + i)
+            shard[i].iterations = 20
+        dist.barrier()
+        t0 = time.perf_counter()
+        local = pkg.shard.records_to_array(shard, rank * a.c5_pairs)
+        allrec = pkg.shard.gather_records(local, world * a.c5_pairs, world, rank)
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        recs = pkg.shard.array_to_records(allrec, pkg.IcpResult)
+        c5 = {"workload": "DRY RUN of the C5 leg's protocol (stand-in records)", "n_gpus": world, "pairs_total": world * a.c5_pairs,
+              "gather_us_max_over_ranks": float(t.item()) * 1e6,
+              "gathered_pair_ids_in_order": bool(len(recs) == world * a.c5_pairs and all(r.pair_id == i and r.fitness == float(i) for i, r in enumerate(recs)))}
     if rank == 0:
         ok = True
         if world > 1:
@@ -207,113 +229,235 @@ def dry_run(a, world, rank):
                           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "DRY RUN of the rank protocol on CPU (gloo): no registration is computed"},
-                          "dry_run": True, "records_gathered_ok": bool(ok), "slowest_rank_sleep_ms": 2.0 * world}), flush=True)
+                          "dry_run": True, "records_gathered_ok": bool(ok), "slowest_rank_sleep_ms": 2.0 * world,
+                          "secondary": {"c5": c5} if c5 else {}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     return 0
 
 
-def secondary_legs(pkg, ctx, torch, np):
+def register_leg(pkg, ctx, np):
+    """The reference's ONE live entry point (Main_KSS_ICP.cpp:79-82 -> KSSICP_Registration, KSS_ICP.hpp:69-131) on C1-size
+    inputs: AIVS down-sampling of both clouds to pNumber = min(n) / 2 (2000-point clouds -> 1000-point samples, accurate = 8)
+    and kss_register (pre-shape, 729-candidate rotation search, judge ICP, candidate ICP batch, final transform), and
+    kss_register alone on 2000 x 2000 samples (the reference's cap, KSS_ICP.hpp:64-66).  The oracle's one-core time of the same
+    call stands beside each; rot_search_kernel is event-timed and priced against the FP32 vector peak (8 flop per pair)."""
+    import __graft_entry__ as graft
+    S = pkg.synth
+    O = graft.load_oracle()
+    out = {}
+    for name, n, sub in (("c1_2000_to_1000", 2000, True), ("samples_2000x2000", 2000, False)):
+        src, tgt = S.make_pair(4242 + n + int(sub), n, R=S.rot_axis_angle([0.3, 0.2, 1.0], np.deg2rad(30.0)), t=(0.05, -0.02, 0.03), shape="bumpy")
+        src = src.astype(np.float64); tgt = tgt.astype(np.float64)
+        m = min(len(src), len(tgt)) // 2
+
+        def gpu():
+            if sub:
+                t_, _ = ctx.downsample_aivs(tgt, m); s_, _ = ctx.downsample_aivs(src, m)      # target first, as the reference
+            else:
+                s_, t_ = src, tgt
+            return s_, t_, ctx.register(s_, t_, src, 8.0, 1000)
+        gpu()
+        reps = 10
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ss, tt, r = gpu()
+        dt = (time.perf_counter() - t0) / reps
+        ctx.profile_enable(True); ctx.profile_reset()
+        ctx.register(ss, tt, src, 8.0, 1000)
+        rms, rn = ctx.profile_get(pkg.K_ROT_SEARCH)
+        ctx.profile_enable(False)
+        t0 = time.perf_counter()
+        if sub:
+            os_, ot_ = src[O.aivs(src, m)], tgt[O.aivs(tgt, m)]
+        else:
+            os_, ot_ = src, tgt
+        k = O.kssicp_register(os_, ot_, src, 8.0, 1000)
+        cpu_dt = time.perf_counter() - t0
+        g = int(r["grid"])
+        flops = 8.0 * g ** 3 * len(ss) * len(tt)
+        rs = rms / rn * 1e-3 if rn else None
+        out[name] = {"workload": "KSSICP_Registration on a %d x %d bumpy pair, 30 deg: %s kss_register (pre-shape, %d-candidate rotation search, judge ICP, "
+                                 "%d-candidate ICP batch, transform of the full cloud)" % (n, n, "AIVS to %d-point samples + " % m if sub else "", g ** 3, int(r["n_angle_list"])),
+                     "ms_per_registration": dt * 1e3, "registrations_per_sec": 1.0 / dt,
+                     "cpu_oracle_1core_ms": cpu_dt * 1e3, "speedup_vs_cpu_1core": cpu_dt / dt,
+                     "max_abs_R_diff_vs_oracle": float(np.abs(r["R"] - k["R"]).max()), "same_angle_index": bool(r["angle_index"] == k["angle_index"]),
+                     "n_src_samples": len(ss), "n_tgt_samples": len(tt), "candidates": int(r["n_angle_list"]), "icp_iterations": int(r["icp_iterations"]),
+                     "rot_search_kernel": {"avg_launch_ms": rms / rn if rn else None, "launches": rn, "flops_per_launch": flops,
+                                           "achieved_TFLOPs": flops / rs / 1e12 if rs else None, "peak_TFLOPs": FP32_VALU_PEAK_TFLOPS,
+                                           "frac_of_fp32_valu_peak": flops / rs / 1e12 / FP32_VALU_PEAK_TFLOPS if rs else None}}
+    return out
+
+
+def c5_leg(pkg, ctx, torch, np, dist, world, rank, dev, pairs_per_rank=1024, n=10000, iters=20):
+    """C5: every rank registers ITS shard of `pairs_per_rank` ModelNet40-scale pairs (pair ids rank * shard + i, no input
+    exchange) in one kss_icp_batch_dev call, then ONE all-gather of the 96-byte records over RCCL.  Run by every rank; the time
+    is the MAX over ranks of (batch + gather) between barriers."""
+    S = pkg.synth
+    src = np.empty((pairs_per_rank * n, 3), np.float32); tgt = np.empty((pairs_per_rank * n, 3), np.float32)
+    for i in range(pairs_per_rank):
+        s, t = S.config_c3_pair(rank * pairs_per_rank + i, n)
+        src[i * n:(i + 1) * n] = s; tgt[i * n:(i + 1) * n] = t
+    off = np.arange(pairs_per_rank + 1, dtype=np.int64) * n
+    d_src = torch.from_numpy(src).to(dev); d_tgt = torch.from_numpy(tgt).to(dev)
+    p = ctx.icp_params(max_iterations=iters, fixed_iterations=1)
+    ctx.icp_batch_dev(d_src.data_ptr(), off, d_tgt.data_ptr(), off, p)        # warm-up (workspace, worker threads)
+    reps = 3
+    times, gathers, allrec, res = [], [], None, None
+    for _ in range(reps):
+        dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = ctx.icp_batch_dev(d_src.data_ptr(), off, d_tgt.data_ptr(), off, p)
+        t1 = time.perf_counter()
+        local = pkg.shard.records_to_array(res, rank * pairs_per_rank)
+        allrec = pkg.shard.gather_records(local, world * pairs_per_rank, world, rank, device=dev)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        dist.barrier()
+        t = torch.tensor([t2 - t0, t2 - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        times.append(float(t[0].item())); gathers.append(float(t[1].item()))
+    out = None
+    if rank == 0:
+        dt = min(times)
+        recs = pkg.shard.array_to_records(allrec, pkg.IcpResult)
+        mine_ok = all(np.array_equal(np.array(recs[i].T), np.array(res[i].T)) and recs[i].fitness == res[i].fitness and recs[i].pair_id == i
+                      for i in range(pairs_per_rank))
+        ids_ok = len(recs) == world * pairs_per_rank and all(r.pair_id == i for i, r in enumerate(recs))
+        out = {"workload": "C5: %d pairs of %dx%d per rank x %d ranks, %d fixed ICP iterations + fitness, one kss_icp_batch_dev call per rank, "
+                           "one all-gather of the %d 96-byte records over RCCL" % (pairs_per_rank, n, n, world, iters, world * pairs_per_rank),
+               "n_gpus": world, "pairs_total": world * pairs_per_rank, "ms_per_batch_max_over_ranks": dt * 1e3,
+               "registrations_per_sec": world * pairs_per_rank / dt, "pair_iterations_per_sec": world * pairs_per_rank * iters / dt,
+               "gather_us_max_over_ranks": min(gathers) * 1e6, "gathered_records_equal_local": bool(mine_ok), "gathered_pair_ids_in_order": bool(ids_ok),
+               "scaling": "weak", "result_iterations": int(res[0].iterations)}
+    del d_src, d_tgt
+    return out
+
+
+def secondary_legs(pkg, ctx, torch, np, legs=("c3", "c4", "stream")):
     """GPU-only legs of the other BASELINE configs (each a fraction of a second of GPU time)."""
     S = pkg.synth
     out = {}
     sync = torch.cuda.synchronize
+    if "c3" not in legs and "c4" not in legs and "stream" not in legs:
+        return out
 
     def kernel_time(k):
         ms, n = ctx.profile_get(k)
         return (ms / n if n else None), n
 
-    # ---- C3: 1024 x (10k x 10k), 20 fixed iterations + fitness, one kss_icp_batch_dev call -----------------------
-    npairs, n, iters = 1024, 10000, 20
-    src = np.empty((npairs * n, 3), np.float32); tgt = np.empty((npairs * n, 3), np.float32)
-    for i in range(npairs):
-        s, t = S.config_c3_pair(i, n)
-        src[i * n:(i + 1) * n] = s; tgt[i * n:(i + 1) * n] = t
-    off = np.arange(npairs + 1, dtype=np.int64) * n
-    d_src = torch.from_numpy(src).cuda(); d_tgt = torch.from_numpy(tgt).cuda()
-    p = ctx.icp_params(max_iterations=iters, fixed_iterations=1)
-    ctx.icp_batch_dev(d_src.data_ptr(), off, d_tgt.data_ptr(), off, p)
-    ctx.profile_enable(True); ctx.profile_reset()
-    reps = 3
-    sync(); t0 = time.perf_counter()
-    for _ in range(reps):
-        res = ctx.icp_batch_dev(d_src.data_ptr(), off, d_tgt.data_ptr(), off, p)
-    sync(); dt = (time.perf_counter() - t0) / reps
-    kms, kn = kernel_time(pkg.K_GRID_NN)
-    ctx.profile_enable(False)
-    comp = 12.0 * (2 * npairs * n) + 8.0 * npairs * n           # SURVEY 8d compulsory bytes of one pass over the batch
-    out["c3"] = {"workload": "C3: %d independent %dx%d pairs in one kss_icp_batch_dev call, %d fixed ICP iterations + fitness pass, setup included" % (npairs, n, n, iters),
-                 "ms_per_batch": dt * 1e3, "pair_iterations_per_sec": npairs * iters / dt, "registrations_per_sec": npairs / dt,
-                 "correspondences_per_sec": npairs * n * (iters + 1) / dt,
-                 "kernel": "gridb_pass_kernel", "avg_launch_ms": kms, "launches": kn,
-                 "bound": "residency / HBM (64 B of traffic per source and pass: float4 source in and out, winner, skip state)",
-                 "queries_per_sec_in_kernel": npairs * n / (kms * 1e-3) if kms else None,
-                 "compulsory_bytes_per_launch": comp, "frac_of_hbm_peak": comp / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if kms else None,
-                 "traffic": read_traffic("gridb_pass"),
-                 "frac_by_pmc_traffic": (read_traffic("gridb_pass") / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (kms and read_traffic("gridb_pass")) else None,
-                 "result_iterations": int(res[0].iterations)}
-    del d_src, d_tgt, src, tgt
+    if "c3" in legs:
+        # ---- C3: 1024 x (10k x 10k), 20 fixed iterations + fitness, one kss_icp_batch_dev call -----------------------
+        npairs, n, iters = 1024, 10000, 20
+        src = np.empty((npairs * n, 3), np.float32); tgt = np.empty((npairs * n, 3), np.float32)
+        for i in range(npairs):
+            s, t = S.config_c3_pair(i, n)
+            src[i * n:(i + 1) * n] = s; tgt[i * n:(i + 1) * n] = t
+        off = np.arange(npairs + 1, dtype=np.int64) * n
+        d_src = torch.from_numpy(src).cuda(); d_tgt = torch.from_numpy(tgt).cuda()
+        p = ctx.icp_params(max_iterations=iters, fixed_iterations=1)
+        ctx.icp_batch_dev(d_src.data_ptr(), off, d_tgt.data_ptr(), off, p)
+        ctx.profile_enable(True); ctx.profile_reset()
+        reps = 3
+        sync(); t0 = time.perf_counter()
+        for _ in range(reps):
+            res = ctx.icp_batch_dev(d_src.data_ptr(), off, d_tgt.data_ptr(), off, p)
+        sync(); dt = (time.perf_counter() - t0) / reps
+        kms, kn = kernel_time(pkg.K_GRID_NN)
+        rms, rn = kernel_time(pkg.K_RESIDENT)
+        _, runits = ctx.profile_get(pkg.K_RESIDENT_PASS)
+        bms, bn = kernel_time(pkg.K_GRID_BUILD)
+        ctx.profile_enable(False)
+        comp = 12.0 * (2 * npairs * n) + 8.0 * npairs * n           # SURVEY 8d compulsory bytes of one pass over the batch
+        out["c3"] = {"workload": "C3: %d independent %dx%d pairs in one kss_icp_batch_dev call, %d fixed ICP iterations + fitness pass, setup included" % (npairs, n, n, iters),
+                     "ms_per_batch": dt * 1e3, "pair_iterations_per_sec": npairs * iters / dt, "registrations_per_sec": npairs / dt,
+                     "correspondences_per_sec": npairs * n * (iters + 1) / dt, "cell_list_build_ms": bms,
+                     "result_iterations": int(res[0].iterations)}
+        if rn:   # the pair-resident engine: ONE launch runs every pass of every pair (kss_resident.hip)
+            passes = iters + 1
+            pass_eq = rms / passes                       # the launch's time per pass of the whole batch
+            tr = read_traffic("resident_icp")
+            out["c3"].update({"kernel": "resident_icp_kernel", "avg_launch_ms": rms, "launches": rn, "pair_passes_per_launch": runits / rn if rn else None,
+                              "ms_per_pass_of_the_batch": pass_eq,
+                              "bound": "VALU / LDS latency inside one CU per pair (targets and cell table in LDS, sources in registers: a pass moves no "
+                                       "source or target through HBM; the canonical f64 sum tree is ~60 % of a pass's instructions)",
+                              "queries_per_sec_in_kernel": npairs * n * passes / (rms * 1e-3),
+                              "compulsory_bytes_per_pass": comp, "frac_of_hbm_peak": comp / (pass_eq * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "traffic": tr, "traffic_per_pass": tr / passes if tr else None,
+                              "frac_by_pmc_traffic": (tr / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else None})
+        else:
+            out["c3"].update({"kernel": "gridb_pass_kernel", "avg_launch_ms": kms, "launches": kn,
+                              "bound": "residency / HBM (64 B of traffic per source and pass: float4 source in and out, winner, skip state)",
+                              "queries_per_sec_in_kernel": npairs * n / (kms * 1e-3) if kms else None,
+                              "compulsory_bytes_per_launch": comp, "frac_of_hbm_peak": comp / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if kms else None,
+                              "traffic": read_traffic("gridb_pass"),
+                              "frac_by_pmc_traffic": (read_traffic("gridb_pass") / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (kms and read_traffic("gridb_pass")) else None})
+        del d_src, d_tgt, src, tgt
 
-    # ---- C4: 1M x 1M, 2x scale + 60 deg: pre-shape of both clouds, one NN pass, 10 ICP iterations ------------------
-    n = 1000000
-    src, tgt = S.config_c4(n)
-    d_src = torch.from_numpy(src).cuda(); d_tgt = torch.from_numpy(tgt).cuda()
-    for _ in range(3):
-        (cS, rS), (cT, rT) = ctx.preshape_stats_pair_dev(d_src.data_ptr(), n, d_tgt.data_ptr(), n, pkg.binding.F32)
-    ctx.profile_enable(True); ctx.profile_reset()
-    reps = 20
-    sync(); t0 = time.perf_counter()
-    for _ in range(reps):
-        (cS, rS), (cT, rT) = ctx.preshape_stats_pair_dev(d_src.data_ptr(), n, d_tgt.data_ptr(), n, pkg.binding.F32)
-    sync(); pre_dt = (time.perf_counter() - t0) / reps
-    pms, pn = kernel_time(pkg.K_PRESHAPE)
-    # S' on the device (f64 as the reference holds clouds), narrowed for the NN engine
-    d_s64 = d_src.to(torch.float64); d_sp = torch.empty_like(d_s64)
-    pose = ctx.make_pose([cT[k] - cS[k] for k in range(3)], cT, rT / rS, [0.0, 0.0, 0.0])
-    ctx.pose_apply_dev(d_s64.data_ptr(), n, pose, d_sp.data_ptr()); ctx.synchronize()
-    d_pre = d_sp.to(torch.float32).contiguous()
-    d_idx = torch.empty(n, dtype=torch.int32, device="cuda"); d_d2 = torch.empty(n, dtype=torch.float32, device="cuda")
-    ctx.nn_dev(d_pre.data_ptr(), n, d_tgt.data_ptr(), n, d_idx.data_ptr(), d_d2.data_ptr())
-    sync(); t0 = time.perf_counter()
-    ctx.nn_dev(d_pre.data_ptr(), n, d_tgt.data_ptr(), n, d_idx.data_ptr(), d_d2.data_ptr())
-    sync(); nn_dt = time.perf_counter() - t0
-    p = ctx.icp_params(max_iterations=10, fixed_iterations=1)
-    ctx.icp_dev(d_pre.data_ptr(), n, d_tgt.data_ptr(), n, p)
-    ctx.profile_enable(5)        # (a bracketed launch is a plain one: sample a few of the 11, keep the others gated)
-    ctx.profile_reset()
-    sync(); t0 = time.perf_counter()
-    r = ctx.icp_dev(d_pre.data_ptr(), n, d_tgt.data_ptr(), n, p)
-    sync(); icp_dt = time.perf_counter() - t0
-    kms, kn = kernel_time(pkg.K_GRID_NN)
-    ctx.profile_enable(False)
-    comp = 12.0 * (2 * n) + 8.0 * n
-    out["c4"] = {"workload": "C4: one %dx%d pair, source = 2 x R(60 deg) x target + t: pre-shape statistics of both clouds (one call), one exact NN pass (setup included), 10 fixed ICP iterations + fitness (setup included)" % (n, n),
-                 "preshape_stats_ms": pre_dt * 1e3, "preshape_event_ms": pms, "preshape_algorithmic_bytes": 24.0 * 2 * n,
-                 "preshape_frac_of_hbm_peak": 24.0 * 2 * n / pre_dt / 1e9 / HBM_PEAK_GBS, "scale_estimate": rT / rS,
-                 "nn_pass_ms": nn_dt * 1e3, "icp_10_iters_ms": icp_dt * 1e3, "icp_iterations_per_sec": 10 / icp_dt,
-                 "kernel": "grid_pass_kernel", "avg_launch_ms": kms, "launches": kn, "bound": "vector-memory pipe / L2 latency",
-                 "queries_per_sec_in_kernel": n / (kms * 1e-3) if kms else None,
-                 "compulsory_bytes_per_launch": comp, "frac_of_hbm_peak": comp / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if kms else None,
-                 "fitness": float(r.fitness)}
-    del d_src, d_tgt, d_s64, d_sp, d_pre, d_idx, d_d2
+    if "c4" in legs:
+        # ---- C4: 1M x 1M, 2x scale + 60 deg: pre-shape of both clouds, one NN pass, 10 ICP iterations ------------------
+        n = 1000000
+        src, tgt = S.config_c4(n)
+        d_src = torch.from_numpy(src).cuda(); d_tgt = torch.from_numpy(tgt).cuda()
+        for _ in range(3):
+            (cS, rS), (cT, rT) = ctx.preshape_stats_pair_dev(d_src.data_ptr(), n, d_tgt.data_ptr(), n, pkg.binding.F32)
+        ctx.profile_enable(True); ctx.profile_reset()
+        reps = 20
+        sync(); t0 = time.perf_counter()
+        for _ in range(reps):
+            (cS, rS), (cT, rT) = ctx.preshape_stats_pair_dev(d_src.data_ptr(), n, d_tgt.data_ptr(), n, pkg.binding.F32)
+        sync(); pre_dt = (time.perf_counter() - t0) / reps
+        pms, pn = kernel_time(pkg.K_PRESHAPE)
+        # S' on the device (f64 as the reference holds clouds), narrowed for the NN engine
+        d_s64 = d_src.to(torch.float64); d_sp = torch.empty_like(d_s64)
+        pose = ctx.make_pose([cT[k] - cS[k] for k in range(3)], cT, rT / rS, [0.0, 0.0, 0.0])
+        ctx.pose_apply_dev(d_s64.data_ptr(), n, pose, d_sp.data_ptr()); ctx.synchronize()
+        d_pre = d_sp.to(torch.float32).contiguous()
+        d_idx = torch.empty(n, dtype=torch.int32, device="cuda"); d_d2 = torch.empty(n, dtype=torch.float32, device="cuda")
+        ctx.nn_dev(d_pre.data_ptr(), n, d_tgt.data_ptr(), n, d_idx.data_ptr(), d_d2.data_ptr())
+        sync(); t0 = time.perf_counter()
+        ctx.nn_dev(d_pre.data_ptr(), n, d_tgt.data_ptr(), n, d_idx.data_ptr(), d_d2.data_ptr())
+        sync(); nn_dt = time.perf_counter() - t0
+        p = ctx.icp_params(max_iterations=10, fixed_iterations=1)
+        ctx.icp_dev(d_pre.data_ptr(), n, d_tgt.data_ptr(), n, p)
+        ctx.profile_enable(5)        # (a bracketed launch is a plain one: sample a few of the 11, keep the others gated)
+        ctx.profile_reset()
+        sync(); t0 = time.perf_counter()
+        r = ctx.icp_dev(d_pre.data_ptr(), n, d_tgt.data_ptr(), n, p)
+        sync(); icp_dt = time.perf_counter() - t0
+        kms, kn = kernel_time(pkg.K_GRID_NN)
+        ctx.profile_enable(False)
+        comp = 12.0 * (2 * n) + 8.0 * n
+        out["c4"] = {"workload": "C4: one %dx%d pair, source = 2 x R(60 deg) x target + t: pre-shape statistics of both clouds (one call), one exact NN pass (setup included), 10 fixed ICP iterations + fitness (setup included)" % (n, n),
+                     "preshape_stats_ms": pre_dt * 1e3, "preshape_event_ms": pms, "preshape_algorithmic_bytes": 24.0 * 2 * n,
+                     "preshape_frac_of_hbm_peak": 24.0 * 2 * n / pre_dt / 1e9 / HBM_PEAK_GBS, "scale_estimate": rT / rS,
+                     "nn_pass_ms": nn_dt * 1e3, "icp_10_iters_ms": icp_dt * 1e3, "icp_iterations_per_sec": 10 / icp_dt,
+                     "kernel": "grid_pass_kernel", "avg_launch_ms": kms, "launches": kn, "bound": "vector-memory pipe / L2 latency",
+                     "queries_per_sec_in_kernel": n / (kms * 1e-3) if kms else None,
+                     "compulsory_bytes_per_launch": comp, "frac_of_hbm_peak": comp / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if kms else None,
+                     "traffic": read_traffic("grid_pass_c4"),
+                     "frac_by_pmc_traffic": (read_traffic("grid_pass_c4") / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (kms and read_traffic("grid_pass_c4")) else None,
+                     "fitness": float(r.fitness)}
+        del d_src, d_tgt, d_s64, d_sp, d_pre, d_idx, d_d2
 
-    # ---- streaming: pre-shape statistics (two read passes) of 64M f32 points = 768 MB, past every cache ------------------
-    n = 64 * 1024 * 1024
-    x = torch.rand((n, 3), dtype=torch.float32, device="cuda")
-    ctx.preshape_stats_dev(x.data_ptr(), pkg.binding.F32, n)
-    ctx.profile_enable(True); ctx.profile_reset()
-    reps = 5
-    sync(); t0 = time.perf_counter()
-    for _ in range(reps):
+    if "stream" in legs:
+        # ---- streaming: pre-shape statistics (two read passes) of 64M f32 points = 768 MB, past every cache ------------------
+        n = 64 * 1024 * 1024
+        x = torch.rand((n, 3), dtype=torch.float32, device="cuda")
         ctx.preshape_stats_dev(x.data_ptr(), pkg.binding.F32, n)
-    sync(); dt = (time.perf_counter() - t0) / reps
-    pms, pn = kernel_time(pkg.K_PRESHAPE)
-    ctx.profile_enable(False)
-    out["stream_64m"] = {"workload": "pre-shape statistics of one %d-point f32 cloud (768 MB, two read passes: sum + centroid, radius)" % n,
-                         "kernel": "preshape_sum_kernel + preshape_radius_kernel", "bound": "hbm", "ms": dt * 1e3, "event_ms_both_launches": pms,
-                         "algorithmic_bytes": 24.0 * n, "achieved_GBps": 24.0 * n / dt / 1e9, "frac_of_hbm_peak": 24.0 * n / dt / 1e9 / HBM_PEAK_GBS}
-    del x
+        ctx.profile_enable(True); ctx.profile_reset()
+        reps = 5
+        sync(); t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.preshape_stats_dev(x.data_ptr(), pkg.binding.F32, n)
+        sync(); dt = (time.perf_counter() - t0) / reps
+        pms, pn = kernel_time(pkg.K_PRESHAPE)
+        ctx.profile_enable(False)
+        out["stream_64m"] = {"workload": "pre-shape statistics of one %d-point f32 cloud (768 MB, two read passes: sum + centroid, radius)" % n,
+                             "kernel": "preshape_sum_kernel + preshape_radius_kernel", "bound": "hbm", "ms": dt * 1e3, "event_ms_both_launches": pms,
+                             "algorithmic_bytes": 24.0 * n, "achieved_GBps": 24.0 * n / dt / 1e9, "frac_of_hbm_peak": 24.0 * n / dt / 1e9 / HBM_PEAK_GBS}
+        del x
     return out
 
 
@@ -449,6 +593,11 @@ def main():
         ctx.profile_enable(False)
         brute = (bdt, bms, bn, blast)
 
+    # ---- C5 (world > 1, or KSS_BENCH_FORCE_DIST=1 with one rank): every rank's 1024-pair shard + ONE gather -- all ranks take part
+    c5 = None
+    if (world > 1 or force_dist) and not split and not a.no_secondary and "c5" in a.legs.split(","):
+        c5 = c5_leg(pkg, ctx, torch, np, dist, world, rank, dev, pairs_per_rank=a.c5_pairs)
+
     if rank == 0:
         value = a.steps * a.iters * (1 if split else world) / dt   # split: the ranks share ONE registration
         passes = a.iters + 1
@@ -545,7 +694,12 @@ def main():
                                   "max_abs_T_diff_vs_default": float(np.abs(np.array(blast.T) - np.array(last.T)).max())}
         if world == 1 and not a.no_secondary:
             del d_src, d_tgt
-            out["secondary"] = secondary_legs(pkg, ctx, torch, np)
+            legs = set(a.legs.split(","))
+            out["secondary"] = secondary_legs(pkg, ctx, torch, np, legs)
+            if "register" in legs:
+                out["secondary"]["register"] = register_leg(pkg, ctx, np)
+        if c5 is not None:
+            out.setdefault("secondary", {})["c5"] = c5
         if world == 1 and not a.no_cpu_baseline:
             cb = cpu_baseline(a.n, a.iters, src, tgt)
             Tg = np.array(last.T, dtype=np.float64)

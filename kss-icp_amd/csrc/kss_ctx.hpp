@@ -32,6 +32,7 @@ struct DevBuf {
 
 struct kss_ctx {
     int device = 0;
+    int cu_count = 0;                   // compute units of the device (0: not asked yet)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;

@@ -11,6 +11,20 @@
 
 namespace kss {
 
+static int restore_zero_at_rest(kss_ctx* c);
+
+// Workgroups of ONE launch that are certainly on the chip at the same time: one per compute unit of THIS device (the fused
+// single-pair kernels need at most one CU's registers and LDS each).  Tagged rows and chained launches rely on it; on a
+// partitioned or smaller part the limit shrinks with the CU count instead of stalling every chain until its polls run out.
+static int resident_rows_limit(kss_ctx* c) {
+    if (c->cu_count <= 0) {
+        hipDeviceProp_t prop;
+        c->cu_count = hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+        (void)hipGetLastError();
+    }
+    return c->cu_count;
+}
+
 constexpr int PUB_PAIRS = 32;   // brute-force batches up to this many pairs are awaited by spinning on the published sums
 static int ensure_pub(kss_ctx* c, int npairs = PUB_PAIRS);   // host-mapped result slots (defined with wait_seq)
 
@@ -404,11 +418,11 @@ static int grid_setup_batch(kss_ctx* c, IcpPlan& pl) {
     for (int p = 0; p < np; ++p) half = half && pl.g[p].nt < 65536 && pl.g[p].ns < 65536;
     static const bool no_half = getenv("KSS_GRIDB_NOHALF") != nullptr;   // A/B switch: 32-bit counters
     if (no_half) half = false;
-    if (most_cells <= gridb_lds_max_cells(half) && !no_lds) {
-        // every pair's counters fit a CU's LDS: one workgroup per pair builds both of its lists (kss_grid.hip)
+    // every pair's counters fit a CU's LDS: one workgroup per pair builds both of its lists (kss_grid.hip)
+    const bool built_in_lds = most_cells <= gridb_lds_max_cells(half) && !no_lds &&
         launch_gridb_build_lds(c->stream, (const float4*)c->tgt4.p, (float4*)c->src0.p, (float4*)c->cur[0].p, (const GridPairDev*)c->g_pairs.p, np,
                                (int32_t*)c->g_start.p + 1, (float4*)c->g_sorted.p, (int)most_cells, half);
-    } else {
+    if (!built_in_lds) {
         // (zero at rest, as the single-pair build expects of this buffer: a plain ensure() here once left the slack behind
         // `cells` uninitialised, and a later single pair with more cells scanned garbage counts -- see DESIGN.md, incidents)
         KCHK(ensure_zeroed(c, c->g_counts, (size_t)cells * sizeof(int32_t)));
@@ -457,14 +471,26 @@ static int ensure_pub(kss_ctx* c, int npairs) {
 // without progress it falls back to the stream sync, which also surfaces a faulted kernel instead of spinning forever.
 static void gated_cancel(kss_ctx* c);
 
+// A result slot is ONE 16-byte device store {bits of the f64, low half of the launch number, check word of those three}.  The
+// host reads it as two 8-byte loads; it takes the value when the number matches AND the check word fits the bits it read -- a
+// slot seen torn (new number, old bits or the reverse) fails the check and is simply read again.
+static inline bool slot_value(const unsigned long long* sl, int k, unsigned long long want, unsigned long long* bits_out) {
+    const unsigned long long w = __atomic_load_n(&sl[2 * k + 1], __ATOMIC_ACQUIRE);
+    if ((unsigned)w != (unsigned)want) return false;
+    const unsigned long long bits = __atomic_load_n(&sl[2 * k], __ATOMIC_RELAXED);
+    if ((unsigned)(w >> 32) != kss_mix3((unsigned)bits, (unsigned)(bits >> 32), (unsigned)w)) return false;
+    *bits_out = bits;
+    return true;
+}
+
 // the 20 sums of pair p of launch `want`, if they have all landed
 static inline bool collect_pair(kss_ctx* c, int p, unsigned long long want) {
     const unsigned long long* sl = c->h_seq + (size_t)2 * NSUMS * p;
-    if (__atomic_load_n(&sl[2 * (NSUMS - 1) + 1], __ATOMIC_ACQUIRE) != want) return false;   // the highest slot is usually the last to land
+    unsigned long long bits;
+    if (!slot_value(sl, NSUMS - 1, want, &bits)) return false;   // the highest slot is usually the last to land
     double* out = (double*)c->h_sums + (size_t)NSUMS * p;
     for (int k = NSUMS - 1; k >= 0; --k) {
-        if (__atomic_load_n(&sl[2 * k + 1], __ATOMIC_ACQUIRE) != want) return false;
-        const unsigned long long bits = __atomic_load_n(&sl[2 * k], __ATOMIC_RELAXED);
+        if (!slot_value(sl, k, want, &bits)) return false;
         std::memcpy(&out[k], &bits, sizeof(double));
     }
     return true;
@@ -506,8 +532,8 @@ int wait_slots(kss_ctx* c, int nslots, double* out) {
     const unsigned long long want = c->seq;
     auto collect = [&]() -> bool {
         for (int k = nslots - 1; k >= 0; --k) {
-            if (__atomic_load_n(&c->h_seq[2 * k + 1], __ATOMIC_ACQUIRE) != want) return false;
-            const unsigned long long bits = __atomic_load_n(&c->h_seq[2 * k], __ATOMIC_RELAXED);
+            unsigned long long bits;
+            if (!slot_value(c->h_seq, k, want, &bits)) return false;
             std::memcpy(&out[k], &bits, sizeof(double));
         }
         return true;
@@ -580,11 +606,25 @@ static void gated_release(kss_ctx* c, const PairState& st, int skip) {   // tran
         std::memcpy(words, &st, sizeof st);
         words[14] = skip;                       // pad[0]
         unsigned int* slot = c->gate_bar + 32 * c->gated.slot;   // two records, 128 bytes apart
-        for (int g = 0; g < 5; ++g) {
-            const __m128i v = _mm_set_epi32(c->gated.stamp, words[3 * g + 2], words[3 * g + 1], words[3 * g]);
-            _mm_store_si128((__m128i*)(slot + 4 * g), v);
+        // (test hook: the n-th record first arrives with a granule whose words do not fit its check -- what a torn 16-byte
+        // store would look like -- and only a while later as it should be; the kernel must not take the first for data)
+        static const long torn_at = getenv("KSS_TEST_TORN_GATE") ? atol(getenv("KSS_TEST_TORN_GATE")) : -1;
+        static long released = 0;
+        const bool torn = ++released == torn_at;
+        for (int pass = torn ? 0 : 1; pass < 2; ++pass) {
+            for (int g = 0; g < 5; ++g) {
+                // the stamp word carries the check of the granule's three data words
+                const unsigned tag = (unsigned)c->gated.stamp + kss_mix3((unsigned)words[3 * g], (unsigned)words[3 * g + 1], (unsigned)words[3 * g + 2]);
+                const int w1 = pass == 0 && g == 1 ? words[3 * g + 1] ^ 0x00010000 : words[3 * g + 1];
+                const __m128i v = _mm_set_epi32((int)tag, words[3 * g + 2], w1, words[3 * g]);
+                _mm_store_si128((__m128i*)(slot + 4 * g), v);
+            }
+            _mm_sfence();
+            if (pass == 0) {
+                const auto t0 = std::chrono::steady_clock::now();
+                while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < 200.0) __builtin_ia32_pause();
+            }
         }
-        _mm_sfence();
     } else {
         PairState* rec = &c->h_xf[c->gated.slot];
         for (int k = 0; k < 12; ++k) rec->m[k] = st.m[k];
@@ -645,6 +685,11 @@ static PassArgs pass_args(kss_ctx* c, const IcpPlan& pl, const float4* d_in, flo
     a.rows = (double*)c->partials.p; a.tickets = (int32_t*)c->pair_ticket.p;
     a.pub = c->h_seq_dev;
     a.idx_out = d_idx_out; a.d2_out = d_d2_out;
+    {   // test hook: the n-th fused launch stores one of its result slots torn first (kss_grid.hip)
+        static const long torn_at = getenv("KSS_TEST_TORN_SLOT") ? atol(getenv("KSS_TEST_TORN_SLOT")) : -1;
+        static long launches = 0;
+        a.test_torn = torn_at > 0 && ++launches == torn_at ? 1 : 0;
+    }
     if (pl.gridb) {
         a.pairs = (const GridPairDev*)c->g_pairs.p;
         a.row_pair = (const int32_t*)c->g_rowpair.p;
@@ -653,7 +698,7 @@ static PassArgs pass_args(kss_ctx* c, const IcpPlan& pl, const float4* d_in, flo
         // rows as tagged granules + a designated reducer instead of drain + ticket: only when every workgroup is resident at
         // once (one per CU), so the reducer never polls for a workgroup that cannot start.  KSS_TAGGED_ROWS=0: A/B switch.
         static const bool tagged = getenv("KSS_TAGGED_ROWS") == nullptr || atoi(getenv("KSS_TAGGED_ROWS")) != 0;
-        a.tagged_rows = tagged && pl.total_rows <= 256 ? 1 : 0;
+        a.tagged_rows = tagged && pl.total_rows <= resident_rows_limit(c) ? 1 : 0;
     }
     return a;
 }
@@ -766,6 +811,11 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
                 G.pending = false; G.steps_left = 0;
                 c->err.clear();
                 std::fprintf(stderr, "[kss] a waiting kernel was not answered in time and left; the pass is launched again\n");
+                // With more rows than resident workgroups the launch may have left in part only: workgroups that started after
+                // the answer finally arrived have run, written their sources and drawn tickets that nobody completed.  The
+                // stream has drained (wait_seq synchronised): re-arm everything that is zero at rest before the plain launch.
+                c->ws_dirty = true;
+                KCHK(restore_zero_at_rest(c));
                 ProfScope ps(c, KSS_K_GRID_NN);
                 a.ps0 = hs[0];
                 a.seq = ++c->seq;
@@ -990,14 +1040,12 @@ static unsigned int* resident_gate(kss_ctx* c, int npairs) {
     return c->res_gate;
 }
 
-// the 20 sums of pair p under sequence number `want` (low 32 bits + check word, kss_resident.hip), if they have all landed
+// the 20 sums of pair p under sequence number `want`, if they have all landed
 static inline bool resident_collect(const unsigned long long* h_seq, int p, unsigned long long want, double* out) {
     const unsigned long long* sl = h_seq + (size_t)2 * NSUMS * p;
     for (int k = NSUMS - 1; k >= 0; --k) {
-        const unsigned long long w = __atomic_load_n(&sl[2 * k + 1], __ATOMIC_ACQUIRE);
-        if ((unsigned)w != (unsigned)want) return false;
-        const unsigned long long bits = __atomic_load_n(&sl[2 * k], __ATOMIC_RELAXED);
-        if ((unsigned)(w >> 32) != kss_mix3((unsigned)bits, (unsigned)(bits >> 32), (unsigned)w)) return false;   // seen torn: look again
+        unsigned long long bits;
+        if (!slot_value(sl, k, want, &bits)) return false;
         std::memcpy(&out[k], &bits, sizeof(double));
     }
     return true;
@@ -1067,28 +1115,41 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
         mat4_identity(H[p].fin);
     }
     if (P.trace_n) *P.trace_n = 0;
-    std::atomic<int> failed{0}, kernel_done{0};
+    std::atomic<int> failed{0}, kernel_done{0}, pairs_left{np};
     std::atomic<long long> units{0};
     const unsigned long long* h_seq = c->h_seq;
+    // test hooks: the n-th record first arrives with a granule whose words do not fit its check word (what a torn 16-byte store
+    // would look like), the right one 200 us later; the n-th answer is held back for 300 ms (a stalled host thread: with a small
+    // KSS_GATE_POLLS the workgroup leaves, and the call starts over on the other engine)
+    static const long torn_at = getenv("KSS_TEST_TORN_RES_GATE") ? atol(getenv("KSS_TEST_TORN_RES_GATE")) : -1;
+    static const long stall_at = getenv("KSS_TEST_RES_STALL") ? atol(getenv("KSS_TEST_RES_STALL")) : -1;
+    std::atomic<long> sent{0};
     auto send = [&](int p, const float* T, int apply, int mode) {   // the gate record of pair p's NEXT pass (number H[p].k + 1)
         unsigned w[15];
         if (T) std::memcpy(w, T, 12 * sizeof(float)); else std::memset(w, 0, 12 * sizeof(float));
         w[12] = 1u; w[13] = (unsigned)apply; w[14] = (unsigned)mode;
         const unsigned stamp = a.stamp0 + (unsigned)(H[p].k + 1);
         unsigned int* slot = gate + (size_t)p * 32;
-        for (int g = 0; g < 5; ++g) {
-            const unsigned tag = stamp + kss_mix3(w[3 * g], w[3 * g + 1], w[3 * g + 2]);
-            _mm_store_si128((__m128i*)(slot + 4 * g), _mm_set_epi32((int)tag, (int)w[3 * g + 2], (int)w[3 * g + 1], (int)w[3 * g]));
+        const long nth = sent.fetch_add(1) + 1;
+        if (nth == stall_at) std::this_thread::sleep_for(std::chrono::milliseconds(300));
+        for (int pass = nth == torn_at ? 0 : 1; pass < 2; ++pass) {
+            for (int g = 0; g < 5; ++g) {
+                const unsigned tag = stamp + kss_mix3(w[3 * g], w[3 * g + 1], w[3 * g + 2]);   // stamp + check of the granule's three words
+                const unsigned w1 = pass == 0 && g == 2 ? w[3 * g + 1] ^ 0x00010000u : w[3 * g + 1];
+                _mm_store_si128((__m128i*)(slot + 4 * g), _mm_set_epi32((int)tag, (int)w[3 * g + 2], (int)w1, (int)w[3 * g]));
+            }
+            _mm_sfence();
+            if (pass == 0) std::this_thread::sleep_for(std::chrono::microseconds(200));
         }
-        _mm_sfence();
     };
     auto serve = [&](int t, int nt) {
         int remaining = 0;
         for (int p = t; p < np; p += nt) ++remaining;
-        long idle = 0;
+        long idle = 0, grace = 0;
         double s[NSUMS];
         long long my_units = 0;
-        while (remaining > 0 && !failed.load(std::memory_order_relaxed)) {
+        // (the calling thread stays until EVERY pair is done: it is the one that asks HIP whether the kernel is still there)
+        while ((remaining > 0 || (t == 0 && pairs_left.load(std::memory_order_relaxed) > 0)) && !failed.load(std::memory_order_relaxed)) {
             bool progress = false;
             for (int p = t; p < np; p += nt) {
                 PairHost& h = H[p];
@@ -1098,7 +1159,7 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
                 ++my_units;
                 if (h.phase == PH_FIT) {   // getFitnessScore(): mean d2 over ALL source points
                     h.fitness = s[17] / (double)pl.g[p].ns;
-                    h.phase = PH_DONE; --remaining;
+                    h.phase = PH_DONE; --remaining; pairs_left.fetch_sub(1, std::memory_order_relaxed);
                     continue;
                 }
                 bool finished = false;
@@ -1129,16 +1190,17 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
                     h.phase = PH_FIT;
                 } else {
                     send(p, nullptr, 0, 2);
-                    h.phase = PH_DONE; --remaining;
+                    h.phase = PH_DONE; --remaining; pairs_left.fetch_sub(1, std::memory_order_relaxed);
                 }
             }
-            if (progress) { idle = 0; continue; }
+            if (progress) { idle = 0; grace = 0; continue; }
             __builtin_ia32_pause();
             if (++idle % 4096 == 0) {
                 // nothing for a while: has the kernel gone?  (Only the calling thread talks to HIP.)  A workgroup that was not
-                // answered within its bounded poll has left; its pair will never publish
+                // answered within its bounded poll has left; its pair will never publish.  After the kernel has ended every
+                // result is in host memory already: a thread that still finds nothing for ~10 ms of polling gives up.
                 if (t == 0 && !kernel_done.load() && hipStreamQuery(c->stream) != hipErrorNotReady) kernel_done.store(1);
-                if (kernel_done.load() && idle > (1 << 16)) failed.store(1);   // (a few more rounds: results already on their way over PCIe)
+                if (kernel_done.load() && ++grace > 64) failed.store(1);
             }
         }
         units.fetch_add(my_units);
@@ -1355,7 +1417,9 @@ static int icp_loop(kss_ctx* c, const IcpPlan& pl_in, const kss_icp_params& P, k
         const bool cell_lists = plan->grid || plan->gridb;
         for (int p = 0; p < np; ++p) {
             set_state(hs[p], &fin[(size_t)p * 16], 1, 1);
-            if (cell_lists && plan == &pl_in && iters[p] >= 1) hs[p].pad[0] = 1 + ((iters[p] - 1) & 1);
+            // (a pair that ended without correspondences took part in one more pass than it counted: its last position is in
+            // the other buffer -- no claim is made for it, its sources simply search)
+            if (cell_lists && plan == &pl_in && iters[p] >= 1 && state[p] != KSS_STATE_NO_CORRESPONDENCES) hs[p].pad[0] = 1 + ((iters[p] - 1) & 1);
             mirror_state(bar, p, hs[p]);
         }
         c->fit_last = cell_lists && plan == &pl_in;

@@ -715,7 +715,7 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
                     const int w0 = __shfl(v, min(3 * g, 15), 64), w1 = __shfl(v, min(3 * g + 1, 15), 64), w2 = __shfl(v, min(3 * g + 2, 15), 64);
                     if (g < 5) {
                         u32x4 o;
-                        o.x = (unsigned)w0; o.y = (unsigned)w1; o.z = (unsigned)w2; o.w = (unsigned)gate_k;
+                        o.x = (unsigned)w0; o.y = (unsigned)w1; o.z = (unsigned)w2; o.w = (unsigned)gate_k + kss_mix3(o.x, o.y, o.z);
                         unsigned int* dst = gate_ptr + 4 * g;
                         asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(o) : "memory");
                     }
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
                 bool ok = true;
                 for (;;) {
                     asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(src) : "memory");   // system scope: the writer may be the host
-                    if (__builtin_amdgcn_ballot_w64((int)v.w == gate_k) == 0xffull) break;
+                    if (__builtin_amdgcn_ballot_w64(v.w - kss_mix3(v.x, v.y, v.z) == (unsigned)gate_k) == 0xffull) break;   // (stamp + check of the three words: a granule seen torn fails and is read again)
                     __builtin_amdgcn_s_sleep(1);
                     if (++n > a.gate_polls) { ok = false; break; }
                 }
@@ -1018,7 +1018,14 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
         // write-acknowledge round trip over PCIe) and no L2 write-back fence is needed
         const unsigned long long vb = (unsigned long long)__double_as_longlong(v);
         u32x4 o;
-        o.x = (unsigned)vb; o.y = (unsigned)(vb >> 32); o.z = (unsigned)seq_k; o.w = (unsigned)(seq_k >> 32);
+        o.x = (unsigned)vb; o.y = (unsigned)(vb >> 32); o.z = (unsigned)seq_k; o.w = kss_mix3(o.x, o.y, o.z);   // (check word: a slot seen torn is read again)
+        if (a.test_torn && threadIdx.x == 5) {   // test hook: first a slot whose data does not fit its check word, the real one a while later
+            u32x4 bad = o;
+            bad.x ^= 0x00100000u;
+            unsigned long long* dst0 = a.pub + 2 * ((int64_t)pi * NSUMS + threadIdx.x);
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" ::"v"(dst0), "v"(bad) : "memory");
+            for (int k = 0; k < 400; ++k) __builtin_amdgcn_s_sleep(64);
+        }
         unsigned long long* dst = a.pub + 2 * ((int64_t)pi * NSUMS + threadIdx.x);
         asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(o) : "memory");
         KSS_STAMP(4);
@@ -1255,7 +1262,7 @@ __global__ __launch_bounds__(256, KSS_BATCH2_WAVES) void gridb_pass_kernel(const
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
         const unsigned long long vb = (unsigned long long)__double_as_longlong(v);
         u32x4 o;
-        o.x = (unsigned)vb; o.y = (unsigned)(vb >> 32); o.z = (unsigned)a.seq; o.w = (unsigned)(a.seq >> 32);
+        o.x = (unsigned)vb; o.y = (unsigned)(vb >> 32); o.z = (unsigned)a.seq; o.w = kss_mix3(o.x, o.y, o.z);
         unsigned long long* dst = a.pub + 2 * ((int64_t)pi * NSUMS + threadIdx.x);
         asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(o) : "memory");
         KSS_STAMP(4);
@@ -1550,23 +1557,23 @@ __global__ __launch_bounds__(GB_THREADS) void gridb_build_pair_kernel(const floa
 }
 
 // max_cells: the largest grid of the batch; half: no pair has 65536 or more targets or sources
-void launch_gridb_build_lds(hipStream_t st, const float4* d_tgt4, float4* d_src, float4* d_tmp, const GridPairDev* d_pairs, int npairs,
+bool launch_gridb_build_lds(hipStream_t st, const float4* d_tgt4, float4* d_src, float4* d_tmp, const GridPairDev* d_pairs, int npairs,
                             int32_t* d_cell_start, float4* d_sorted, int max_cells, bool half) {
     const size_t bytes = half ? (size_t)((max_cells + 1) / 2) * 4 : (size_t)max_cells * 4;
-    static const bool attr_set = [] {   // dynamic LDS beyond 64 KB has to be allowed once per kernel
+    // dynamic LDS beyond 64 KB has to be allowed per kernel AND per device: asked for on every launch (the attribute applies
+    // to the device current at the call; a process-wide "done once" flag left a second device without it)
+    {
         const int most = GB_MAX_CELLS * 4;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gridb_build_pair_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gridb_build_pair_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
-        (void)hipGetLastError();
-        return true;
-    }();
-    (void)attr_set;
+        const void* fn = half ? reinterpret_cast<const void*>(&gridb_build_pair_kernel<true>) : reinterpret_cast<const void*>(&gridb_build_pair_kernel<false>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, most) != hipSuccess) { (void)hipGetLastError(); return false; }
+    }
     if (half)
         hipLaunchKernelGGL(gridb_build_pair_kernel<true>, dim3(npairs), dim3(GB_THREADS), bytes, st, d_tgt4, (const float4*)d_src, d_tmp, d_src, d_pairs,
                            d_cell_start, d_sorted);
     else
         hipLaunchKernelGGL(gridb_build_pair_kernel<false>, dim3(npairs), dim3(GB_THREADS), bytes, st, d_tgt4, (const float4*)d_src, d_tmp, d_src, d_pairs,
                            d_cell_start, d_sorted);
+    return true;
 }
 
 // statistics for the roofline statement: evaluations of one r = 1 pass and occupied cells (profiling only)

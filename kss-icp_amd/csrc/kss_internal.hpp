@@ -124,6 +124,7 @@ struct PassArgs {
     unsigned long long* pub; unsigned long long seq;
     int32_t* idx_out; float* d2_out;
     unsigned long long* stamps;                 // diagnostics (null in production): see KSS_STAMP below
+    int32_t test_torn;                          // test hook: one result slot is first stored with data that does not fit its check word
 };
 
 // ---- the pair-resident ICP kernel (kss_resident.hip) ---------------------------------------------------------------
@@ -226,7 +227,8 @@ void launch_gridb_sort_sources(hipStream_t st, const float4* d_src, int total_sr
 int gridb_lds_max_cells(bool half);
 // all of a batch's cell lists, one workgroup per pair, counters in LDS sized for the largest grid of the batch (max_cells <=
 // gridb_lds_max_cells(half)); half: 16-bit counters, allowed when no pair has 65536 or more targets or sources
-void launch_gridb_build_lds(hipStream_t st, const float4* d_tgt4, float4* d_src, float4* d_tmp, const GridPairDev* d_pairs, int npairs,
+// (false: the device refused the LDS size -- the caller builds through the global-atomic path)
+bool launch_gridb_build_lds(hipStream_t st, const float4* d_tgt4, float4* d_src, float4* d_tmp, const GridPairDev* d_pairs, int npairs,
                             int32_t* d_cell_start, float4* d_sorted, int max_cells, bool half);
 void launch_grid_stats(hipStream_t st, const float4* d_src, int ns, const GridParams& gp, const int32_t* d_cell_start,
                        unsigned long long* d_out /* [0] evaluations of the 3x3x3 block, [1] occupied cells */);

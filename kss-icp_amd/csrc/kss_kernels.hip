@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void corr_reduce_kernel(const RedWork* __restr
             typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
             const unsigned long long vb = (unsigned long long)__double_as_longlong(v);
             u32x4 o;
-            o.x = (unsigned)vb; o.y = (unsigned)(vb >> 32); o.z = (unsigned)seq; o.w = (unsigned)(seq >> 32);
+            o.x = (unsigned)vb; o.y = (unsigned)(vb >> 32); o.z = (unsigned)seq; o.w = kss_mix3(o.x, o.y, o.z);
             unsigned long long* dst = pub + 2 * ((int64_t)w.pair * NSUMS + t0);
             asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(o) : "memory");
         }
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256) void preshape_radius_kernel(PreArgs a, double*
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
         const unsigned long long vb = (unsigned long long)__double_as_longlong(o);
         u32x4 w;
-        w.x = (unsigned)vb; w.y = (unsigned)(vb >> 32); w.z = (unsigned)seq; w.w = (unsigned)(seq >> 32);
+        w.x = (unsigned)vb; w.y = (unsigned)(vb >> 32); w.z = (unsigned)seq; w.w = kss_mix3(w.x, w.y, w.z);
         unsigned long long* dst = pub + 2 * slot;
         asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(w) : "memory");
     }

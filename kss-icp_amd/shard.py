@@ -29,6 +29,12 @@ def records_to_array(records, lo):
     GLOBAL pair index; other fixed-size records (kss_register_result: s, R, t, ...) are copied as they are."""
     n = len(records)
     size = C.sizeof(records[0]) if n else RECORD_BYTES
+    if n and isinstance(records, C.Array) and hasattr(records[0], "pair_id"):
+        # one contiguous ctypes array (what kss_icp_batch_dev fills): no per-record marshalling -- a 1024-record shard is 96 KB
+        out = np.frombuffer(records, dtype=np.uint8).reshape(n, size).copy()
+        off = type(records[0]).pair_id.offset
+        out[:, off:off + 4] = (lo + np.arange(n, dtype=np.int32)).view(np.uint8).reshape(n, 4)
+        return out
     out = np.zeros((n, size), np.uint8)
     for i in range(n):
         if hasattr(records[i], "pair_id"):

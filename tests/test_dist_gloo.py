@@ -145,12 +145,15 @@ def test_bench_gpus_n_starts_n_ranks():
     touches torch / HIP) and print ONE JSON line with n_gpus = 2.  --dry-run-dist swaps the registration for a stand-in
     so that the protocol (gloo group, barriers, MAX over ranks, padded record gather) runs on CPU."""
     import json
-    r = _run_bench(["--gpus", "2", "--dry-run-dist", "--steps", "3", "--warmup", "1"])
+    r = _run_bench(["--gpus", "2", "--dry-run-dist", "--steps", "3", "--warmup", "1", "--c5-pairs", "96"])
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["dry_run"] is True
+    # the C5 leg's protocol (every rank's shard, ONE gather, records in global pair order) with stand-in records
+    c5 = d["secondary"]["c5"]
+    assert c5["n_gpus"] == 2 and c5["pairs_total"] == 192 and c5["gathered_pair_ids_in_order"] is True
     assert d["records_gathered_ok"] is True and d["scaling"] == "weak" and d["metric"] == "icp_iterations_per_sec"
     # the time is the slowest rank's: rank 1 sleeps 4 ms per step
     assert d["ms_per_step"] >= 4.0

@@ -221,3 +221,21 @@ def test_batch_builds_with_wide_and_narrow_counters(ctx, pkg):
     batch([15000, 9000, 14000, 3000], 900)          # ~48k cells: LDS only with 16-bit counters
     batch([6000, 70000, 5000], 910)                 # a pair of >= 65536 points: 32-bit counters are not enough either -> global path
     batch([2500, 4000, 8000, 1200, 600], 920)       # small grids: LDS, 16-bit
+
+
+def test_c5_leg_of_the_bench_on_one_rank_over_rccl():
+    """BASELINE config 5 (8192 pairs over 8 GPUs + RCCL gather) cannot run on a one-GPU box; its per-rank code can: with
+    KSS_BENCH_FORCE_DIST=1 bench.py creates a real RCCL process group of one rank and runs the C5 leg -- this rank's shard in one
+    kss_icp_batch_dev call, ONE all-gather of the 96-byte records -- exactly as every rank of an 8-GPU job would."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update({"KSS_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--brute-steps", "0", "--no-cpu-baseline",
+                        "--legs", "c5", "--c5-pairs", "96"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    c5 = d["secondary"]["c5"]
+    assert c5["n_gpus"] == 1 and c5["pairs_total"] == 96 and c5["result_iterations"] == 20
+    assert c5["gathered_records_equal_local"] is True and c5["gathered_pair_ids_in_order"] is True
+    assert c5["registrations_per_sec"] > 0 and c5["gather_us_max_over_ranks"] > 0

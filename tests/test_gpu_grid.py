@@ -220,3 +220,15 @@ def test_soak_tools_short_run():
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)] + args, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, tool + "\n" + r.stdout[-2000:] + r.stderr[-2000:]
         assert "Memory access fault" not in r.stdout + r.stderr
+
+
+def test_canonical_wave_trees_on_the_device():
+    """kss_device.hpp: wave_tree16 / wave_tree2 (permlane swaps + DPP) against a plain __shfl_xor restatement of the same
+    binary tree, bit for bit (tools/tree_check.hip, built by __graft_entry__.build()).  Every engine sums through these trees,
+    so a wrong tree makes all engines wrong ALIKE and no engine-against-engine test sees it -- an inline-asm form of the swaps
+    once lost gfx950's wait state after a permlane swap and put every sum off by ~1e-8 relative."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "tree_check")
+    assert os.path.exists(exe), "tools/tree_check not built: run __graft_entry__.build()"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout + r.stderr

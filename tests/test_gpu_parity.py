@@ -159,6 +159,36 @@ def test_rotation_search_matches_oracle(ctx, pkg, step):
     assert np.array_equal(alist, g["g2_list_%d" % step])
 
 
+@pytest.mark.parametrize("step", [12, 16])
+def test_rotation_search_steps_12_and_16_on_the_device(ctx, O, pkg, step):
+    """initRegistrationKSS.hpp:245-296 at the other step counts the reference uses: 12 (KSSICP_Registration_Additional,
+    KSS_ICP.hpp:371-379: g = 12) and 16 (g = 17, from the double accumulation of 6.3 / 16).  Error volume to 1e-12, identical
+    arg-min and angleList, with every candidates-per-lane width of rot_search_kernel (KSS_ROT_S: read at each launch)."""
+    g = np.load(os.path.join(GOLDEN, "oracle_vectors.npz"))
+    Sp, T = g["g1_preshaped"], g["g1_tgt"].astype(np.float64)
+    ref = O.rotation_search(Sp, T, step)
+    assert ref["g"] == {12: 12, 16: 17}[step]
+    old = os.environ.get("KSS_ROT_S")
+    try:
+        for width in (None, "1", "2", "4"):
+            if width is None:
+                os.environ.pop("KSS_ROT_S", None)
+            else:
+                os.environ["KSS_ROT_S"] = width
+            err = ctx.rotation_search(Sp, T, step)
+            assert err.shape == ref["value"].shape, width
+            assert _close(err, ref["value"], 1e-12), width
+            assert np.unravel_index(np.argmin(err), err.shape) == np.unravel_index(np.argmin(ref["value"]), err.shape), width
+            best, alist = pkg.rotation_candidates(err, step)
+            assert np.array_equal(best, ref["angle"]), width
+            assert np.array_equal(alist, ref["angle_list"]), width
+    finally:
+        if old is None:
+            os.environ.pop("KSS_ROT_S", None)
+        else:
+            os.environ["KSS_ROT_S"] = old
+
+
 # ---- (a9) ICP ---------------------------------------------------------------------------------------------------------
 def test_icp_trace_matches_oracle(ctx, O):
     g = np.load(os.path.join(GOLDEN, "oracle_vectors.npz"))
@@ -472,7 +502,12 @@ print("RESULT" + json.dumps(out))
                 # an answer that never arrives (a stalled host thread): the waiting kernel's bounded poll runs out, it leaves
                 # without having touched anything, and the pass is launched again as a plain one
                 "lost_answer": {"KSS_TEST_DROP_GATE": "7", "KSS_GATE_POLLS": "20000"},
-                "lost_answer_unchained": {"KSS_TEST_DROP_GATE": "5", "KSS_GATE_POLLS": "20000", "KSS_CHAIN": "0"}}
+                "lost_answer_unchained": {"KSS_TEST_DROP_GATE": "5", "KSS_GATE_POLLS": "20000", "KSS_CHAIN": "0"},
+                # a 16-byte granule seen TORN: the host's gate record first arrives with a granule whose words
+                # do not fit its check word; a result slot is first stored with bits that do not fit its check word.  The
+                # receiver polls again instead of taking it for data
+                "torn_gate": {"KSS_TEST_TORN_GATE": "6"}, "torn_gate_unchained": {"KSS_TEST_TORN_GATE": "4", "KSS_CHAIN": "0"},
+                "torn_slot": {"KSS_TEST_TORN_SLOT": "4"}, "torn_slot_late": {"KSS_TEST_TORN_SLOT": "23"}}
     for name, extra in variants.items():
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
@@ -481,6 +516,55 @@ print("RESULT" + json.dumps(out))
         assert ("launched again" in r.stderr) == name.startswith("lost_answer"), name   # (the hook did fire, and only there)
     for name in variants:
         assert res[name] == res["default"], name
+
+
+def test_lost_answer_with_more_rows_than_compute_units(pkg):
+    """A 150k-point pair has 293 rows for 256 compute units: when the host's answer to a gated launch is lost, the first
+    workgroups leave at the gate but later ones may still run.  The recovery re-arms every zero-at-rest counter
+    before the plain relaunch; the registration must come out as without the loss, bit for bit."""
+    import subprocess, sys, json
+    code = r"""
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as g
+pkg = g.load_package(); S = pkg.synth; ctx = pkg.Context(0)
+src, tgt = S.make_pair(91, 150000, R=S.rot_axis_angle([0.2, 0.1, 1.0], np.deg2rad(7.0)), t=(0.01, 0.0, -0.01), shape="bumpy")
+out = []
+for kw in (dict(max_iterations=8, fixed_iterations=1), dict()):
+    r = ctx.icp(src, tgt, ctx.icp_params(nn_mode=pkg.NN_GRID, **kw))
+    out.append([r["T"].tolist(), r["iterations"], r["fitness"], r["last_mse"]])
+print("RESULT" + json.dumps(out))
+""" % ROOT
+    res = {}
+    for name, extra in {"default": {}, "lost": {"KSS_TEST_DROP_GATE": "3", "KSS_GATE_POLLS": "20000"},
+                        "lost_late": {"KSS_TEST_DROP_GATE": "9", "KSS_GATE_POLLS": "20000"}}.items():
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, **extra))
+        assert r.returncode == 0, name + r.stdout + r.stderr
+        res[name] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT")][0][6:])
+        assert ("launched again" in r.stderr) == (name != "default"), name
+    assert res["lost"] == res["default"] and res["lost_late"] == res["default"]
+
+
+def test_a_new_context_never_takes_an_old_contexts_rows(pkg):
+    """Rows handed over as {bits, launch number} granules are accepted on the number alone: a context that gets
+    a destroyed context's workspace block back must not take its rows for its own.  Launch numbers are unique per process
+    and the row buffer is zeroed when (re)allocated: same-shaped registrations on successive contexts equal the same
+    registration on a context of their own."""
+    S = pkg.synth
+    pairs = [S.make_pair(600 + k, 60000, R=S.rot_axis_angle([0.3, 1.0, 0.2], np.deg2rad(5.0 + k)), t=(0.01 * k, 0.0, 0.0), shape="bumpy") for k in range(3)]
+    p_kw = dict(nn_mode=pkg.NN_GRID, max_iterations=12, fixed_iterations=1)
+    chained = []
+    for src, tgt in pairs:                   # A registers and dies, B gets its blocks back, ...
+        c = pkg.Context(0)
+        chained.append(c.icp(src, tgt, c.icp_params(**p_kw)))
+        c.close()
+    keep = pkg.Context(0)                    # (a live context in between changes what the allocator hands out)
+    for (src, tgt), r in zip(pairs, chained):
+        c = pkg.Context(0)
+        one = c.icp(src, tgt, c.icp_params(**p_kw))
+        c.close()
+        assert np.array_equal(r["T"], one["T"]) and r["fitness"] == one["fitness"] and r["last_mse"] == one["last_mse"]
+    keep.close()
 
 
 def test_growing_registrations_on_one_context(pkg):
