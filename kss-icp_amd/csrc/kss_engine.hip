@@ -12,6 +12,7 @@
 namespace kss {
 
 static int restore_zero_at_rest(kss_ctx* c);
+static bool resident_gate_available(kss_ctx* c, int npairs);
 
 // Workgroups of ONE launch that are certainly on the chip at the same time: one per compute unit of THIS device (the fused
 // single-pair kernels need at most one CU's registers and LDS each).  Tagged rows and chained launches rely on it; on a
@@ -107,6 +108,18 @@ static int build_plan(kss_ctx* c, const int64_t* ns, const int64_t* nt, int npai
         int64_t least_nt = nt[0], tot_ns = 0;
         for (int p = 0; p < npairs; ++p) { least_nt = std::min(least_nt, nt[p]); tot_ns += ns[p]; }
         pl.gridb = nn_mode == KSS_NN_GRID || (nn_mode == KSS_NN_AUTO && least_nt >= 2 * min_nt && tot_ns >= 32 * min_ns);
+    }
+    if (npairs > 1 && shared_target && nn_mode != KSS_NN_BRUTE) {
+        // Pairs sharing ONE target (the candidate batch of kss_register) on the pair-resident engine -- every candidate a workgroup
+        // of its own with the (small) target in LDS, no lockstep between candidates -- was built and measured in round 3: Bunny,
+        // 14 candidates x 1406 points: kss_register 24.3 ms against 4.5 ms on the brute-force engine.  The candidates start from
+        // local minima of the rotation search and move far in every pass: nearly every source searches in every pass, and 1406
+        // cell-list searches on ONE compute unit (50-100 us) lose to the tiled sweep of the same candidate spread over the chip
+        // (25 us).  KSS_RESIDENT_SHARED=1 runs it anyway (A/B; same results).
+        static const bool want_res = getenv("KSS_RESIDENT_SHARED") != nullptr && atoi(getenv("KSS_RESIDENT_SHARED")) != 0;
+        bool fits = want_res && nt[0] >= 64 && nt[0] <= 12000;
+        for (int p = 0; p < npairs; ++p) fits = fits && ns[p] <= (int64_t)RES_SMAX * RES_THREADS;
+        pl.gridb = fits && resident_gate_available(c, npairs);
     }
     const bool any_grid = pl.grid || pl.gridb;
     pl.src_in_cell_order = any_grid;
@@ -1040,6 +1053,8 @@ static unsigned int* resident_gate(kss_ctx* c, int npairs) {
     return c->res_gate;
 }
 
+static bool resident_gate_available(kss_ctx* c, int npairs) { return resident_gate(c, npairs) != nullptr; }
+
 // the 20 sums of pair p under sequence number `want`, if they have all landed
 static inline bool resident_collect(const unsigned long long* h_seq, int p, unsigned long long want, double* out) {
     const unsigned long long* sl = h_seq + (size_t)2 * NSUMS * p;
@@ -1250,6 +1265,19 @@ static int icp_loop(kss_ctx* c, const IcpPlan& pl_in, const kss_icp_params& P, k
         bool handled = false;
         KCHK(resident_loop(c, pl_in, P, results, &handled));
         if (handled) return KSS_OK;
+        if (pl_in.shared_target) {
+            // candidates of one target that the resident engine declined: the brute-force engine (the packed clouds stay where
+            // they are, in cell order; the engines agree on every correspondence)
+            std::vector<int64_t> ns(pl_in.npairs), nt(pl_in.npairs);
+            for (int p = 0; p < pl_in.npairs; ++p) { ns[p] = pl_in.g[p].ns; nt[p] = pl_in.g[p].nt; }
+            IcpPlan bp;
+            KCHK(build_plan(c, ns.data(), nt.data(), pl_in.npairs, true, P.nn_sources_per_thread, P.nn_target_splits, KSS_NN_BRUTE, bp));
+            bp.src_in_cell_order = true;
+            KCHK(stage_plan(c, bp));
+            kss_icp_params Pb = P;
+            Pb.nn_mode = KSS_NN_BRUTE;
+            return icp_loop(c, bp, Pb, results);
+        }
     }
     const IcpPlan* plan = &pl_in;   // may change to the brute-force plan below
     IcpPlan brute_plan;

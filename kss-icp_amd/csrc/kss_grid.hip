@@ -412,6 +412,86 @@ void launch_grid_build_pair(hipStream_t st, const float4* d_tgt, int nt, float4*
                        d_src);
 }
 
+// ---- phase A of the fused pass, per source (shared by grid_pass_kernel and gridb_pass_kernel) -------------------------
+// KEEP last pass's winner w without searching, or ask for a search.  Per source the kernels carry {B, acc}: at the position
+// where the source was last searched every target other than w was at true distance >= B; acc bounds how far the source has
+// moved since (sum of the per-pass displacements, rounded up).  By the triangle inequality every other target is now at true
+// distance >= B - acc, so its COMPUTED squared distance (5 roundings: relative error < 6 * 2^-24) exceeds (B - acc)^2 * 0.99999.
+// If the winner's computed distance is below that, w wins again, strictly -- no tie to break -- exactly the key a search would
+// return.  (1e-7: a displacement component below 1.1e-19 squares to zero; over a million passes that is 2e-13 unaccounted
+// for, 2e-6 of the smallest room accepted -- inside the 1e-5 margin.  A lane with less room searches.)
+// (A second candidate per source -- winner and runner-up, B bounding all the others -- was built and measured in round 3: 8x
+// fewer searches, and no faster: a workgroup with ANY walker pays the same chain of dependent round trips, and at two or
+// three walkers per row almost every workgroup still has one; the heavier bookkeeping cost C2 20 %.  The pair-resident
+// engine, whose searches cost LDS reads instead of round trips, keeps two: kss_resident.hip.)
+struct SkipOut {
+    unsigned long long key;     // the previous winner's key at the new position (~0: none)
+    int kpos;                   // -2: "the last winner, whose coordinates are in nn_win" (-1: none)
+    float rho;                  // a walker's pruning radius
+    float acc;                  // a kept winner: the distance covered since the search, this pass included
+    bool walker;
+};
+template <bool FMA>
+__device__ __forceinline__ SkipOut skip_test(bool qok, float qx, float qy, float qz, float pold_x, float pold_y, float pold_z, const float4& prevp,
+                                             const float2& st, bool chained_k, float skin_frac, float h) {
+    SkipOut o;
+    o.key = ~0ull; o.kpos = -1; o.rho = __builtin_inff(); o.acc = 0.f; o.walker = false;
+    if (!qok) return o;
+    o.walker = true;
+    if (__float_as_uint(prevp.w) != ~0u) {   // prevp = the last winner's coordinates, .w = its index in the pair's target
+        o.key = point_key<FMA>(prevp, qx, qy, qz);
+        o.kpos = -2;
+        const float d0 = __uint_as_float((unsigned)(o.key >> 32));
+        const float mx = qx - pold_x, my = qy - pold_y, mz = qz - pold_z;
+        const float moved = __builtin_amdgcn_sqrtf((mx * mx + my * my) + mz * mz);
+        const float acc = (st.y + moved) * 1.00001f;
+        const float room = st.x - acc;
+        if (chained_k && skin_frac >= 0.f && room > 1e-7f && (room * room) * 0.99999f > d0) {
+            o.walker = false;              // w again
+            o.acc = acc;
+        } else {
+            // the walk prunes with the winner's distance grown by a skin (a fraction of the cell edge): what it then proves
+            // about the other targets leaves room for the next passes.  A source that is still moving by more than a quarter
+            // of the skin per pass would not profit: plain radius.
+            const float skin = fmaxf(skin_frac, 0.f) * h, grown = __builtin_amdgcn_sqrtf(d0) + skin;
+            o.rho = !chained_k || moved * 4.f <= skin ? fmaxf(d0, grown * grown) : d0;
+        }
+    }
+    return o;
+}
+
+// ---- phase C of the fused pass, per source: its correspondence as 16 f64 columns (KSS_NSUMS layout), the wave's totals of
+// those columns in the canonical order of kss_device.hpp (+ counts by ballot, + the two FULL columns) into its row of shw ----
+template <bool FULL>
+__device__ __forceinline__ void wave_row(bool have, bool kept, bool fell_back, float qx, float qy, float qz, const float4& win, double d2d, double* shw_row) {
+    const int lane = threadIdx.x & 63;
+    double col[16];
+    {
+        const double px = kept ? (double)qx : 0.0, py = kept ? (double)qy : 0.0, pz = kept ? (double)qz : 0.0;
+        const double tx = kept ? (double)win.x : 0.0, ty = kept ? (double)win.y : 0.0, tz = kept ? (double)win.z : 0.0;
+        col[0] = px; col[1] = py; col[2] = pz; col[3] = tx; col[4] = ty; col[5] = tz;
+        col[6] = px * tx; col[7] = px * ty; col[8] = px * tz;
+        col[9] = py * tx; col[10] = py * ty; col[11] = py * tz;
+        col[12] = pz * tx; col[13] = pz * ty; col[14] = pz * tz;
+        col[15] = kept ? d2d : 0.0;
+    }
+    wave_tree16(col);
+    const unsigned long long mk = __builtin_amdgcn_ballot_w64(kept), mf = __builtin_amdgcn_ballot_w64(fell_back);
+    double extra = 0.0;
+    if constexpr (FULL) extra = wave_tree2(d2d, have ? sqrt(d2d) : 0.0);   // lane 0: sum of all d2, lane 32: sum of sqrt(d2)
+    if ((lane & 15) == 0) {
+        const int q = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) shw_row[1 + 4 * q + j] = col[j];
+        if (lane == 0) {
+            shw_row[0] = (double)__builtin_popcountll(mk);
+            shw_row[NSUMS - 1] = (double)__builtin_popcountll(mf);
+            shw_row[17] = extra;
+        }
+        if (lane == 32) shw_row[18] = extra;
+    }
+}
+
 // Phase B of the fused pass (grid_pass_kernel, gridb_pass_kernel): the first lanes of the workgroup serve the `nwalk`
 // walkers whose lane numbers are in s_wl and whose requests are in their hand-over columns (s_ent), and overwrite every
 // column with the answer.  NT = threads of the workgroup, WQ = columns of the range queue.
@@ -746,16 +826,9 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
         }
     }
     // ---- the search ------------------------------------------------------------------------------------------
-    // Phase A, every lane: move the source, then try to KEEP last pass's winner w without searching.  Per source the
-    // kernel carries {B, acc}: at the position q_ref where the source was last searched, every target other than w was at
-    // true distance >= B; acc bounds how far the source has moved since (sum of the per-pass displacements, rounded up).
-    // By the triangle inequality every other target is now at true distance >= B - acc, so its COMPUTED squared distance
-    // (5 roundings: relative error < 6 * 2^-24) exceeds (B - acc)^2 * 0.99999.  If the winner's computed distance is
-    // below that, w wins again, strictly -- no tie to break -- and the lane is done: exactly the key a search would
-    // return.  (1e-7: a displacement component below 1.1e-19 squares to zero; over a million passes that is 2e-13 unaccounted for,
-    // 2e-6 of the smallest room accepted -- inside the 1e-5 margin.  A lane with less room searches.)
-    // Lanes that cannot skip ("walkers") are compacted into the first waves of the workgroup (phase B): near convergence
-    // ~8 % of the sources walk, so ONE wave per workgroup pays for the walk instead of eight (the pass is VALU-bound).
+    // Phase A, every lane: move the source, then try to KEEP last pass's winner without searching (skip_test).  Lanes that
+    // cannot ("walkers") are compacted into the first waves of the workgroup (phase B): near convergence a few per cent of
+    // the sources walk, so ONE wave per workgroup pays for the walk instead of eight.
     unsigned long long key = ~0ull;
     float pold_x = p.x, pold_y = p.y, pold_z = p.z;   // where the source was in the last pass
     if (SEARCH && last_known && valid) {
@@ -792,33 +865,15 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
         float acc_keep = 0.f;
         {
             const bool qok = valid && (qx - qx) == 0.f && (qy - qy) == 0.f && (qz - qz) == 0.f;
-            int kpos = -1;
-            float rho = __builtin_inff();
+            const SkipOut so = skip_test<FMA>(qok, qx, qy, qz, pold_x, pold_y, pold_z, prevp, st, chained_k, a.skin, gp.h);
+            walker = so.walker;
+            key = so.key;
+            acc_keep = so.acc;
             unsigned fl = 0u;
-            if (qok) {
-                walker = true;
-                if (has_prev) {
-                    key = point_key<FMA>(prevp, qx, qy, qz);
-                    kpos = -2;                     // "the last winner, whose coordinates are in nn_win"
-                    const float d0 = __uint_as_float((unsigned)(key >> 32));
-                    const float mx = qx - pold_x, my = qy - pold_y, mz = qz - pold_z;
-                    const float moved = __builtin_amdgcn_sqrtf((mx * mx + my * my) + mz * mz);
-                    const float acc = (st.y + moved) * 1.00001f;
-                    const float room = st.x - acc;
-                    if (chained_k && a.skin >= 0.f && room > 1e-7f && (room * room) * 0.99999f > d0) {
-                        walker = false;            // w again
-                        fl = 1u;
-                        acc_keep = acc;
-                        a.nn_state[i] = make_float2(st.x, acc);
-                    } else {
-                        // the walk prunes with the winner's distance grown by a skin (a fraction of the cell edge): what it
-                        // then proves about the other targets leaves room for the next passes.  A source that is still
-                        // moving by more than a quarter of the skin per pass would not profit: plain radius.
-                        const float skin = fmaxf(a.skin, 0.f) * gp.h, grown = __builtin_amdgcn_sqrtf(d0) + skin;
-                        rho = !chained_k || moved * 4.f <= skin ? fmaxf(d0, grown * grown) : d0;
-                    }
-                }
-            } else if (valid) {
+            if (qok && !walker) {
+                fl = 1u;
+                a.nn_state[i] = make_float2(st.x, so.acc);
+            } else if (valid && !qok) {
                 a.nn_win[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(~0u));
                 a.nn_state[i] = make_float2(0.f, 0.f);
             }
@@ -826,8 +881,8 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
             const float4 c4 = walker ? make_float4(qx, qy, qz, 0.f) : prevp;
             s_ent[WK_X][threadIdx.x] = __float_as_uint(c4.x); s_ent[WK_Y][threadIdx.x] = __float_as_uint(c4.y); s_ent[WK_Z][threadIdx.x] = __float_as_uint(c4.z);
             s_ent[WK_IDX][threadIdx.x] = (unsigned)key; s_ent[WK_D2][threadIdx.x] = (unsigned)(key >> 32);
-            s_ent[WK_POS][threadIdx.x] = walker ? (unsigned)kpos : fl;   // (a walker: where its last winner is; the others: their flags)
-            s_ent[WK_R][threadIdx.x] = __float_as_uint(rho);
+            s_ent[WK_POS][threadIdx.x] = walker ? (unsigned)so.kpos : fl;   // (a walker: where its last winner is; the others: their flags)
+            s_ent[WK_R][threadIdx.x] = __float_as_uint(so.rho);
         }
         // compaction: walkers take consecutive slots (wave by wave in arrival order, lane order inside a wave)
         const unsigned long long wm = __builtin_amdgcn_ballot_w64(walker);
@@ -879,31 +934,7 @@ __global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pas
     // ---- the row of this chunk, canonical order (kss_device.hpp) ----
     const double d2d = have ? (double)d2 : 0.0;
     const bool kept = have && !(d2d > a.max_d2);   // PCL: `if (distance[0] > max_dist_sqr) continue;`
-    double col[16];
-    {
-        const double px = kept ? (double)qx : 0.0, py = kept ? (double)qy : 0.0, pz = kept ? (double)qz : 0.0;
-        const double tx = kept ? (double)win.x : 0.0, ty = kept ? (double)win.y : 0.0, tz = kept ? (double)win.z : 0.0;
-        col[0] = px; col[1] = py; col[2] = pz; col[3] = tx; col[4] = ty; col[5] = tz;
-        col[6] = px * tx; col[7] = px * ty; col[8] = px * tz;
-        col[9] = py * tx; col[10] = py * ty; col[11] = py * tz;
-        col[12] = pz * tx; col[13] = pz * ty; col[14] = pz * tz;
-        col[15] = kept ? d2d : 0.0;
-    }
-    wave_tree16(col);
-    const unsigned long long mk = __builtin_amdgcn_ballot_w64(kept), mf = __builtin_amdgcn_ballot_w64(fell_back);
-    double extra = 0.0;
-    if constexpr (FULL) extra = wave_tree2(d2d, have ? sqrt(d2d) : 0.0);   // lane 0: sum of all d2, lane 32: sum of sqrt(d2)
-    if ((lane & 15) == 0) {
-        const int q = lane >> 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) shw[wave][1 + 4 * q + j] = col[j];
-        if (lane == 0) {
-            shw[wave][0] = (double)__builtin_popcountll(mk);
-            shw[wave][NSUMS - 1] = (double)__builtin_popcountll(mf);
-            shw[wave][17] = extra;
-        }
-        if (lane == 32) shw[wave][18] = extra;
-    }
+    wave_row<FULL>(have, kept, fell_back, qx, qy, qz, win, d2d, shw[wave]);
     __syncthreads();
     double r = 0.0;
     if (threadIdx.x < NSUMS)
@@ -1121,40 +1152,21 @@ __global__ __launch_bounds__(256, KSS_BATCH2_WAVES) void gridb_pass_kernel(const
         }
         const float qx = p[k].x, qy = p[k].y, qz = p[k].z;
         const bool qok = valid[k] && (qx - qx) == 0.f && (qy - qy) == 0.f && (qz - qz) == 0.f;
-        const bool has_prev = __float_as_uint(prevp[k].w) != ~0u;
-        unsigned long long key = ~0ull;
-        int kpos = -1;
-        float rho = __builtin_inff();
+        const SkipOut so = skip_test<FMA>(qok, qx, qy, qz, pold_x, pold_y, pold_z, prevp[k], st[k], chained_k, a.skin, gp.h);
+        walker[k] = so.walker;
         unsigned fl = 0u;
-        walker[k] = false;
-        if (qok) {
-            walker[k] = true;
-            if (has_prev) {
-                key = point_key<FMA>(prevp[k], qx, qy, qz);
-                kpos = -2;
-                const float d0 = __uint_as_float((unsigned)(key >> 32));
-                const float mx = qx - pold_x, my = qy - pold_y, mz = qz - pold_z;
-                const float moved = __builtin_amdgcn_sqrtf((mx * mx + my * my) + mz * mz);
-                const float acc = (st[k].y + moved) * 1.00001f;
-                const float room = st[k].x - acc;
-                if (chained_k && a.skin >= 0.f && room > 1e-7f && (room * room) * 0.99999f > d0) {
-                    walker[k] = false;
-                    fl = 1u;
-                    a.nn_state[i] = make_float2(st[k].x, acc);
-                } else {
-                    const float skin = fmaxf(a.skin, 0.f) * gp.h, grown = __builtin_amdgcn_sqrtf(d0) + skin;
-                    rho = !chained_k || moved * 4.f <= skin ? fmaxf(d0, grown * grown) : d0;
-                }
-            }
-        } else if (valid[k]) {
+        if (qok && !so.walker) {
+            fl = 1u;
+            a.nn_state[i] = make_float2(st[k].x, so.acc);
+        } else if (valid[k] && !qok) {
             a.nn_win[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(~0u));
             a.nn_state[i] = make_float2(0.f, 0.f);
         }
-        const float4 c4 = walker[k] ? make_float4(qx, qy, qz, 0.f) : prevp[k];
+        const float4 c4 = so.walker ? make_float4(qx, qy, qz, 0.f) : prevp[k];
         s_ent[WK_X][slot] = __float_as_uint(c4.x); s_ent[WK_Y][slot] = __float_as_uint(c4.y); s_ent[WK_Z][slot] = __float_as_uint(c4.z);
-        s_ent[WK_IDX][slot] = (unsigned)key; s_ent[WK_D2][slot] = (unsigned)(key >> 32);
-        s_ent[WK_POS][slot] = walker[k] ? (unsigned)kpos : fl;
-        s_ent[WK_R][slot] = __float_as_uint(rho);
+        s_ent[WK_IDX][slot] = (unsigned)so.key; s_ent[WK_D2][slot] = (unsigned)(so.key >> 32);
+        s_ent[WK_POS][slot] = so.walker ? (unsigned)so.kpos : fl;
+        s_ent[WK_R][slot] = __float_as_uint(so.rho);
         const unsigned long long wm = __builtin_amdgcn_ballot_w64(walker[k]);
         if (wm != 0ull) {
             int base = 0;
@@ -1189,32 +1201,7 @@ __global__ __launch_bounds__(256, KSS_BATCH2_WAVES) void gridb_pass_kernel(const
         }
         const double d2d = have ? (double)d2 : 0.0;
         const bool kept = have && !(d2d > a.max_d2);
-        double col[16];
-        {
-            const double px = kept ? (double)qx : 0.0, py = kept ? (double)qy : 0.0, pz = kept ? (double)qz : 0.0;
-            const double tx = kept ? (double)win.x : 0.0, ty = kept ? (double)win.y : 0.0, tz = kept ? (double)win.z : 0.0;
-            col[0] = px; col[1] = py; col[2] = pz; col[3] = tx; col[4] = ty; col[5] = tz;
-            col[6] = px * tx; col[7] = px * ty; col[8] = px * tz;
-            col[9] = py * tx; col[10] = py * ty; col[11] = py * tz;
-            col[12] = pz * tx; col[13] = pz * ty; col[14] = pz * tz;
-            col[15] = kept ? d2d : 0.0;
-        }
-        wave_tree16(col);
-        const unsigned long long mk = __builtin_amdgcn_ballot_w64(kept), mf = __builtin_amdgcn_ballot_w64(fell_back);
-        double extra = 0.0;
-        if constexpr (FULL) extra = wave_tree2(d2d, have ? sqrt(d2d) : 0.0);
-        const int vw = k * (NT / 64) + wave;   // the wave this half plays
-        if ((lane & 15) == 0) {
-            const int q = lane >> 4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) shw[vw][1 + 4 * q + j] = col[j];
-            if (lane == 0) {
-                shw[vw][0] = (double)__builtin_popcountll(mk);
-                shw[vw][NSUMS - 1] = (double)__builtin_popcountll(mf);
-                shw[vw][17] = extra;
-            }
-            if (lane == 32) shw[vw][18] = extra;
-        }
+        wave_row<FULL>(have, kept, fell_back, qx, qy, qz, win, d2d, shw[k * (NT / 64) + wave]);   // the wave this half plays
     }
     KSS_STAMP(1);
     __syncthreads();

@@ -174,7 +174,11 @@ __device__ __forceinline__ void res_search(bool act, const GridParams& gp, const
     if (act) {
         float face2 = __builtin_inff();
         int rfin = 0;
-        for (int r = 1; r <= gp.rcap; ++r) {
+        // (a small target is swept by the wave in less time than one further shell takes: 64 targets per step.  The candidate
+        // ICPs of a registration start from local minima of the rotation search -- a few per cent of their sources are more
+        // than a cell away from every target in every pass)
+        const int rcap = nt <= 4096 ? 1 : gp.rcap;
+        for (int r = 1; r <= rcap; ++r) {
             if (r > 1) {   // shell r: every row of the (2r+1)^2 window over its whole x extent (points seen before are seen again: a minimum does not mind)
                 const int xh1 = (1 << L.xs) - 1;
                 const int c_lo = max(cx - r, 0), c_hi = min(cx + r + 1, gp.gx);

@@ -1,5 +1,7 @@
 """GPU tests of the exact cell-list NN (KSS_NN_GRID): bit-identical to the brute-force sweep and to the
 oracle on every input class, including the ones that force the brute-force list fallback."""
+import os
+
 import numpy as np
 import pytest
 
