@@ -480,7 +480,9 @@ int preshape_blocks(int64_t n) {
     // >= 8 points per lane before another workgroup is added: every workgroup costs a row hand-over and a ticket on the
     // cloud's counter (one counter takes ~12 ns per ticket: 2048 workgroups on a 1M-point cloud spent 25 us per launch
     // queueing there).  Capped at 256 CUs x 8 workgroups, grid-stride beyond (64M points: 2048 workgroups, as before).
-    int64_t b = (n + 2047) / 2048;
+    // (round 3: 16 points per lane -- 245 workgroups and tickets per 1M-point cloud instead of 489: both launches of C4's two
+    // clouds are held by their tails -- the serial tickets, then the last workgroup's row sum -- not by the 24 MB they stream)
+    int64_t b = (n + 4095) / 4096;
     if (b > 2048) b = 2048;
     if (b < 1) b = 1;
     return (int)b;
@@ -510,10 +512,12 @@ __device__ __forceinline__ void pre_sum_scalar(const T* __restrict__ xyz, int64_
 __device__ __forceinline__ void pre_sum_f32v(const float* __restrict__ xyz, int64_t n, int lb, int nb, double (&acc)[3]) {
     const float4* __restrict__ v = (const float4*)xyz;
     const int64_t nfloats = 3 * n, nf4 = nfloats / 4;
+    const int64_t j0 = (int64_t)lb * 256 + threadIdx.x, stride = (int64_t)nb * 256;
+    int m = (int)(j0 % 3);                         // j mod 3, carried along (a 64-bit modulo per trip cost more than the loads)
+    const int mstep = (int)(stride % 3);
 #pragma unroll 4
-    for (int64_t j = (int64_t)lb * 256 + threadIdx.x; j < nf4; j += (int64_t)nb * 256) {
+    for (int64_t j = j0; j < nf4; j += stride, m = m + mstep >= 3 ? m + mstep - 3 : m + mstep) {
         const float4 q = v[j];
-        const int m = (int)(j % 3);
         const double e0 = (double)q.x, e1 = (double)q.y, e2 = (double)q.z, e3 = (double)q.w;
         if (m == 0) { acc[0] += e0; acc[1] += e1; acc[2] += e2; acc[0] += e3; }
         else if (m == 1) { acc[1] += e0; acc[2] += e1; acc[0] += e2; acc[1] += e3; }
