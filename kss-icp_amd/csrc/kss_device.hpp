@@ -113,21 +113,24 @@ __device__ __forceinline__ double xor1(double x) { return dpp_f64(x, [](int v) {
 // a: lanes with the distance bit clear keep a (and receive the partner's a); b: lanes with the bit set keep b.
 // Returns a_own + a_partner in the "clear" lanes and b_partner + b_own in the "set" lanes: one tree level of TWO
 // columns for the price of one (v_permlane32_swap / v_permlane16_swap exchange half-waves / odd-even rows in place).
-// (the swaps stay compiler builtins: written as inline asm -- which saves the two register copies per swap the builtin's
-// pair-returning form costs -- the compiler no longer knows a permlane swap is there and leaves out the wait state gfx950 needs
-// between the swap and the next VALU read of its registers: low words came back stale, every sum was off by ~1e-8 relative,
-// and only tools/tree_check.hip noticed, because every engine was off alike)
+// The swaps work IN PLACE on their two registers: as inline asm with read-write operands they need no copies (the builtin
+// returns a pair and the compiler copies both inputs first: two moves per swap, fifty-six per tree).  gfx950 wants two wait
+// states between a VALU write of either operand and the swap that reads it; the compiler inserts them for the builtin but
+// cannot see inside an asm string, so `s_nop 1` stands on both sides of the swap INSIDE the string (cdna_hip_programming.md T21: the
+// documented hazard is the one before the swap; the one behind it is what the compiler's own code shows).  Without it the low
+// words came back stale, every sum of every engine was off by ~1e-8 relative, and only tools/tree_check.hip (now a test)
+// noticed -- because every engine was off alike.
 __device__ __forceinline__ double level32(double a, double b) {
     unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a), blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
-    const auto r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
-    const auto r1 = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
-    return __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(alo), "+v"(blo));
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(ahi), "+v"(bhi));
+    return __hiloint2double((int)ahi, (int)alo) + __hiloint2double((int)bhi, (int)blo);
 }
 __device__ __forceinline__ double level16(double a, double b) {
     unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a), blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
-    const auto r0 = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
-    const auto r1 = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
-    return __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(alo), "+v"(blo));
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(ahi), "+v"(bhi));
+    return __hiloint2double((int)ahi, (int)alo) + __hiloint2double((int)bhi, (int)blo);
 }
 __device__ __forceinline__ double tree_low4(double x) {   // levels 8, 4, 2, 1: every lane of a 16-lane row ends with the row total
     x += xor8(x); x += xor4(x); x += xor2(x); x += xor1(x);

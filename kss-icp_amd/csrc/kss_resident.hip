@@ -465,7 +465,7 @@ __global__ __launch_bounds__(RES_THREADS, 1) void resident_icp_kernel(const ResA
             __syncthreads();               // the requests are in
             const int total = s_ctl[0], nq = min(total, RES_NQ);
             if (a.stamps && tid == 0) a.stamps[(size_t)pi * 16 + 14] += (unsigned long long)nq;
-            // lanes per search by how many there are: few -> sixteen lanes each (shortest chain), more -> four, many -> one
+            // lanes per search by how many there are: few -> sixteen lanes each (shortest chain), more -> four
             auto serve = [&](auto lgc) {
                 constexpr int LGC = decltype(lgc)::value;
                 for (int e0 = 0; e0 < nq; e0 += RES_THREADS / LGC) {
@@ -488,9 +488,10 @@ __global__ __launch_bounds__(RES_THREADS, 1) void resident_icp_kernel(const ResA
                     }
                 }
             };
+            // (measured at C3, searches per microsecond of a round: 16 lanes 13, 4 lanes 32, one lane 25 -- one lane per search only
+            // pays when EVERY lane has one, which is the own-slot loop below)
             if (nq <= RES_THREADS / 16) serve(std::integral_constant<int, 16>());
-            else if (nq <= RES_THREADS / 4) serve(std::integral_constant<int, 4>());
-            else serve(std::integral_constant<int, 1>());
+            else serve(std::integral_constant<int, 4>());
             __syncthreads();
             // the owners pick their answers up
             if (queued != 0u) {
