@@ -463,7 +463,12 @@ __global__ __launch_bounds__(RES_THREADS, 1) void resident_icp_kernel(const ResA
         // searches), searched by its own lane, ten searches per lane with every lane busy ----
         for (;;) {
             __syncthreads();               // the requests are in
-            const int total = s_ctl[0], nq = min(total, RES_NQ);
+            const int total = s_ctl[0];
+            // most of the cloud searches (the first pass): nobody serves the queue -- the lanes whose requests went there take
+            // them back (the query, the radius are still in their registers) and every lane searches its own slots
+            const bool dense = total > 5 * RES_NQ;
+            if (dense) { pend |= queued; queued = 0u; }
+            const int nq = dense ? 0 : min(total, RES_NQ);
             if (a.stamps && tid == 0) a.stamps[(size_t)pi * 16 + 14] += (unsigned long long)nq;
             // lanes per search by how many there are: few -> sixteen lanes each (shortest chain), more -> four
             auto serve = [&](auto lgc) {
@@ -508,7 +513,7 @@ __global__ __launch_bounds__(RES_THREADS, 1) void resident_icp_kernel(const ResA
             }
             const int rem = total - nq;    // uniform
             if (rem <= 0) break;
-            if (rem > 4 * RES_NQ) {
+            if (dense || rem > 4 * RES_NQ) {
                 // most of the cloud searches: every lane takes its own pending slots, one per trip (no queue, no barrier: the
                 // targets and the table are read-only)
                 while (__builtin_amdgcn_ballot_w64(pend != 0u) != 0ull) {
