@@ -682,7 +682,9 @@ int kss_rotation_search_dev(kss_ctx* c, const double* d_src, int64_t ns, const d
     std::vector<double> cs(2 * g);
     for (int a = 0; a < g; ++a) { cs[2 * a] = std::cos(ang[a]); cs[2 * a + 1] = std::sin(ang[a]); }
     const int64_t nt_pad = (nt + NN_TILE - 1) / NN_TILE * NN_TILE;
-    const int nsb = (int)((ns + 255) / 256);
+    const int nth = rot_search_grain(ns, nt, g);
+    const int nsb = (int)((ns + nth - 1) / nth);
+    const int64_t nt_sweep = (nt + nth - 1) / nth * nth;   // what the search sweeps (<= nt_pad: the rest of the padding is never read)
     KCHK(ensure(c, c->tgt4, (size_t)nt_pad * sizeof(float4)));
     KCHK(ensure(c, c->cs, cs.size() * sizeof(double)));
     KCHK(ensure(c, c->partials, (size_t)ncand * nsb * sizeof(double)));
@@ -691,8 +693,8 @@ int kss_rotation_search_dev(kss_ctx* c, const double* d_src, int64_t ns, const d
     launch_pack_f64_to_f4(c->stream, d_tgt, nt, (float4*)c->tgt4.p, nt_pad, true);   // :232-234 narrowing to PointXYZ
     {
         ProfScope ps(c, KSS_K_ROT_SEARCH);
-        launch_rot_search(c->stream, d_src, ns, (const float4*)c->tgt4.p, nt_pad, (const double*)c->cs.p, g,
-                          (double*)c->partials.p, nsb);
+        launch_rot_search(c->stream, d_src, ns, (const float4*)c->tgt4.p, nt_sweep, (const double*)c->cs.p, g,
+                          (double*)c->partials.p, nsb, nth);
         launch_row_sums(c->stream, (const double*)c->partials.p, (int)ncand, nsb, 1.0, (double*)c->scratch_c.p);
     }
     HIPCHK(c, hipGetLastError());

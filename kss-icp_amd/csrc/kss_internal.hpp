@@ -262,8 +262,9 @@ int octree_voxels_device(hipStream_t st, const float* d_pts, int n, const OctBox
                          const std::function<void*(int, size_t)>& scratch);
 void launch_fps(hipStream_t st, const double* d_xyz, int n, int m, double* d_mind, int32_t* d_idx, double* d_out);
 
-void launch_rot_search(hipStream_t st, const double* d_src, int64_t ns, const float4* d_tgt4, int64_t nt_pad,
-                       const double* d_cs /* g*2: cos,sin */, int g, double* d_partials, int n_src_blocks);
+int rot_search_grain(int64_t ns, int64_t nt, int g);   // sources per workgroup = targets per tile: 256 or 128
+void launch_rot_search(hipStream_t st, const double* d_src, int64_t ns, const float4* d_tgt4, int64_t nt_pad /* multiple of nth */,
+                       const double* d_cs /* g*2: cos,sin */, int g, double* d_partials, int n_src_blocks /* ceil(ns / nth) */, int nth);
 
 int knn_plan_splits(int nq, int nt_pad, int k, size_t* scratch_bytes);
 void launch_knn_sweep(hipStream_t st, const float4* d_qry, int nq, const float4* d_tgt, int nt_pad, int k, int32_t* d_idx, float* d_d2,

@@ -824,18 +824,21 @@ void launch_fps(hipStream_t st, const double* d_xyz, int n, int m, double* d_min
 // source point in f64 by the candidate's Euler angles, narrows to f32 (:440-442), sweeps the
 // whole target through LDS keeping only the minimum d2, and contributes sqrt((double)d2) (:444).
 // ---------------------------------------------------------------------------------------------
-template <int S>
-__global__ __launch_bounds__(256) void rot_search_kernel(const double* __restrict__ src, int ns,
+template <int S, int NTH>
+__global__ __launch_bounds__(NTH) void rot_search_kernel(const double* __restrict__ src, int ns,
                                                          const float4* __restrict__ tgt, int nt_pad,
                                                          const double* __restrict__ cs, int g,
                                                          double* __restrict__ partials) {
     // One lane = one source point under S consecutive candidates: the target tile read from LDS (one broadcast
     // ds_read_b128 per target) is shared by S distance evaluations, as the S sources per lane of nn_sweep_kernel.
-    __shared__ float4 tile[2][NN_TILE];
+    // NTH = lanes of the workgroup = sources per workgroup = targets per tile: 256, or 128 for the <= 2000-point samples of
+    // KSSICP_Registration, whose sizes a 256-grain pads by up to a fifth (1406 sources: 6 x 256 = 1536, 11 x 128 = 1408;
+    // same for the targets) and whose 1098 workgroups of 256 leave a fifth of the last round's CUs idle.
+    __shared__ float4 tile[2][NTH];
     __shared__ double sh[4][S];
     const int g3 = g * g * g;
     const int tid = threadIdx.x;
-    const int i = blockIdx.x * 256 + tid;
+    const int i = blockIdx.x * NTH + tid;
     const bool valid = i < ns;
     double x0 = 0.0, y0 = 0.0, z0 = 0.0;
     if (valid) { x0 = src[3 * (int64_t)i]; y0 = src[3 * (int64_t)i + 1]; z0 = src[3 * (int64_t)i + 2]; }
@@ -849,16 +852,16 @@ __global__ __launch_bounds__(256) void rot_search_kernel(const double* __restric
         sx[j] = (float)x; sy[j] = (float)y; sz[j] = (float)z;   // narrowed to float before the NN query (:440-442)
         best[j] = __builtin_inff();
     }
-    const int ntiles = nt_pad / NN_TILE;
+    const int ntiles = nt_pad / NTH;
     float4 pre = tgt[tid];
     int buf = 0;
     for (int t = 0; t < ntiles; ++t) {
         tile[buf][tid] = pre;
         __syncthreads();
-        if (t + 1 < ntiles) pre = tgt[(t + 1) * NN_TILE + tid];
+        if (t + 1 < ntiles) pre = tgt[(t + 1) * NTH + tid];
         const float4* __restrict__ tl = tile[buf];
 #pragma unroll 8
-        for (int u = 0; u < NN_TILE; ++u) {
+        for (int u = 0; u < NTH; ++u) {
             const float4 q = tl[u];
 #pragma unroll
             for (int j = 0; j < S; ++j) best[j] = fminf(best[j], dist2<false>(sx[j], sy[j], sz[j], q.x, q.y, q.z));
@@ -875,17 +878,36 @@ __global__ __launch_bounds__(256) void rot_search_kernel(const double* __restric
     }
 }
 
+// sources per workgroup (= targets per tile) of the rotation search: the grain that wastes less on padding and on the last
+// round of workgroups.  KSS_ROT_NTH overrides (A/B).
+int rot_search_grain(int64_t ns, int64_t nt, int g) {
+    if (const char* e = getenv("KSS_ROT_NTH")) { const int v = atoi(e); if (v == 128 || v == 256) return v; }
+    const double g3 = (double)g * g * g;
+    double best_cost = 0.0;
+    int best = 256;
+    for (int nth : {256, 128}) {
+        const double nsb = (double)((ns + nth - 1) / nth), ntb = (double)((nt + nth - 1) / nth);
+        const double pad = (nsb * nth / (double)ns) * (ntb * nth / (double)nt);
+        const double wgs = nsb * std::ceil(g3 / 4.0), per_round = 256.0 * (2048.0 / nth);   // (2048 lanes per CU at these register counts)
+        const double rounds = wgs / per_round;
+        const double cost = pad * std::ceil(rounds) / rounds * (nth == 128 ? 1.03 : 1.0);   // (a barrier per 128 targets instead of per 256)
+        if (best_cost == 0.0 || cost < best_cost) { best_cost = cost; best = nth; }
+    }
+    return best;
+}
+
 void launch_rot_search(hipStream_t st, const double* d_src, int64_t ns, const float4* d_tgt4, int64_t nt_pad,
-                       const double* d_cs, int g, double* d_partials, int n_src_blocks) {
+                       const double* d_cs, int g, double* d_partials, int n_src_blocks, int nth) {
     const int g3 = g * g * g;
     // candidates per lane: 4 when that still leaves >= 4 workgroups per CU, else 2 (the loop is VALU bound and wants a
     // few waves per SIMD to cover the LDS latency); KSS_ROT_S overrides for measurements
     int S = (int64_t)n_src_blocks * ((g3 + 3) / 4) >= 1024 ? 4 : 2;
     if (const char* e = getenv("KSS_ROT_S")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) S = v; }
     const dim3 grid(n_src_blocks, (g3 + S - 1) / S);
-    if (S == 4) hipLaunchKernelGGL(rot_search_kernel<4>, grid, dim3(256), 0, st, d_src, (int)ns, d_tgt4, (int)nt_pad, d_cs, g, d_partials);
-    else if (S == 2) hipLaunchKernelGGL(rot_search_kernel<2>, grid, dim3(256), 0, st, d_src, (int)ns, d_tgt4, (int)nt_pad, d_cs, g, d_partials);
-    else hipLaunchKernelGGL(rot_search_kernel<1>, grid, dim3(256), 0, st, d_src, (int)ns, d_tgt4, (int)nt_pad, d_cs, g, d_partials);
+#define KSS_ROT(SS, NN) hipLaunchKernelGGL((rot_search_kernel<SS, NN>), grid, dim3(NN), 0, st, d_src, (int)ns, d_tgt4, (int)nt_pad, d_cs, g, d_partials)
+    if (nth == 128) { if (S == 4) KSS_ROT(4, 128); else if (S == 2) KSS_ROT(2, 128); else KSS_ROT(1, 128); }
+    else            { if (S == 4) KSS_ROT(4, 256); else if (S == 2) KSS_ROT(2, 256); else KSS_ROT(1, 256); }
+#undef KSS_ROT
 }
 
 }  // namespace kss

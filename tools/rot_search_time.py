@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 pkg = g.load_package(); O = g.load_oracle(); S = pkg.synth
 ctx = pkg.Context(0)
-for n, step in ((1000, 8.0), (2000, 8.0), (2000, 12.0), (2000, 16.0)):
+for n, step in ((1000, 8.0), (1406, 8.0), (2000, 8.0), (2000, 12.0), (2000, 16.0)):
     src, tgt = S.make_pair(3, n, R=S.rot_axis_angle([0, 0, 1], np.deg2rad(30.0)), shape="bumpy")
     s64, t64 = src.astype(np.float64), tgt.astype(np.float64)
     ctx.rotation_search(s64, t64, step)
