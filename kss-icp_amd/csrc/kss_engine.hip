@@ -944,6 +944,29 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
     }
     if (d_state == (const PairState*)c->state.p)
         HIPCHK(c, hipMemcpyAsync(c->state.p, hs, (size_t)pl.npairs * sizeof(PairState), hipMemcpyHostToDevice, c->stream));
+    // The candidate batch of a registration (pairs sharing ONE small target, all of one size): sweep + sums + publication in a
+    // single launch per pass (kss_kernels.hip: cand_pass_kernel).  KSS_CAND_FUSED=0: sweep + reduce as before (A/B; the two
+    // forms agree on every correspondence, their sums differ in the order of additions).
+    static const bool cand_fused = getenv("KSS_CAND_FUSED") == nullptr || atoi(getenv("KSS_CAND_FUSED")) != 0;
+    if (cand_fused && pl.shared_target && pl.npairs > 1 && !pl.src_in_cell_order && pl.g[0].tgt_pad <= 8192) {
+        bool same = true;
+        for (int p = 1; p < pl.npairs; ++p) same = same && pl.g[p].ns == pl.g[0].ns && pl.g[p].src_base == (int64_t)p * pl.g[0].ns;
+        const int bpp = cand_pass_blocks_per_pair(pl.g[0].ns);
+        if (same && ensure_zeroed(c, c->partials, (size_t)pl.npairs * bpp * NSUMS * sizeof(double)) == KSS_OK) {
+            bool launched;
+            {
+                ProfScope ps(c, KSS_K_NN_SWEEP);
+                launched = launch_cand_pass(c->stream, fma, pl.npairs, d_state, d_in, d_out, (const float4*)c->tgt4.p + pl.g[0].tgt_base, pl.g[0].tgt_pad,
+                                            (int)pl.g[0].ns, max_d2, (double*)c->partials.p, (int32_t*)c->pair_ticket.p, c->h_seq_dev, c->seq + 1, d_idx_out, d_d2_out);
+            }
+            if (launched) {
+                ++c->seq;
+                HIPCHK(c, hipGetLastError());
+                KCHK(wait_seq(c, pl.npairs, c->seq, active));
+                return KSS_OK;
+            }
+        }
+    }
     {
         ProfScope ps(c, KSS_K_NN_SWEEP);
         launch_nn_sweep(c->stream, pl.S, fma, (const NNWork*)c->nn_work.p, (int)pl.nn.size(), d_state,

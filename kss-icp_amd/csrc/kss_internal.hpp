@@ -241,6 +241,12 @@ void launch_corr_reduce_publish(hipStream_t st, const RedWork* d_work, int n_wor
                                 const float4* d_src, const float4* d_tgt4, const unsigned long long* d_keys,
                                 double max_d2, double* d_partials, int32_t* d_idx_out, float* d_d2_out, int index_in_w,
                                 const PairRed* d_pair_red, int32_t* d_pair_ticket, unsigned long long* d_pub, unsigned long long seq);
+// the candidate batch of a registration (pairs sharing one small target): sweep + sums + publication in ONE launch per pass
+size_t cand_pass_lds_bytes(int nt_pad);
+int cand_pass_blocks_per_pair(int64_t ns);
+bool launch_cand_pass(hipStream_t st, bool fma, int npairs, const PairState* d_state, const float4* d_src_in, float4* d_src_out, const float4* d_tgt,
+                      int nt_pad, int ns, double max_d2, double* d_partials, int32_t* d_pair_ticket, unsigned long long* d_pub, unsigned long long seq,
+                      int32_t* d_idx_out, float* d_d2_out);
 // idx-driven variant for kss_cov: d2 recomputed with the reference arithmetic
 void launch_corr_reduce_idx(hipStream_t st, const float* d_src3, const float* d_tgt3, const int32_t* d_idx,
                             int64_t n, double max_d2, double* d_partials, int n_blocks);

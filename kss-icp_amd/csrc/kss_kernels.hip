@@ -394,6 +394,153 @@ __global__ __launch_bounds__(256) void corr_reduce_kernel(const RedWork* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The candidate batch of KSSICP_Registration (KSS_ICP.hpp:102-118): up to a few dozen ICPs whose sources are poses of ONE
+// <= 2000-point sample against ONE <= 2000-point target.  ONE launch per pass instead of sweep + reduce: a workgroup =
+// 32 sources of one candidate x ALL targets, the (padded) target staged in LDS once, EIGHT lanes per source each sweeping an
+// eighth of it (sub-tile minima, then the exact arg-min inside the winning sub-tile: the scheme of nn_sweep_kernel, same
+// arithmetic, ties to the lowest index), merged by DPP; the correspondence sums of the 32 sources -> one row per workgroup;
+// the candidate's last workgroup (ticket) adds its rows in a fixed order and publishes the 20 sums.  Exact brute force:
+// these candidates start from local minima of the rotation search, far from convergence -- no cell list pays here.
+// Eighth e of the target sits in LDS shifted by e float4 (the eighths are a multiple of 128 dwords apart: unshifted, the
+// eight addresses of a wave's read would hit the same banks).
+// ---------------------------------------------------------------------------------------------
+constexpr int CAND_SRC = 32;      // sources per workgroup (x 8 lanes = 256 threads)
+template <bool FMA>
+__global__ __launch_bounds__(256) void cand_pass_kernel(const PairState* __restrict__ state, const float4* __restrict__ src_in, float4* __restrict__ src_out,
+                                                        const float4* __restrict__ tgt, int nt_pad, int ns, int blocks_per_pair, double max_d2,
+                                                        double* __restrict__ partials, int32_t* __restrict__ pair_ticket,
+                                                        unsigned long long* __restrict__ pub, unsigned long long seq,
+                                                        int32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
+    extern __shared__ float4 cand_tile[];
+    __shared__ double sh[4][NSUMS];
+    __shared__ int s_last;
+    const int pair = (int)blockIdx.x / blocks_per_pair, blk = (int)blockIdx.x % blocks_per_pair;
+    const PairState ps = state[pair];
+    if (!ps.active) return;   // uniform: whole workgroup leaves
+    const int tid = threadIdx.x, sub = tid & 7;
+    const int chunk = ((nt_pad + 7) / 8 + NN_SUB - 1) / NN_SUB * NN_SUB;   // targets per lane of a group: whole sub-tiles
+    for (int k = tid; k < nt_pad; k += 256) cand_tile[k + k / chunk] = tgt[k];
+    const int sl = blk * CAND_SRC + (tid >> 3);
+    const bool valid = sl < ns;
+    const int gi = pair * ns + sl;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) p = src_in[gi];
+    if (ps.apply) {   // pcl transformCloud with the previous iteration's Matrix4f, Eigen order, float, no fma
+        const float x = p.x, y = p.y, z = p.z;
+        p.x = ((ps.m[0] * x + ps.m[1] * y) + ps.m[2] * z) + ps.m[3];
+        p.y = ((ps.m[4] * x + ps.m[5] * y) + ps.m[6] * z) + ps.m[7];
+        p.z = ((ps.m[8] * x + ps.m[9] * y) + ps.m[10] * z) + ps.m[11];
+    }
+    if (valid && sub == 0) src_out[gi] = p;
+    __syncthreads();
+    // this lane's eighth: sub-tile minima first
+    const int t_lo = sub * chunk, t_hi = min(t_lo + chunk, nt_pad);
+    const float4* __restrict__ tl = cand_tile + t_lo + sub;
+    float best = __builtin_inff();
+    int bsub = 0;
+    for (int s0 = 0; s0 < t_hi - t_lo; s0 += NN_SUB) {
+        float m = __builtin_inff();
+#pragma unroll
+        for (int u = 0; u < NN_SUB; ++u) {
+            const float4 q = tl[s0 + u];
+            m = fminf(m, dist2<FMA>(p.x, p.y, p.z, q.x, q.y, q.z));
+        }
+        if (m < best) { best = m; bsub = s0; }   // strict: the FIRST sub-tile holding the minimum wins
+    }
+    unsigned long long key = ~0ull;
+    if (t_hi > t_lo) {   // exact arg-min inside the winning sub-tile (same arithmetic => same bits as `best`)
+        float bd = __builtin_inff();
+        int bi = 0;
+#pragma unroll 8
+        for (int u = 0; u < NN_SUB; ++u) {
+            const float4 q = tl[bsub + u];
+            const float d = dist2<FMA>(p.x, p.y, p.z, q.x, q.y, q.z);
+            if (d < bd) { bd = d; bi = u; }
+        }
+        key = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned long long)(unsigned)(t_lo + bsub + bi);
+    }
+    // the group's minimum key (distance, then index): lanes l ^ 1, l ^ 2, l ^ 4 by DPP
+    {
+        auto x1 = [](int v) { return __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, false); };
+        auto x2 = [](int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4e, 0xf, 0xf, false); };
+        auto x4 = [](int v) { const int r = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xf, 0x5, false); return __builtin_amdgcn_update_dpp(r, v, 0x114, 0xf, 0xa, false); };
+#define KSS_CAND_MIN(X) do { const unsigned long long o = ((unsigned long long)(unsigned)X((int)(unsigned)(key >> 32)) << 32) | (unsigned)X((int)(unsigned)key); key = o < key ? o : key; } while (0)
+        KSS_CAND_MIN(x1);
+        KSS_CAND_MIN(x2);
+        KSS_CAND_MIN(x4);
+#undef KSS_CAND_MIN
+    }
+    double acc[NSUMS];
+#pragma unroll
+    for (int c = 0; c < NSUMS; ++c) acc[c] = 0.0;
+    const bool qok = (p.x - p.x) == 0.f && (p.y - p.y) == 0.f && (p.z - p.z) == 0.f;   // a non-finite query matches nothing
+    if (valid && sub == 0 && qok && key != ~0ull) {
+        const float d2 = __uint_as_float((unsigned)(key >> 32));
+        const int idx = (int)(unsigned)(key & 0xffffffffull);
+        const float4 q = cand_tile[idx + idx / chunk];
+        accumulate_corr(acc, p.x, p.y, p.z, q.x, q.y, q.z, d2, max_d2);
+        if (idx_out) idx_out[gi] = idx;
+        if (d2_out) d2_out[gi] = d2;
+    }
+    const double r = block_sum<NSUMS>(acc, sh);
+    const int row0 = pair * blocks_per_pair;
+    if (tid < NSUMS) {
+        __hip_atomic_store(&partials[(int64_t)(row0 + blk) * NSUMS + tid], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&pair_ticket[pair], 1) == blocks_per_pair - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __shared__ double shg[ROWSUM_GROUPS][NSUMS];
+    {
+        const int g = tid / NSUMS, c = tid % NSUMS;
+        if (g < ROWSUM_GROUPS) {
+            double a = 0.0;
+            for (int k = g; k < blocks_per_pair; k += 8 * ROWSUM_GROUPS) {
+                double tt[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    tt[j] = k + j * ROWSUM_GROUPS < blocks_per_pair
+                                ? __hip_atomic_load(&partials[(int64_t)(row0 + k + j * ROWSUM_GROUPS) * NSUMS + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                : 0.0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a += tt[j];
+            }
+            shg[g][c] = a;
+        }
+    }
+    __syncthreads();
+    if (tid < NSUMS) {
+        double v = 0.0;
+        for (int gg = 0; gg < ROWSUM_GROUPS; ++gg) v += shg[gg][tid];
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const unsigned long long vb = (unsigned long long)__double_as_longlong(v);
+        u32x4 o;
+        o.x = (unsigned)vb; o.y = (unsigned)(vb >> 32); o.z = (unsigned)seq; o.w = kss_mix3(o.x, o.y, o.z);
+        unsigned long long* dst = pub + 2 * ((int64_t)pair * NSUMS + tid);
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(o) : "memory");
+    }
+    if (tid == 0) pair_ticket[pair] = 0;   // re-arm for the next pass (stream order makes it visible)
+}
+
+size_t cand_pass_lds_bytes(int nt_pad) { return (size_t)(nt_pad + 8) * sizeof(float4); }
+int cand_pass_blocks_per_pair(int64_t ns) { return (int)((ns + CAND_SRC - 1) / CAND_SRC); }
+// false: the device refused the LDS size (the caller runs sweep + reduce)
+bool launch_cand_pass(hipStream_t st, bool fma, int npairs, const PairState* d_state, const float4* d_src_in, float4* d_src_out, const float4* d_tgt,
+                      int nt_pad, int ns, double max_d2, double* d_partials, int32_t* d_pair_ticket, unsigned long long* d_pub, unsigned long long seq,
+                      int32_t* d_idx_out, float* d_d2_out) {
+    const size_t bytes = cand_pass_lds_bytes(nt_pad);
+    const void* fn = fma ? reinterpret_cast<const void*>(&cand_pass_kernel<true>) : reinterpret_cast<const void*>(&cand_pass_kernel<false>);
+    if (bytes > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const int bpp = cand_pass_blocks_per_pair(ns);
+    const dim3 grid((unsigned)(npairs * bpp)), block(256);
+    if (fma) hipLaunchKernelGGL(cand_pass_kernel<true>, grid, block, bytes, st, d_state, d_src_in, d_src_out, d_tgt, nt_pad, ns, bpp, max_d2, d_partials, d_pair_ticket, d_pub, seq, d_idx_out, d_d2_out);
+    else hipLaunchKernelGGL(cand_pass_kernel<false>, grid, block, bytes, st, d_state, d_src_in, d_src_out, d_tgt, nt_pad, ns, bpp, max_d2, d_partials, d_pair_ticket, d_pub, seq, d_idx_out, d_d2_out);
+    return true;
+}
+
 void launch_corr_reduce(hipStream_t st, const RedWork* d_work, int n_work, const PairState* d_state,
                         const float4* d_src, const float4* d_tgt4, const unsigned long long* d_keys,
                         double max_d2, double* d_partials, int32_t* d_idx_out, float* d_d2_out, int index_in_w) {
