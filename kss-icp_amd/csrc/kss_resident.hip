@@ -463,6 +463,7 @@ __global__ __launch_bounds__(RES_THREADS, 1) void resident_icp_kernel(const ResA
         // searches), searched by its own lane, ten searches per lane with every lane busy ----
         for (;;) {
             __syncthreads();               // the requests are in
+            if (pass > 0) KSS_RLAP(2);
             const int total = s_ctl[0];
             // most of the cloud searches (the first pass): nobody serves the queue -- the lanes whose requests went there take
             // them back (the query, the radius are still in their registers) and every lane searches its own slots
@@ -484,8 +485,7 @@ __global__ __launch_bounds__(RES_THREADS, 1) void resident_icp_kernel(const ResA
                     }
                     unsigned w, fell;
                     float bnew;
-                    res_search<FMA, LGC>(act, gp, L, nt, sg, skin_abs, qx, qy, qz, rho, w, bnew, fell,
-                                         a.stamps && tid == 0 && pass > 0 ? a.stamps + (size_t)pi * 16 : nullptr);
+                    res_search<FMA, LGC>(act, gp, L, nt, sg, skin_abs, qx, qy, qz, rho, w, bnew, fell);
                     // (the lanes of a group have read the request before any of them overwrites it: same wave, program order)
                     if (act && (tid & (LGC - 1)) == 0) {
                         unsigned* q = queue + e * RES_QW;
@@ -497,6 +497,7 @@ __global__ __launch_bounds__(RES_THREADS, 1) void resident_icp_kernel(const ResA
             // pays when EVERY lane has one, which is the own-slot loop below)
             if (nq <= RES_THREADS / 16) serve(std::integral_constant<int, 16>());
             else serve(std::integral_constant<int, 4>());
+            if (pass > 0) KSS_RLAP(3);
             __syncthreads();
             // the owners pick their answers up
             if (queued != 0u) {

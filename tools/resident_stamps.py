@@ -34,11 +34,13 @@ print("passes per pair (median): %d" % np.median(passes))
 print("start (us after first): median %.1f  max %.1f" % (np.median(st[:, 0] - t0) / 100.0, (st[:, 0].max() - t0) / 100.0))
 print("move in: median %.2f us" % (np.median(st[:, 1] - st[:, 0]) / 100.0))
 print("pass 0: phase B (every source searches) median %.2f us; the rest of pass 0 %.2f us" % (np.median(st[:, 13]) / 100.0, np.median(st[:, 6]) / 100.0))
+st[:, 10] = st[:, 10] + st[:, 2] + st[:, 3]          # phase B = wait for the slowest wave + serving the queue + the rest
 for idx, nm in ((8, "gate wait"), (9, "phase A"), (10, "phase B"), (11, "phase C"), (12, "total+publish")):
     per = st[:, idx] / np.maximum(passes - 1, 1) / 100.0
     print("%-14s per pass: median %6.2f us  p90 %6.2f" % (nm, np.median(per), np.percentile(per, 90)))
-print("wave 0 in the quad searches, per pass: rows %.2f us, merge + shells %.2f us, sweep %.2f us; sweeps asked for per pass (its wave) %.2f" % tuple(
-    np.median(st[:, k] / np.maximum(passes - 1, 1)) / (100.0 if k != 5 else 1.0) for k in (2, 3, 4, 5)))
+per = lambda k: np.median(st[:, k] / np.maximum(passes - 1, 1)) / 100.0
+print("inside phase B (wave 0's view), per pass: wait for the slowest wave's phase A %.2f us, serving the queue %.2f us, the rest (barriers, pick-up, further rounds) %.2f us" % (
+    per(2), per(3), per(10) - per(2) - per(3)))
 print("requests queued per pass (median over pairs): %.0f" % np.median(st[:, 14] / passes))
 rq = st[:, 14] / passes
 print("requests queued per pass, over pairs: p10 %.0f median %.0f p90 %.0f max %.0f" % (np.percentile(rq, 10), np.median(rq), np.percentile(rq, 90), rq.max()))
