@@ -770,30 +770,59 @@ int kss_register(kss_ctx* c, const double* src_sub, int64_t nss, const double* t
     kss_icp_default_params(&ip);
     ip.max_iterations = iter;
     const int64_t to[2] = {0, nts};
-    // (a14) judge: ICP from the best grid pose (KSS_ICP.hpp:92-93)
-    for (int k = 0; k < 3; ++k) pose.angle[k] = best[k];
-    RCHK(kss_pose_apply_dev(c, (const double*)dS.p, nss, &pose, (double*)dP.p));
-    kss_icp_result r0;
-    {
+    double chosen[3] = {best[0], best[1], best[2]};
+    kss_icp_result r0, rfinal;
+    std::vector<kss_icp_result> rr;
+    bool have_judge = false, have_cands = false;
+    // The judge ICP (from the best grid pose, KSS_ICP.hpp:92-93) and the candidate ICPs of the angle list (:102-118) do not
+    // depend on each other -- only whether the candidates' results are USED depends on the judge's fitness (:99).  They run as
+    // ONE batch sharing the target, the judge as its last pair; when the judge ends at or below the threshold the candidates
+    // are told to stop where they are (the reference would not have run them; nothing of theirs is used).  Each pair is an
+    // independent registration: the results equal those of the sequential calls.  KSS_REGISTER_SPEC=0, or an engine that
+    // cannot cancel (no large BAR, a batch that does not fit the device at once): the sequential route below.
+    static const bool want_spec = getenv("KSS_REGISTER_SPEC") == nullptr || atoi(getenv("KSS_REGISTER_SPEC")) != 0;
+    auto fill_poses = [&](int n_list, bool with_judge) -> int {
+        RCHK(ensure(c, dAll, (size_t)(n_list + (with_judge ? 1 : 0)) * nss * 3 * sizeof(double)));
+        for (int i = 0; i < n_list + (with_judge ? 1 : 0); ++i) {
+            for (int k = 0; k < 3; ++k) pose.angle[k] = i < n_list ? alist[3 * i + k] : best[k];
+            RCHK(kss_pose_apply_dev(c, (const double*)dS.p, nss, &pose, (double*)dAll.p + (size_t)i * nss * 3));
+        }
+        return KSS_OK;
+    };
+    if (want_spec && nl > 0) {
+        RCHK(fill_poses(nl, true));
+        std::vector<int64_t> so(nl + 2);
+        for (int i = 0; i <= nl + 1; ++i) so[i] = (int64_t)i * nss;
+        rr.resize(nl + 1);
+        c->spec_judge = nl; c->spec_threshold = 0.0005; c->spec_ran = false; c->spec_cancelled = false;
+        const int rc = icp_run_dev(c, dAll.p, so.data(), dT.p, to, nl + 1, true, KSS_F64, &ip, rr.data());
+        c->spec_judge = -1;
+        if (rc != KSS_OK) return rc;
+        if (c->spec_ran) {
+            r0 = rr[nl];
+            have_judge = true;
+            have_cands = !c->spec_cancelled;
+        }
+    }
+    if (!have_judge) {
+        // (a14) judge: ICP from the best grid pose (KSS_ICP.hpp:92-93)
+        for (int k = 0; k < 3; ++k) pose.angle[k] = best[k];
+        RCHK(kss_pose_apply_dev(c, (const double*)dS.p, nss, &pose, (double*)dP.p));
         const int64_t so[2] = {0, nss};
         RCHK(icp_run_dev(c, dP.p, so, dT.p, to, 1, false, KSS_F64, &ip, &r0));
     }
     res->E_d_init = r0.fitness;
-    double chosen[3] = {best[0], best[1], best[2]};
-    kss_icp_result rfinal = r0;
+    rfinal = r0;
     // the judge ICP *is* the final ICP when the threshold branch is not taken (same inputs, :93 vs :130)
     if (res->E_d_init > 0.0005 && nl > 0) {   // :99
         // (a14) all candidate ICPs as ONE batch sharing the target (:102-118)
-        RCHK(ensure(c, dAll, (size_t)nl * nss * 3 * sizeof(double)));
-        std::vector<int64_t> so(nl + 1);
-        for (int i = 0; i < nl; ++i) {
-            so[i] = (int64_t)i * nss;
-            for (int k = 0; k < 3; ++k) pose.angle[k] = alist[3 * i + k];
-            RCHK(kss_pose_apply_dev(c, (const double*)dS.p, nss, &pose, (double*)dAll.p + (size_t)i * nss * 3));
+        if (!have_cands) {
+            RCHK(fill_poses(nl, false));
+            std::vector<int64_t> so(nl + 1);
+            for (int i = 0; i <= nl; ++i) so[i] = (int64_t)i * nss;
+            rr.resize(nl);
+            RCHK(icp_run_dev(c, dAll.p, so.data(), dT.p, to, nl, true, KSS_F64, &ip, rr.data()));
         }
-        so[nl] = (int64_t)nl * nss;
-        std::vector<kss_icp_result> rr(nl);
-        RCHK(icp_run_dev(c, dAll.p, so.data(), dT.p, to, nl, true, KSS_F64, &ip, rr.data()));
         double Q = 9999; int angleIndex = 0;
         for (int i = 0; i < nl; ++i) {
             const double ri = rr[i].fitness;

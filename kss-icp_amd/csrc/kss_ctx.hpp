@@ -89,6 +89,11 @@ struct kss_ctx {
     unsigned int* res_gate = nullptr; int res_gate_cap = 0; bool res_gate_failed = false;   // pair-resident engine: one 128-byte gate record per pair, same kind of memory
     unsigned res_launches = 0;          // ... its launches so far (every launch has its own range of gate stamps)
     double res_passes = 0.0;            // ... (pair, pass) units its profiled launches ran
+    int cand_cap = 0, cand_cap_pad = -1, cand_cap_fma = -1;   // candidate-resident kernel: workgroups resident at once for this target size
+    // kss_register runs the judge ICP and the candidate ICPs as ONE speculative batch: pair spec_judge is the judge; once its
+    // fitness is known and does not exceed spec_threshold the candidates are told to stop (their results are not used).
+    // spec_ran: the batch ran that way (otherwise the caller takes the sequential route); spec_cancelled: candidates were stopped
+    int spec_judge = -1; double spec_threshold = 0.0; bool spec_ran = false, spec_cancelled = false;
     unsigned long long seq = 0;
     void* h_state = nullptr; size_t h_state_cap = 0;
 

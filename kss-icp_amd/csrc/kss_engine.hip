@@ -1089,58 +1089,142 @@ static inline bool resident_collect(const unsigned long long* h_seq, int p, unsi
     return true;
 }
 
+// workgroups of candidate-resident launches in flight, per device, over all contexts of the process
+static std::atomic<int> g_cand_in_flight[64];
+struct CandReservation {
+    int dev = -1, n = 0;
+    bool take(int device, int want, int cap) {
+        if (device < 0 || device >= 64 || n != 0) return false;
+        const int before = g_cand_in_flight[device].fetch_add(want);
+        if (before + want > cap) { g_cand_in_flight[device].fetch_sub(want); return false; }
+        dev = device; n = want;
+        return true;
+    }
+    ~CandReservation() { if (n > 0) g_cand_in_flight[dev].fetch_sub(n); }
+};
+
 // *handled = false with KSS_OK: the plan does not qualify (or the engine gave up before touching any result): the caller
 // runs the launch-per-pass loop
-static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P, kss_icp_result* results, bool* handled) {
+static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P, kss_icp_result* results, bool* handled, bool cand = false) {
     *handled = false;
     static const bool want = getenv("KSS_RESIDENT") == nullptr || atoi(getenv("KSS_RESIDENT")) != 0;
-    if (!want || !pl.gridb || P.allreduce || P.max_iterations < 1 || P.max_iterations > 4000) return KSS_OK;
-    int ntc = 0, tabc = 0;
-    if (!resident_capacities(pl, &ntc, &tabc)) return KSS_OK;
-    unsigned int* gate = resident_gate(c, pl.npairs);
-    if (!gate) return KSS_OK;
+    static const bool want_cand = getenv("KSS_CAND_RESIDENT") == nullptr || atoi(getenv("KSS_CAND_RESIDENT")) != 0;
+    if (!(cand ? want_cand : want) || P.allreduce || P.max_iterations < 1 || P.max_iterations > 4000) return KSS_OK;
+    if (cand ? (pl.grid || pl.gridb || !pl.shared_target || pl.src_in_cell_order || pl.g[0].tgt_pad > 8192) : !pl.gridb) return KSS_OK;
     const int np = pl.npairs;
-    ResArgs a;
-    std::memset(&a, 0, sizeof a);
-    a.pairs = (const GridPairDev*)c->g_pairs.p;
-    a.cell_start = (const int32_t*)c->g_start.p + 1;
-    a.sorted = (const float4*)c->g_sorted.p;
-    a.src0 = (const float4*)c->src0.p;
-    a.gate = gate;
-    a.pub = c->h_seq_dev;
-    a.max_passes = P.max_iterations + 2;
-    a.seq0 = c->seq + 1;
-    c->seq += (unsigned long long)a.max_passes + 1;
-    c->res_launches = c->res_launches % 500000u + 1u;
-    a.stamp0 = c->res_launches * 4096u;          // every launch has its own 4096 stamps: a record of an earlier launch never matches
-    a.max_d2 = P.max_corr_dist * P.max_corr_dist;
-    static const float skin = getenv("KSS_SKIN") ? (float)atof(getenv("KSS_SKIN")) : 0.25f;
-    a.skin = skin;
+    // what the serving loop needs to know about the launch, whichever kernel it is
+    struct { unsigned long long seq0 = 0; unsigned stamp0 = 0; int32_t* idx_out = nullptr; float* d2_out = nullptr; unsigned long long* stamps = nullptr; } a;
     static const int gate_polls = getenv("KSS_GATE_POLLS") ? atoi(getenv("KSS_GATE_POLLS")) : (1 << 22);
-    a.gate_polls = gate_polls;
-    a.full_always = P.trace_sums != nullptr ? 1 : 0;
-    a.ntc = ntc; a.tabc = tabc;
-    if (P.compute_fitness && (P.fitness_idx || P.fitness_d2)) {
-        KCHK(ensure(c, c->stage_idx, (size_t)pl.total_src * sizeof(int32_t)));
-        KCHK(ensure(c, c->stage_d2, (size_t)pl.total_src * sizeof(float)));
-        a.idx_out = (int32_t*)c->stage_idx.p; a.d2_out = (float*)c->stage_d2.p;
-    }
     static const bool stamps_on = getenv("KSS_GRID_STAMPS") != nullptr;   // diagnostic timeline (tools/resident_stamps.py)
-    if (stamps_on) {
-        KCHK(ensure(c, c->g_stamps, (size_t)np * 16 * sizeof(unsigned long long)));
-        HIPCHK(c, hipMemsetAsync(c->g_stamps.p, 0, (size_t)np * 16 * sizeof(unsigned long long), c->stream));
-        a.stamps = (unsigned long long*)c->g_stamps.p;
-    }
-    {
+    unsigned int* gate = nullptr;
+    const int max_passes = P.max_iterations + 2;
+    CandReservation cand_reserve;   // (given back when this function returns: the kernel has drained by then on every path)
+    auto number_launch = [&]() {
+        a.seq0 = c->seq + 1;
+        c->seq += (unsigned long long)max_passes + 1;
+        c->res_launches = c->res_launches % 500000u + 1u;
+        a.stamp0 = c->res_launches * 4096u;          // every launch has its own 4096 stamps: a record of an earlier launch never matches
+    };
+    auto want_correspondences = [&]() -> int {
+        if (P.compute_fitness && (P.fitness_idx || P.fitness_d2)) {
+            KCHK(ensure(c, c->stage_idx, (size_t)pl.total_src * sizeof(int32_t)));
+            KCHK(ensure(c, c->stage_d2, (size_t)pl.total_src * sizeof(float)));
+            a.idx_out = (int32_t*)c->stage_idx.p; a.d2_out = (float*)c->stage_d2.p;
+        }
+        return KSS_OK;
+    };
+    if (!cand) {
+        int ntc = 0, tabc = 0;
+        if (!resident_capacities(pl, &ntc, &tabc)) return KSS_OK;
+        gate = resident_gate(c, np);
+        if (!gate) return KSS_OK;
+        ResArgs ra;
+        std::memset(&ra, 0, sizeof ra);
+        ra.pairs = (const GridPairDev*)c->g_pairs.p;
+        ra.cell_start = (const int32_t*)c->g_start.p + 1;
+        ra.sorted = (const float4*)c->g_sorted.p;
+        ra.src0 = (const float4*)c->src0.p;
+        ra.gate = gate;
+        ra.pub = c->h_seq_dev;
+        ra.max_passes = max_passes;
+        number_launch();
+        ra.seq0 = a.seq0; ra.stamp0 = a.stamp0;
+        ra.max_d2 = P.max_corr_dist * P.max_corr_dist;
+        static const float skin = getenv("KSS_SKIN") ? (float)atof(getenv("KSS_SKIN")) : 0.25f;
+        ra.skin = skin;
+        ra.gate_polls = gate_polls;
+        ra.full_always = P.trace_sums != nullptr ? 1 : 0;
+        ra.ntc = ntc; ra.tabc = tabc;
+        KCHK(want_correspondences());
+        ra.idx_out = a.idx_out; ra.d2_out = a.d2_out;
+        if (stamps_on) {
+            KCHK(ensure(c, c->g_stamps, (size_t)np * 16 * sizeof(unsigned long long)));
+            HIPCHK(c, hipMemsetAsync(c->g_stamps.p, 0, (size_t)np * 16 * sizeof(unsigned long long), c->stream));
+            ra.stamps = a.stamps = (unsigned long long*)c->g_stamps.p;
+        }
         ProfScope ps(c, KSS_K_RESIDENT, true);
         std::string lerr;
-        const int rc = launch_resident(c->stream, P.nn_fma != 0, np, a, lerr);
+        const int rc = launch_resident(c->stream, P.nn_fma != 0, np, ra, lerr);
         if (rc != KSS_OK) { (void)hipGetLastError(); return KSS_OK; }   // (not launched: nothing touched, the other engine runs)
+    } else {
+        // candidates of one registration: equal sizes, packed one after the other, original order (what cand_pass_kernel asks
+        // for), and the whole launch resident at once -- up to CAND_TPW tiles of 32 sources per workgroup
+        for (int p = 0; p < np; ++p)
+            if (pl.g[p].ns != pl.g[0].ns || pl.g[p].src_base != (int64_t)p * pl.g[0].ns) return KSS_OK;
+        const int nt_pad = (int)pl.g[0].tgt_pad;
+        const bool fma = P.nn_fma != 0;
+        if (c->cand_cap_pad != nt_pad || c->cand_cap_fma != (fma ? 1 : 0)) {
+            c->cand_cap = cand_resident_capacity(fma, nt_pad);
+            c->cand_cap_pad = nt_pad; c->cand_cap_fma = fma ? 1 : 0;
+        }
+        // Every workgroup of the launch has to be on the chip at once, and so do those of the launches other contexts of this
+        // process (the workers of kss_register_batch) have in flight on the same device: each launch RESERVES its workgroups
+        // out of the device's capacity, takes more tiles per workgroup when little is left, and goes to the launch-per-pass
+        // form when that is not enough.  (KSS_CAND_CAP: a smaller capacity, to exercise exactly that.)
+        static const int cap_env = getenv("KSS_CAND_CAP") ? atoi(getenv("KSS_CAND_CAP")) : 0;
+        const int cap = cap_env > 0 ? std::min(c->cand_cap, cap_env) : c->cand_cap;
+        const int bpp = cand_pass_blocks_per_pair(pl.g[0].ns);
+        if (cap <= 0 || bpp <= 0) return KSS_OK;
+        int tpw = 0;
+        for (int t = 1; t <= CAND_TPW && !tpw; ++t) {
+            const int want_wg = np * ((bpp + t - 1) / t);
+            if (want_wg > cap) continue;
+            if (cand_reserve.take(c->device, want_wg, cap)) tpw = t;
+        }
+        if (!tpw) return KSS_OK;
+        gate = resident_gate(c, np);
+        if (!gate) return KSS_OK;
+        if (ensure_zeroed(c, c->partials, (size_t)np * bpp * NSUMS * sizeof(double)) != KSS_OK) return KSS_OK;
+        CandArgs ca;
+        std::memset(&ca, 0, sizeof ca);
+        ca.src0 = (const float4*)c->src0.p;
+        ca.tgt = (const float4*)c->tgt4.p + pl.g[0].tgt_base;
+        ca.nt_pad = nt_pad; ca.ns = (int)pl.g[0].ns;
+        ca.bpp = bpp; ca.tpw = tpw; ca.wpp = (bpp + tpw - 1) / tpw;
+        ca.max_d2 = P.max_corr_dist * P.max_corr_dist;
+        ca.partials = (double*)c->partials.p;
+        ca.pair_ticket = (int32_t*)c->pair_ticket.p;
+        ca.gate = gate;
+        ca.pub = c->h_seq_dev;
+        number_launch();
+        ca.seq0 = a.seq0; ca.stamp0 = a.stamp0;
+        ca.gate_polls = gate_polls; ca.max_passes = max_passes;
+        KCHK(want_correspondences());
+        ca.idx_out = a.idx_out; ca.d2_out = a.d2_out;
+        if (stamps_on) {   // (tools/cand_stamps.py)
+            KCHK(ensure(c, c->g_stamps, (size_t)np * 16 * sizeof(unsigned long long)));
+            HIPCHK(c, hipMemsetAsync(c->g_stamps.p, 0, (size_t)np * 16 * sizeof(unsigned long long), c->stream));
+            ca.stamps = a.stamps = (unsigned long long*)c->g_stamps.p;
+        }
+        ProfScope ps(c, KSS_K_RESIDENT, true);
+        std::string lerr;
+        const int rc = launch_cand_resident(c->stream, fma, np, ca, lerr);
+        if (rc != KSS_OK) { (void)hipGetLastError(); return KSS_OK; }
     }
 
     // ---- per-pair host state (what icp_loop keeps in its vectors) ----
     enum { PH_ITER = 0, PH_FIT = 1, PH_DONE = 2 };
-    struct PairHost { Convergence cv; float fin[16]; int iters = 0, converged = 0, state = 0, k = 0, phase = PH_ITER; double last_mse = 0.0, fitness = 0.0; };
+    struct PairHost { Convergence cv; float fin[16]; int iters = 0, converged = 0, state = 0, k = 0, phase = PH_ITER, cancelled = 0; double last_mse = 0.0, fitness = 0.0; };
     std::vector<PairHost> H((size_t)np);
     for (int p = 0; p < np; ++p) {
         Convergence& cv = H[p].cv;
@@ -1153,7 +1237,9 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
         mat4_identity(H[p].fin);
     }
     if (P.trace_n) *P.trace_n = 0;
-    std::atomic<int> failed{0}, kernel_done{0}, pairs_left{np};
+    std::atomic<int> failed{0}, kernel_done{0}, pairs_left{np}, cancel_all{0};
+    const int judge = cand ? c->spec_judge : -1;
+    const double judge_threshold = c->spec_threshold;
     std::atomic<long long> units{0};
     const unsigned long long* h_seq = c->h_seq;
     // test hooks: the n-th record first arrives with a granule whose words do not fit its check word (what a torn 16-byte store
@@ -1162,11 +1248,12 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
     static const long torn_at = getenv("KSS_TEST_TORN_RES_GATE") ? atol(getenv("KSS_TEST_TORN_RES_GATE")) : -1;
     static const long stall_at = getenv("KSS_TEST_RES_STALL") ? atol(getenv("KSS_TEST_RES_STALL")) : -1;
     std::atomic<long> sent{0};
-    auto send = [&](int p, const float* T, int apply, int mode) {   // the gate record of pair p's NEXT pass (number H[p].k + 1)
+    auto send = [&](int p, const float* T, int apply, int mode, bool any_pass = false) {   // the gate record of pair p's NEXT pass (number H[p].k + 1)
         unsigned w[15];
         if (T) std::memcpy(w, T, 12 * sizeof(float)); else std::memset(w, 0, 12 * sizeof(float));
         w[12] = 1u; w[13] = (unsigned)apply; w[14] = (unsigned)mode;
-        const unsigned stamp = a.stamp0 + (unsigned)(H[p].k + 1);
+        // (any_pass: an order to stop that may land while some workgroups still wait for an EARLIER record -- one record per pair)
+        const unsigned stamp = a.stamp0 + (any_pass ? RES_STAMP_ANY : (unsigned)(H[p].k + 1));
         unsigned int* slot = gate + (size_t)p * 32;
         const long nth = sent.fetch_add(1) + 1;
         if (nth == stall_at) std::this_thread::sleep_for(std::chrono::milliseconds(300));
@@ -1189,15 +1276,26 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
         // (the calling thread stays until EVERY pair is done: it is the one that asks HIP whether the kernel is still there)
         while ((remaining > 0 || (t == 0 && pairs_left.load(std::memory_order_relaxed) > 0)) && !failed.load(std::memory_order_relaxed)) {
             bool progress = false;
+            const bool cancelling = judge >= 0 && cancel_all.load(std::memory_order_relaxed) != 0;
             for (int p = t; p < np; p += nt) {
                 PairHost& h = H[p];
                 if (h.phase == PH_DONE) continue;
+                if (cancelling && p != judge) {
+                    // the judge was good enough: this candidate's result will not be looked at.  Its workgroups are told to stop at
+                    // whatever gate they reach next (some may be inside a pass the others will never join: the tickets are cleared
+                    // after the launch); a candidate already on its last pass leaves by itself.
+                    if (h.phase == PH_ITER) send(p, nullptr, 0, 2, true);
+                    h.phase = PH_DONE; h.cancelled = 1; --remaining; pairs_left.fetch_sub(1, std::memory_order_relaxed);
+                    progress = true;
+                    continue;
+                }
                 if (!resident_collect(h_seq, p, a.seq0 + (unsigned long long)h.k, s)) continue;
                 progress = true;
                 ++my_units;
                 if (h.phase == PH_FIT) {   // getFitnessScore(): mean d2 over ALL source points
                     h.fitness = s[17] / (double)pl.g[p].ns;
                     h.phase = PH_DONE; --remaining; pairs_left.fetch_sub(1, std::memory_order_relaxed);
+                    if (p == judge && h.fitness <= judge_threshold) cancel_all.store(1, std::memory_order_relaxed);
                     continue;
                 }
                 bool finished = false;
@@ -1249,25 +1347,33 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
         if (const char* e = getenv("KSS_HOST_THREADS")) { const int u = atoi(e); if (u >= 1 && u <= 64) v = u; }
         return v;
     }();
-    const int nthreads = std::max(1, std::min(res_threads, (np + 7) / 8));
+    // (a candidate batch is a handful of pairs in lockstep, each pass a few microseconds: a thread per candidate, so that no
+    // answer queues behind another candidate's SVD; a large batch has pairs in every phase at any time: eight pairs a thread)
+    static const int cand_div = getenv("KSS_CAND_PAIRS_PER_THREAD") ? std::max(1, atoi(getenv("KSS_CAND_PAIRS_PER_THREAD"))) : 1;
+    const int nthreads = std::max(1, std::min(res_threads, cand ? (np + cand_div - 1) / cand_div : (np + 7) / 8));
     c->pool.run_threads(nthreads, serve);
     if (failed.load()) {
         // let every workgroup that still waits (or has not started yet) leave, then report: the caller starts over on the
-        // launch-per-pass engine (the resident kernel has written nothing but its result slots)
+        // launch-per-pass engine (the resident kernel has written nothing but its result slots -- and, for candidates, the
+        // tickets and rows the launch-per-pass form uses: re-armed here)
         for (int p = 0; p < np; ++p)
-            if (H[p].phase != PH_DONE) send(p, nullptr, 0, 2);
+            if (H[p].phase != PH_DONE) send(p, nullptr, 0, 2, true);
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (cand) { c->ws_dirty = true; KCHK(restore_zero_at_rest(c)); }
         std::fprintf(stderr, "[kss] the pair-resident kernel left before every pair was finished (a stalled host thread?); running the launch-per-pass engine\n");
         return KSS_OK;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));   // every workgroup has left (its last act was the publication just consumed)
+    if (cand && cancel_all.load() != 0)           // stopped candidates may have left a pass half drawn
+        HIPCHK(c, hipMemsetAsync(c->pair_ticket.p, 0, (size_t)np * sizeof(int32_t), c->stream));
     if (c->prof > 0) { c->prof_n[KSS_K_RESIDENT_PASS] += units.load(); }
     for (int p = 0; p < np; ++p) {
         kss_icp_result& r = results[p];
         std::memcpy(r.T, H[p].fin, 16 * sizeof(float));
-        r.iterations = H[p].iters; r.converged = H[p].converged; r.state = H[p].state;
-        r.last_mse = H[p].last_mse; r.fitness = P.compute_fitness ? H[p].fitness : 0.0; r.pair_id = p;
+        r.iterations = H[p].iters; r.converged = H[p].cancelled ? 0 : H[p].converged; r.state = H[p].cancelled ? KSS_STATE_NOT_CONVERGED : H[p].state;
+        r.last_mse = H[p].last_mse; r.fitness = P.compute_fitness && !H[p].cancelled ? H[p].fitness : 0.0; r.pair_id = p;
     }
+    if (judge >= 0) { c->spec_ran = true; c->spec_cancelled = cancel_all.load() != 0; }
     if (a.idx_out) {
         const size_t n0 = (size_t)pl.g[0].ns;
         if (P.fitness_idx) HIPCHK(c, hipMemcpyAsync(P.fitness_idx, a.idx_out, n0 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -1302,6 +1408,12 @@ static int icp_loop(kss_ctx* c, const IcpPlan& pl_in, const kss_icp_params& P, k
             return icp_loop(c, bp, Pb, results);
         }
     }
+    if (!pl_in.grid && !pl_in.gridb && pl_in.shared_target) {   // the candidate batch of a registration: one launch, every workgroup resident
+        bool handled = false;
+        KCHK(resident_loop(c, pl_in, P, results, &handled, true));
+        if (handled) return KSS_OK;
+    }
+    if (c->spec_judge >= 0) return KSS_OK;   // a speculative batch (kss_register) runs on that engine only: spec_ran stays false, the caller takes the sequential route
     const IcpPlan* plan = &pl_in;   // may change to the brute-force plan below
     IcpPlan brute_plan;
     const int np = pl_in.npairs;

@@ -681,8 +681,11 @@ do {                                                                            
 #ifndef KSS_BATCH_WAVES
 #define KSS_BATCH_WAVES 6   // waves per SIMD the batched variant is compiled for (3 workgroups per CU; 8 spills)
 #endif
+#ifndef KSS_SINGLE_WAVES
+#define KSS_SINGLE_WAVES 1
+#endif
 template <bool FMA, bool FULL, bool BATCH, bool SEARCH, bool CHAIN>
-__global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : 1) void grid_pass_kernel(const PassArgs a) {
+__global__ __launch_bounds__(PASS_BS, BATCH ? KSS_BATCH_WAVES : KSS_SINGLE_WAVES) void grid_pass_kernel(const PassArgs a) {
     static_assert(!CHAIN || (!BATCH && SEARCH), "chained launches: single pair, search passes");
     // diagnostic stamps (100 MHz s_memrealtime): [block*16 + {0 start, 13 first loads in, 9 gate open, 14 phase A done,
     // 5 phase B entered, 8 answered, 15 phase B done, 1 searched, 2 row ready, 3 ticketed, 4 result stored (last

@@ -134,6 +134,9 @@ constexpr int RES_NQ = 640;           // search requests queued per round (the r
 constexpr int RES_QW = 4;             // words per request {query, pruning radius}; answered in place {winner | runner-up << 16, bound, fell back}
 constexpr int RES_G = 4;              // source slots whose wave totals are in LDS at a time
 constexpr int RES_LDS_MAX = 160 * 1024 - 256;   // dynamic LDS of a workgroup (the rest: its few static words)
+// gate stamps: every launch owns 4096; stamp0 + k opens pass k (k <= 4002), stamp0 + RES_STAMP_ANY is accepted at ANY pass --
+// the host's order to stop, which may overwrite a record some workgroups have not read yet
+constexpr unsigned RES_STAMP_ANY = 4095u;
 struct ResArgs {
     const GridPairDev* pairs;                   // per-pair table (cell grid, segments, rows)
     const int32_t* cell_start;                  // exclusive prefix of the cell counts (global positions in `sorted`)
@@ -247,6 +250,29 @@ int cand_pass_blocks_per_pair(int64_t ns);
 bool launch_cand_pass(hipStream_t st, bool fma, int npairs, const PairState* d_state, const float4* d_src_in, float4* d_src_out, const float4* d_tgt,
                       int nt_pad, int ns, double max_d2, double* d_partials, int32_t* d_pair_ticket, unsigned long long* d_pub, unsigned long long seq,
                       int32_t* d_idx_out, float* d_d2_out);
+// ... and the same batch with every workgroup RESIDENT for the whole registration (cand_resident_kernel): the target is staged
+// once, the sources stay in registers, and between passes a candidate's workgroups wait at its gate record for the transform
+// the host solves from the sums its last workgroup published -- the protocol of the pair-resident engine (ResArgs), one
+// launch per batch instead of one per pass.  A workgroup owns up to CAND_TPW tiles of 32 sources of ONE candidate.
+constexpr int CAND_TPW = 4;
+struct CandArgs {
+    const float4* src0;                         // candidate p's sources at src0 + p * ns (original order)
+    const float4* tgt;                          // the shared target, nt_pad points (padding at +inf)
+    int32_t nt_pad, ns;
+    int32_t bpp, wpp, tpw;                      // tiles per candidate, workgroups per candidate, tiles per workgroup (<= CAND_TPW)
+    double max_d2;
+    double* partials;                           // one row of NSUMS per tile
+    int32_t* pair_ticket;                       // zero at rest
+    const unsigned int* gate;                   // per candidate 32 words the host stores into through the BAR
+    unsigned long long* pub;                    // host-mapped result slots
+    unsigned long long seq0;
+    unsigned int stamp0;
+    int32_t gate_polls, max_passes;
+    int32_t* idx_out; float* d2_out;            // fitness pass: per-source correspondences (null: not wanted)
+    unsigned long long* stamps;                 // diagnostics (null in production): 16 per candidate, written by its workgroup 0
+};
+int cand_resident_capacity(bool fma, int nt_pad);   // workgroups the device keeps resident at once (0: cannot run)
+int launch_cand_resident(hipStream_t st, bool fma, int npairs, const CandArgs& a, std::string& err);
 // idx-driven variant for kss_cov: d2 recomputed with the reference arithmetic
 void launch_corr_reduce_idx(hipStream_t st, const float* d_src3, const float* d_tgt3, const int32_t* d_idx,
                             int64_t n, double max_d2, double* d_partials, int n_blocks);

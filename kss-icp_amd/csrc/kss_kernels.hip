@@ -406,103 +406,133 @@ __global__ __launch_bounds__(256) void corr_reduce_kernel(const RedWork* __restr
 // eight addresses of a wave's read would hit the same banks).
 // ---------------------------------------------------------------------------------------------
 constexpr int CAND_SRC = 32;      // sources per workgroup (x 8 lanes = 256 threads)
+// The candidate kernels' tile: 32 sources of one candidate = four waves of eight sources; source i of a wave lives in lanes
+// 8i .. 8i+7 (lane 8i keeps its sums).  For the sweep a wave regroups: SIXTEEN lanes share TWO sources (row g of the wave:
+// sources 2g and 2g+1), lane e of the row sweeping slice e of the staged target for both -- one LDS read per two distance
+// evaluations (one source per lane was LDS-bound at 2.4 workgroups per CU, and with the compiler's one-read-one-wait
+// schedule latency-bound at one: 10.4 us per pass, measured).  Slice e = targets [e * chunk, (e + 1) * chunk), chunk a
+// multiple of 8, staged at stride chunk + 1 (odd: the sixteen addresses of a wave's read fall into sixteen different bank
+// groups) and padded with +inf points up to 16 * chunk.  Sub-tile minima over 8 points first, then the exact arg-min inside
+// the winning sub-tile (same arithmetic => same bits), ties to the lowest index; the sixteen keys are merged by DPP.  The
+// reads of the NEXT eight points are issued before the CURRENT eight are evaluated (two register sets, ping-pong).
+__device__ __forceinline__ int cand_chunk(int nt_pad) { return ((nt_pad + 15) / 16 + 7) / 8 * 8; }
+__device__ __forceinline__ int cand_slot(int k, int chunk) { return k + k / chunk; }
+__device__ __forceinline__ void cand_stage(float4* cand_tile, const float4* __restrict__ tgt, int nt_pad, int chunk) {
+    const float4 far = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.f);
+    for (int k = threadIdx.x; k < 16 * chunk; k += 256) cand_tile[cand_slot(k, chunk)] = k < nt_pad ? tgt[k] : far;
+    if (threadIdx.x < 8) cand_tile[16 * chunk + 16 + threadIdx.x] = far;   // (the look-ahead of the last slice reads into these)
+}
+
+struct CandQ8 { float x[8], y[8], z[8]; };
+__device__ __forceinline__ void cand_load8(CandQ8& q, const float4* __restrict__ t) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float4 v = t[j]; q.x[j] = v.x; q.y[j] = v.y; q.z[j] = v.z; }
+}
 template <bool FMA>
-__global__ __launch_bounds__(256) void cand_pass_kernel(const PairState* __restrict__ state, const float4* __restrict__ src_in, float4* __restrict__ src_out,
-                                                        const float4* __restrict__ tgt, int nt_pad, int ns, int blocks_per_pair, double max_d2,
-                                                        double* __restrict__ partials, int32_t* __restrict__ pair_ticket,
-                                                        unsigned long long* __restrict__ pub, unsigned long long seq,
-                                                        int32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
-    extern __shared__ float4 cand_tile[];
-    __shared__ double sh[4][NSUMS];
-    __shared__ int s_last;
-    const int pair = (int)blockIdx.x / blocks_per_pair, blk = (int)blockIdx.x % blocks_per_pair;
-    const PairState ps = state[pair];
-    if (!ps.active) return;   // uniform: whole workgroup leaves
-    const int tid = threadIdx.x, sub = tid & 7;
-    const int chunk = ((nt_pad + 7) / 8 + NN_SUB - 1) / NN_SUB * NN_SUB;   // targets per lane of a group: whole sub-tiles
-    for (int k = tid; k < nt_pad; k += 256) cand_tile[k + k / chunk] = tgt[k];
-    const int sl = blk * CAND_SRC + (tid >> 3);
-    const bool valid = sl < ns;
-    const int gi = pair * ns + sl;
-    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) p = src_in[gi];
-    if (ps.apply) {   // pcl transformCloud with the previous iteration's Matrix4f, Eigen order, float, no fma
-        const float x = p.x, y = p.y, z = p.z;
-        p.x = ((ps.m[0] * x + ps.m[1] * y) + ps.m[2] * z) + ps.m[3];
-        p.y = ((ps.m[4] * x + ps.m[5] * y) + ps.m[6] * z) + ps.m[7];
-        p.z = ((ps.m[8] * x + ps.m[9] * y) + ps.m[10] * z) + ps.m[11];
-    }
-    if (valid && sub == 0) src_out[gi] = p;
-    __syncthreads();
-    // this lane's eighth: sub-tile minima first
-    const int t_lo = sub * chunk, t_hi = min(t_lo + chunk, nt_pad);
-    const float4* __restrict__ tl = cand_tile + t_lo + sub;
-    float best = __builtin_inff();
-    int bsub = 0;
-    for (int s0 = 0; s0 < t_hi - t_lo; s0 += NN_SUB) {
-        float m = __builtin_inff();
+__device__ __forceinline__ void cand_min8(const CandQ8& q, float ax, float ay, float az, float bx, float by, float bz, float& ma, float& mb) {
+    ma = __builtin_inff(); mb = __builtin_inff();
 #pragma unroll
-        for (int u = 0; u < NN_SUB; ++u) {
-            const float4 q = tl[s0 + u];
-            m = fminf(m, dist2<FMA>(p.x, p.y, p.z, q.x, q.y, q.z));
-        }
-        if (m < best) { best = m; bsub = s0; }   // strict: the FIRST sub-tile holding the minimum wins
+    for (int j = 0; j < 8; ++j) {
+        ma = fminf(ma, dist2<FMA>(ax, ay, az, q.x[j], q.y[j], q.z[j]));
+        mb = fminf(mb, dist2<FMA>(bx, by, bz, q.x[j], q.y[j], q.z[j]));
     }
-    unsigned long long key = ~0ull;
-    if (t_hi > t_lo) {   // exact arg-min inside the winning sub-tile (same arithmetic => same bits as `best`)
-        float bd = __builtin_inff();
-        int bi = 0;
-#pragma unroll 8
-        for (int u = 0; u < NN_SUB; ++u) {
-            const float4 q = tl[bsub + u];
-            const float d = dist2<FMA>(p.x, p.y, p.z, q.x, q.y, q.z);
-            if (d < bd) { bd = d; bi = u; }
-        }
-        key = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned long long)(unsigned)(t_lo + bsub + bi);
+}
+template <bool FMA>
+__device__ __forceinline__ unsigned long long cand_argmin8(const float4* __restrict__ t, int first, float px, float py, float pz) {
+    CandQ8 q;
+    cand_load8(q, t);
+    float bd = __builtin_inff();
+    int bi = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float d = dist2<FMA>(px, py, pz, q.x[j], q.y[j], q.z[j]);
+        if (d < bd) { bd = d; bi = j; }
     }
-    // the group's minimum key (distance, then index): lanes l ^ 1, l ^ 2, l ^ 4 by DPP
-    {
-        auto x1 = [](int v) { return __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, false); };
-        auto x2 = [](int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4e, 0xf, 0xf, false); };
-        auto x4 = [](int v) { const int r = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xf, 0x5, false); return __builtin_amdgcn_update_dpp(r, v, 0x114, 0xf, 0xa, false); };
+    return ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned long long)(unsigned)(first + bi);
+}
+__device__ __forceinline__ unsigned long long cand_key_min16(unsigned long long key) {   // minimum over the 16 lanes of a row (every lane gets it)
+    auto x1 = [](int v) { return __builtin_amdgcn_mov_dpp(v, 0xb1, 0xf, 0xf, false); };
+    auto x2 = [](int v) { return __builtin_amdgcn_mov_dpp(v, 0x4e, 0xf, 0xf, false); };
+    auto x4 = [](int v) { const int r = __builtin_amdgcn_mov_dpp(v, 0x104, 0xf, 0x5, false); return __builtin_amdgcn_update_dpp(r, v, 0x114, 0xf, 0xa, false); };
+    auto x8 = [](int v) { return __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, false); };
 #define KSS_CAND_MIN(X) do { const unsigned long long o = ((unsigned long long)(unsigned)X((int)(unsigned)(key >> 32)) << 32) | (unsigned)X((int)(unsigned)key); key = o < key ? o : key; } while (0)
-        KSS_CAND_MIN(x1);
-        KSS_CAND_MIN(x2);
-        KSS_CAND_MIN(x4);
+    KSS_CAND_MIN(x1);
+    KSS_CAND_MIN(x2);
+    KSS_CAND_MIN(x4);
+    KSS_CAND_MIN(x8);
 #undef KSS_CAND_MIN
-    }
-    double acc[NSUMS];
+    return key;
+}
+// p: this lane's source (lanes 8i .. 8i+7 hold source i of the wave).  Returns the nearest target's key of THAT source.
+template <bool FMA>
+__device__ __forceinline__ unsigned long long cand_sweep(const float4* cand_tile, int chunk, float px, float py, float pz) {
+    const int lane = threadIdx.x & 63, e = lane & 15, row = lane & 48;
+    const float ax = __shfl(px, row, 64), ay = __shfl(py, row, 64), az = __shfl(pz, row, 64);
+    const float bx = __shfl(px, row + 8, 64), by = __shfl(py, row + 8, 64), bz = __shfl(pz, row + 8, 64);
+    const float4* __restrict__ tl = cand_tile + e * (chunk + 1);
+    float best_a = __builtin_inff(), best_b = __builtin_inff();
+    int sub_a = 0, sub_b = 0;
+    CandQ8 q0, q1;
+    cand_load8(q0, tl);
+    const int nb = chunk / 8;
+    auto step = [&](const CandQ8& cur, CandQ8& nxt, int b) {
+        cand_load8(nxt, tl + (b + 1) * 8);          // (past the last batch: the next slice or the padding behind the tile; never used)
+        __builtin_amdgcn_sched_barrier(0);
+        float ma, mb;
+        cand_min8<FMA>(cur, ax, ay, az, bx, by, bz, ma, mb);
+        if (ma < best_a) { best_a = ma; sub_a = b * 8; }   // strict: the FIRST sub-tile holding the minimum wins
+        if (mb < best_b) { best_b = mb; sub_b = b * 8; }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int b = 0;
+    for (; b + 1 < nb; b += 2) { step(q0, q1, b); step(q1, q0, b + 1); }
+    if (b < nb) step(q0, q1, b);
+    unsigned long long key_a = cand_argmin8<FMA>(tl + sub_a, e * chunk + sub_a, ax, ay, az);
+    unsigned long long key_b = cand_argmin8<FMA>(tl + sub_b, e * chunk + sub_b, bx, by, bz);
+    key_a = cand_key_min16(key_a);
+    key_b = cand_key_min16(key_b);
+    return (lane & 8) ? key_b : key_a;
+}
+
+// Workgroup total of the 20 sums when only the lanes 8i hold a source's contribution (all others +0.0): per column the tree
+// of block_sum / wave_sum -- partners at lane distance 32, 16, 8, then 4, 2, 1 -- whose last three levels add +0.0 and are
+// skipped (x + 0.0 == x bit for bit; a sum that starts from +0.0 is never -0.0), the first three evaluated with the in-place
+// swaps of the canonical tree, two columns per exchange; then the four wave totals in wave order.  Same bits as
+// block_sum<NSUMS>, a twentieth of its exchanges (each of which was two LDS permutes: 5.9 us per pass, measured).
+__device__ __forceinline__ double cand_block_sum(double (&v)[NSUMS], double (*sh)[NSUMS]) {
+    static_assert(NSUMS == 20, "two levels of halving: 20 -> 10 -> 5 columns");
 #pragma unroll
-    for (int c = 0; c < NSUMS; ++c) acc[c] = 0.0;
-    const bool qok = (p.x - p.x) == 0.f && (p.y - p.y) == 0.f && (p.z - p.z) == 0.f;   // a non-finite query matches nothing
-    if (valid && sub == 0 && qok && key != ~0ull) {
-        const float d2 = __uint_as_float((unsigned)(key >> 32));
-        const int idx = (int)(unsigned)(key & 0xffffffffull);
-        const float4 q = cand_tile[idx + idx / chunk];
-        accumulate_corr(acc, p.x, p.y, p.z, q.x, q.y, q.z, d2, max_d2);
-        if (idx_out) idx_out[gi] = idx;
-        if (d2_out) d2_out[gi] = d2;
-    }
-    const double r = block_sum<NSUMS>(acc, sh);
-    const int row0 = pair * blocks_per_pair;
-    if (tid < NSUMS) {
-        __hip_atomic_store(&partials[(int64_t)(row0 + blk) * NSUMS + tid], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int j = 0; j < 10; ++j) v[j] = level32(v[j], v[j + 10]);   // lanes < 32: columns 0-9, lanes >= 32: columns 10-19
+#pragma unroll
+    for (int j = 0; j < 5; ++j) v[j] = level16(v[j], v[j + 5]);     // rows 0 / 1 / 2 / 3: columns 0-4 / 5-9 / 10-14 / 15-19
+#pragma unroll
+    for (int j = 0; j < 5; ++j) v[j] += xor8(v[j]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((lane & 15) == 0) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) sh[wave][5 * (lane >> 4) + j] = v[j];
     }
     __syncthreads();
-    if (tid == 0) s_last = atomicAdd(&pair_ticket[pair], 1) == blocks_per_pair - 1;
-    __syncthreads();
-    if (!s_last) return;
-    __shared__ double shg[ROWSUM_GROUPS][NSUMS];
+    double out = 0.0;
+    if (threadIdx.x < NSUMS)
+        for (int w = 0; w < 4; ++w) out += sh[w][threadIdx.x];   // fixed order: reproducible
+    return out;
+}
+
+// A candidate's last workgroup: the column sums of its rows in a fixed order (lane (g, c) adds rows g, g + 12, ..., then the
+// 12 group totals in group order) and the publication of the 20 sums as checked {bits, launch number} granules.
+__device__ __forceinline__ void cand_rows_publish(const double* __restrict__ partials, int row0, int nrows, double (*shg)[NSUMS],
+                                                  unsigned long long* __restrict__ pub, int pair, unsigned long long seq) {
+    const int tid = threadIdx.x;
     {
         const int g = tid / NSUMS, c = tid % NSUMS;
         if (g < ROWSUM_GROUPS) {
             double a = 0.0;
-            for (int k = g; k < blocks_per_pair; k += 8 * ROWSUM_GROUPS) {
+            for (int k = g; k < nrows; k += 8 * ROWSUM_GROUPS) {
                 double tt[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    tt[j] = k + j * ROWSUM_GROUPS < blocks_per_pair
+                    tt[j] = k + j * ROWSUM_GROUPS < nrows
                                 ? __hip_atomic_load(&partials[(int64_t)(row0 + k + j * ROWSUM_GROUPS) * NSUMS + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                 : 0.0;
 #pragma unroll
@@ -522,10 +552,65 @@ __global__ __launch_bounds__(256) void cand_pass_kernel(const PairState* __restr
         unsigned long long* dst = pub + 2 * ((int64_t)pair * NSUMS + tid);
         asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(o) : "memory");
     }
+}
+
+template <bool FMA>
+__global__ __launch_bounds__(256) void cand_pass_kernel(const PairState* __restrict__ state, const float4* __restrict__ src_in, float4* __restrict__ src_out,
+                                                        const float4* __restrict__ tgt, int nt_pad, int ns, int blocks_per_pair, double max_d2,
+                                                        double* __restrict__ partials, int32_t* __restrict__ pair_ticket,
+                                                        unsigned long long* __restrict__ pub, unsigned long long seq,
+                                                        int32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
+    extern __shared__ float4 cand_tile[];
+    __shared__ double sh[4][NSUMS];
+    __shared__ int s_last;
+    const int pair = (int)blockIdx.x / blocks_per_pair, blk = (int)blockIdx.x % blocks_per_pair;
+    const PairState ps = state[pair];
+    if (!ps.active) return;   // uniform: whole workgroup leaves
+    const int tid = threadIdx.x, sub = tid & 7;
+    const int chunk = cand_chunk(nt_pad);
+    cand_stage(cand_tile, tgt, nt_pad, chunk);
+    const int sl = blk * CAND_SRC + (tid >> 3);
+    const bool valid = sl < ns;
+    const int gi = pair * ns + sl;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) p = src_in[gi];
+    if (ps.apply) {   // pcl transformCloud with the previous iteration's Matrix4f, Eigen order, float, no fma
+        const float x = p.x, y = p.y, z = p.z;
+        p.x = ((ps.m[0] * x + ps.m[1] * y) + ps.m[2] * z) + ps.m[3];
+        p.y = ((ps.m[4] * x + ps.m[5] * y) + ps.m[6] * z) + ps.m[7];
+        p.z = ((ps.m[8] * x + ps.m[9] * y) + ps.m[10] * z) + ps.m[11];
+    }
+    if (valid && sub == 0) src_out[gi] = p;
+    __syncthreads();
+    const unsigned long long key = cand_sweep<FMA>(cand_tile, chunk, p.x, p.y, p.z);
+    double acc[NSUMS];
+#pragma unroll
+    for (int c = 0; c < NSUMS; ++c) acc[c] = 0.0;
+    const bool qok = (p.x - p.x) == 0.f && (p.y - p.y) == 0.f && (p.z - p.z) == 0.f;   // a non-finite query matches nothing
+    if (valid && sub == 0 && qok && key != ~0ull) {
+        const float d2 = __uint_as_float((unsigned)(key >> 32));
+        const int idx = (int)(unsigned)(key & 0xffffffffull);
+        const float4 q = cand_tile[cand_slot(idx, chunk)];
+        accumulate_corr(acc, p.x, p.y, p.z, q.x, q.y, q.z, d2, max_d2);
+        if (idx_out) idx_out[gi] = idx;
+        if (d2_out) d2_out[gi] = d2;
+    }
+    const double r = cand_block_sum(acc, sh);
+    const int row0 = pair * blocks_per_pair;
+    if (tid < NSUMS) {
+        __hip_atomic_store(&partials[(int64_t)(row0 + blk) * NSUMS + tid], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&pair_ticket[pair], 1) == blocks_per_pair - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __shared__ double shg[ROWSUM_GROUPS][NSUMS];
+    cand_rows_publish(partials, row0, blocks_per_pair, shg, pub, pair, seq);
     if (tid == 0) pair_ticket[pair] = 0;   // re-arm for the next pass (stream order makes it visible)
 }
 
-size_t cand_pass_lds_bytes(int nt_pad) { return (size_t)(nt_pad + 8) * sizeof(float4); }
+size_t cand_pass_lds_bytes(int nt_pad) { return (size_t)(16 * (((nt_pad + 15) / 16 + 7) / 8 * 8) + 24) * sizeof(float4); }   // 16 padded slices at stride chunk + 1, eight points of look-ahead
 int cand_pass_blocks_per_pair(int64_t ns) { return (int)((ns + CAND_SRC - 1) / CAND_SRC); }
 // false: the device refused the LDS size (the caller runs sweep + reduce)
 bool launch_cand_pass(hipStream_t st, bool fma, int npairs, const PairState* d_state, const float4* d_src_in, float4* d_src_out, const float4* d_tgt,
@@ -539,6 +624,179 @@ bool launch_cand_pass(hipStream_t st, bool fma, int npairs, const PairState* d_s
     if (fma) hipLaunchKernelGGL(cand_pass_kernel<true>, grid, block, bytes, st, d_state, d_src_in, d_src_out, d_tgt, nt_pad, ns, bpp, max_d2, d_partials, d_pair_ticket, d_pub, seq, d_idx_out, d_d2_out);
     else hipLaunchKernelGGL(cand_pass_kernel<false>, grid, block, bytes, st, d_state, d_src_in, d_src_out, d_tgt, nt_pad, ns, bpp, max_d2, d_partials, d_pair_ticket, d_pub, seq, d_idx_out, d_d2_out);
     return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The candidate batch, every workgroup resident for the whole registration (CandArgs, kss_internal.hpp).  Same tiles, same
+// sweep, same sums in the same order as cand_pass_kernel -- a candidate gives the same bits on both -- but ONE launch per
+// batch: the target is staged once, a workgroup's sources stay in registers, and after a candidate's last workgroup has
+// published the 20 sums of a pass all its workgroups wait at the candidate's gate record (five checked granules the host
+// stores through the BAR, the protocol of resident_icp_kernel) for the next transform, the order to run the
+// getFitnessScore() pass, or to stop.  Every poll is bounded: a workgroup nobody answers leaves and the host starts over on
+// the launch-per-pass form.  The launch must fit the device at once (cand_resident_capacity): a workgroup that never
+// starts would keep its candidate's sums from ever being complete.
+// ---------------------------------------------------------------------------------------------
+template <bool FMA>
+__global__ __launch_bounds__(256) void cand_resident_kernel(const CandArgs a) {
+    extern __shared__ float4 cand_tile[];
+    __shared__ double sh[4][NSUMS];
+    __shared__ double shg[ROWSUM_GROUPS][NSUMS];
+    __shared__ int s_ps[16];
+    __shared__ int s_ctl[2];      // [0] the gate was answered, [1] this workgroup drew the candidate's last ticket
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int pair = (int)blockIdx.x / a.wpp, wg = (int)blockIdx.x % a.wpp;
+    const int tid = threadIdx.x, sub = tid & 7;
+    const int nt_pad = a.nt_pad, ns = a.ns;
+    const int chunk = cand_chunk(nt_pad);
+    // diagnostic timeline (100 MHz s_memrealtime), by workgroup 0 of each candidate: [0] start, [1] target staged, [15] end; sums
+    // over the passes >= 1 of {8 gate wait, 9 sweeps, 10 sums + rows, 11 ticket, 12 the candidate's total + publication}; 7 passes
+    unsigned long long t_last = 0;
+    const bool stamping = a.stamps != nullptr && wg == 0 && tid == 0;
+#define KSS_CSTAMP(k) do { if (stamping) a.stamps[(size_t)pair * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define KSS_CLAP(k) do { if (stamping) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); if (pass > 0) a.stamps[(size_t)pair * 16 + (k)] += now_ - t_last; t_last = now_; } } while (0)
+    KSS_CSTAMP(0);
+    cand_stage(cand_tile, a.tgt, nt_pad, chunk);
+    // tile j of this workgroup = tile wg + j * wpp of the candidate: 32 sources, eight lanes each
+    float px[CAND_TPW], py[CAND_TPW], pz[CAND_TPW];
+#pragma unroll
+    for (int j = 0; j < CAND_TPW; ++j) {
+        px[j] = py[j] = pz[j] = 0.f;
+        const int blk = wg + j * a.wpp, sl = blk * CAND_SRC + (tid >> 3);
+        if (j < a.tpw && blk < a.bpp && sl < ns) {
+            const float4 v = a.src0[(int64_t)pair * ns + sl];
+            px[j] = v.x; py[j] = v.y; pz[j] = v.z;
+        }
+    }
+    __syncthreads();
+    KSS_CSTAMP(1);
+    if (stamping) t_last = __builtin_amdgcn_s_memrealtime();
+    const int row0 = pair * a.bpp;
+    float m[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) m[k] = 0.f;
+    int apply = 0, mode = 0;      // mode 0: a regular pass; 1: the getFitnessScore() pass (the last one); 2: stop
+    for (int pass = 0; pass < a.max_passes; ++pass) {
+        if (pass > 0) {
+            if (tid < 8) {
+                const unsigned expect = a.stamp0 + (unsigned)pass;
+                const unsigned int* src = a.gate + (size_t)pair * 32 + 4 * min(tid, 4);
+                u32x4 v;
+                int n = 0;
+                bool ok = true;
+                for (;;) {
+                    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(src) : "memory");   // system scope: the writer is the host
+                    const unsigned tag = v.w - kss_mix3(v.x, v.y, v.z);
+                    if (__builtin_amdgcn_ballot_w64(tag == expect) == 0xffull) break;
+                    if (__builtin_amdgcn_ballot_w64(tag == a.stamp0 + RES_STAMP_ANY) == 0xffull) break;   // "whatever pass you wait for": a stop order
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++n > a.gate_polls) { ok = false; break; }
+                }
+                if (tid < 5) { s_ps[3 * tid] = (int)v.x; s_ps[3 * tid + 1] = (int)v.y; s_ps[3 * tid + 2] = (int)v.z; }
+                if (tid == 0) s_ctl[0] = ok ? 1 : 0;
+            }
+            __syncthreads();
+            if (!s_ctl[0]) { KSS_CSTAMP(15); return; }   // nobody answered: leave (the host's wait reports it)
+#pragma unroll
+            for (int k = 0; k < 12; ++k) m[k] = __int_as_float(__builtin_amdgcn_readfirstlane(s_ps[k]));
+            apply = __builtin_amdgcn_readfirstlane(s_ps[13]);
+            mode = __builtin_amdgcn_readfirstlane(s_ps[14]);
+            if (mode >= 2) { KSS_CSTAMP(15); return; }
+        }
+        KSS_CLAP(8);
+        const bool fit = mode == 1;
+        // (ONE copy of the tile's code in a runtime loop: the tile being worked on is register 0 of each array, the arrays
+        // rotate by one after every trip and CAND_TPW trips bring every tile home again)
+#pragma unroll 1
+        for (int j = 0; j < CAND_TPW; ++j) {
+            const int blk = wg + j * a.wpp;
+            const bool mine = j < a.tpw && blk < a.bpp;   // uniform
+            if (mine) {
+            const int sl = blk * CAND_SRC + (tid >> 3);
+            const bool valid = sl < ns;
+            const int64_t gi = (int64_t)pair * ns + sl;
+            float x = px[0], y = py[0], z = pz[0];
+            if (fit && valid) {   // getFitnessScore(): final * ORIGINAL input
+                const float4 v = a.src0[gi];
+                x = v.x; y = v.y; z = v.z;
+            }
+            if (apply) {   // pcl transformCloud with the previous iteration's Matrix4f, Eigen order, float, no fma
+                px[0] = ((m[0] * x + m[1] * y) + m[2] * z) + m[3];
+                py[0] = ((m[4] * x + m[5] * y) + m[6] * z) + m[7];
+                pz[0] = ((m[8] * x + m[9] * y) + m[10] * z) + m[11];
+            }
+            const float4 p = make_float4(px[0], py[0], pz[0], 0.f);
+            const unsigned long long key = cand_sweep<FMA>(cand_tile, chunk, p.x, p.y, p.z);
+            KSS_CLAP(9);
+            double acc[NSUMS];
+#pragma unroll
+            for (int c = 0; c < NSUMS; ++c) acc[c] = 0.0;
+            const bool qok = (p.x - p.x) == 0.f && (p.y - p.y) == 0.f && (p.z - p.z) == 0.f;   // a non-finite query matches nothing
+            if (valid && sub == 0 && qok && key != ~0ull) {
+                const float d2 = __uint_as_float((unsigned)(key >> 32));
+                const int idx = (int)(unsigned)(key & 0xffffffffull);
+                const float4 q = cand_tile[cand_slot(idx, chunk)];
+                accumulate_corr(acc, p.x, p.y, p.z, q.x, q.y, q.z, d2, a.max_d2);
+                if (fit && a.idx_out) a.idx_out[gi] = idx;
+                if (fit && a.d2_out) a.d2_out[gi] = d2;
+            }
+            const double r = cand_block_sum(acc, sh);
+            if (tid < NSUMS) __hip_atomic_store(&a.partials[(int64_t)(row0 + blk) * NSUMS + tid], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();               // (sh is written again by the next tile)
+            }
+            {
+                const float x0 = px[0], y0 = py[0], z0 = pz[0];
+#pragma unroll
+                for (int k = 0; k + 1 < CAND_TPW; ++k) { px[k] = px[k + 1]; py[k] = py[k + 1]; pz[k] = pz[k + 1]; }
+                px[CAND_TPW - 1] = x0; py[CAND_TPW - 1] = y0; pz[CAND_TPW - 1] = z0;
+            }
+        }
+        if (tid < NSUMS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        KSS_CLAP(10);
+        if (tid == 0) {
+            const int last = atomicAdd(&a.pair_ticket[pair], 1) == a.wpp - 1;
+            if (last) {   // re-armed BEFORE the publication: the next pass's tickets are drawn only after the host has answered it
+                __hip_atomic_store(&a.pair_ticket[pair], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            s_ctl[1] = last;
+        }
+        __syncthreads();
+        KSS_CLAP(11);
+        if (s_ctl[1]) cand_rows_publish(a.partials, row0, a.bpp, shg, a.pub, pair, a.seq0 + (unsigned long long)pass);
+        KSS_CLAP(12);
+        if (stamping) a.stamps[(size_t)pair * 16 + 7] = (unsigned long long)(pass + 1);
+        if (fit) break;
+    }
+    KSS_CSTAMP(15);
+#undef KSS_CSTAMP
+#undef KSS_CLAP
+}
+
+int cand_resident_capacity(bool fma, int nt_pad) {
+    const size_t bytes = cand_pass_lds_bytes(nt_pad);
+    const void* fn = fma ? reinterpret_cast<const void*>(&cand_resident_kernel<true>) : reinterpret_cast<const void*>(&cand_resident_kernel<false>);
+    if (bytes > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, bytes) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+        hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return per_cu * prop.multiProcessorCount;
+}
+
+int launch_cand_resident(hipStream_t st, bool fma, int npairs, const CandArgs& a, std::string& err) {
+    const size_t bytes = cand_pass_lds_bytes(a.nt_pad);
+    const void* fn = fma ? reinterpret_cast<const void*>(&cand_resident_kernel<true>) : reinterpret_cast<const void*>(&cand_resident_kernel<false>);
+    if (bytes > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        err = "cand_resident: the device refused the LDS size";
+        return KSS_ERR_HIP;
+    }
+    const dim3 grid((unsigned)(npairs * a.wpp)), block(256);
+    if (fma) hipLaunchKernelGGL(cand_resident_kernel<true>, grid, block, bytes, st, a);
+    else hipLaunchKernelGGL(cand_resident_kernel<false>, grid, block, bytes, st, a);
+    if (hipGetLastError() != hipSuccess) { err = "cand_resident: launch failed"; return KSS_ERR_HIP; }
+    return KSS_OK;
 }
 
 void launch_corr_reduce(hipStream_t st, const RedWork* d_work, int n_work, const PairState* d_state,

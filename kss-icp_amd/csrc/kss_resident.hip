@@ -364,7 +364,9 @@ __global__ __launch_bounds__(RES_THREADS, 1) void resident_icp_kernel(const ResA
                 bool ok = true;
                 for (;;) {
                     asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(src) : "memory");   // system scope: the writer is the host
-                    if (__builtin_amdgcn_ballot_w64(v.w - kss_mix3(v.x, v.y, v.z) == expect) == 0xffull) break;
+                    const unsigned tag = v.w - kss_mix3(v.x, v.y, v.z);
+                    if (__builtin_amdgcn_ballot_w64(tag == expect) == 0xffull) break;
+                    if (__builtin_amdgcn_ballot_w64(tag == a.stamp0 + RES_STAMP_ANY) == 0xffull) break;   // "whatever pass you wait for": a stop order
                     __builtin_amdgcn_s_sleep(2);
                     if (++n > a.gate_polls) { ok = false; break; }
                 }
