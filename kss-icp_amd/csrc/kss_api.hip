@@ -739,6 +739,14 @@ int kss_register(kss_ctx* c, const double* src_sub, int64_t nss, const double* t
     if (nss <= 0 || nts <= 0 || nsf < 0 || (nsf > 0 && !src_full)) return set_err(c, KSS_ERR_ARG, "register: bad sizes");
     HIPCHK(c, hipSetDevice(c->device));
     std::memset(res, 0, sizeof *res);
+    const bool reg_timing = getenv("KSS_TIMING") != nullptr;   // phase report on stderr (wall clock; the phases that enqueue only are charged to the next one that waits)
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!reg_timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[kss] register: %-34s %8.1f us\n", what, std::chrono::duration<double, std::micro>(now - t_prev).count());
+        t_prev = now;
+    };
     // resident copies of S', T' (f64) in the context's grow-only workspace (no hipMalloc / hipFree per registration:
     // each costs tens of microseconds and hipFree synchronises the device)
     DevBuf &dS = c->reg_s, &dT = c->reg_t, &dP = c->reg_p, &dAll = c->reg_all;
@@ -746,6 +754,7 @@ int kss_register(kss_ctx* c, const double* src_sub, int64_t nss, const double* t
     RCHK(upload(c, dS, src_sub, (size_t)nss * 3 * sizeof(double)));
     RCHK(upload(c, dT, tgt_sub, (size_t)nts * 3 * sizeof(double)));
     RCHK(ensure(c, dP, (size_t)nss * 3 * sizeof(double)));
+    lap("uploads");
     // (a2) pre-shape
     double cS[3], cT[3], rS, rT;
     RCHK(kss_preshape_stats_pair_dev(c, dS.p, nss, dT.p, nts, KSS_F64, cS, &rS, cT, &rT));
@@ -755,16 +764,19 @@ int kss_register(kss_ctx* c, const double* src_sub, int64_t nss, const double* t
     res->scale = pose.scale;
     for (int k = 0; k < 3; ++k) { res->c_src[k] = cS[k]; res->c_tgt[k] = cT[k]; }
     RCHK(kss_pose_apply_dev(c, (const double*)dS.p, nss, &pose, (double*)dP.p));   // S' (angle 0 -> exact identity rotation)
+    lap("pre-shape statistics + pose");
     // (a4) rotation search
     std::vector<double> err(40 * 40 * 40);
     int g = 0;
     RCHK(kss_rotation_search_dev(c, (const double*)dP.p, nss, (const double*)dT.p, nts, accurate, err.data(), (int64_t)err.size(), &g));
     res->grid = g;
+    lap("rotation search");
     std::vector<double> alist((size_t)3 * g * g * g);
     double best[3];
     int nl = 0;
     RCHK(kss_rotation_candidates(err.data(), g, accurate, best, alist.data(), g * g * g, &nl));
     res->n_angle_list = nl;
+    lap("candidate list (host)");
 
     kss_icp_params ip;
     kss_icp_default_params(&ip);
@@ -781,16 +793,25 @@ int kss_register(kss_ctx* c, const double* src_sub, int64_t nss, const double* t
     // independent registration: the results equal those of the sequential calls.  KSS_REGISTER_SPEC=0, or an engine that
     // cannot cancel (no large BAR, a batch that does not fit the device at once): the sequential route below.
     static const bool want_spec = getenv("KSS_REGISTER_SPEC") == nullptr || atoi(getenv("KSS_REGISTER_SPEC")) != 0;
-    auto fill_poses = [&](int n_list, bool with_judge) -> int {
-        RCHK(ensure(c, dAll, (size_t)(n_list + (with_judge ? 1 : 0)) * nss * 3 * sizeof(double)));
-        for (int i = 0; i < n_list + (with_judge ? 1 : 0); ++i) {
-            for (int k = 0; k < 3; ++k) pose.angle[k] = i < n_list ? alist[3 * i + k] : best[k];
-            RCHK(kss_pose_apply_dev(c, (const double*)dS.p, nss, &pose, (double*)dAll.p + (size_t)i * nss * 3));
+    auto fill_poses = [&](int n_list, bool with_judge) -> int {   // every candidate pose of S (and the judge's) in one launch
+        const int count = n_list + (with_judge ? 1 : 0);
+        RCHK(ensure(c, dAll, (size_t)count * nss * 3 * sizeof(double)));
+        std::vector<double> cs((size_t)count * 6);
+        for (int i = 0; i < count; ++i) {
+            const double* ang = i < n_list ? &alist[3 * i] : best;
+            // cos/sin evaluated on the host so that they are the caller's libm values (as kss_pose_apply_dev)
+            for (int k = 0; k < 3; ++k) { cs[6 * i + 2 * k] = std::cos(ang[k]); cs[6 * i + 2 * k + 1] = std::sin(ang[k]); }
         }
+        {
+            ProfScope ps(c, KSS_K_POSE_APPLY);
+            launch_pose_apply_many(c->stream, (const double*)dS.p, nss, pose, reinterpret_cast<const double (*)[6]>(cs.data()), count, (double*)dAll.p);
+        }
+        HIPCHK(c, hipGetLastError());
         return KSS_OK;
     };
     if (want_spec && nl > 0) {
         RCHK(fill_poses(nl, true));
+        lap("candidate poses (enqueue)");
         std::vector<int64_t> so(nl + 2);
         for (int i = 0; i <= nl + 1; ++i) so[i] = (int64_t)i * nss;
         rr.resize(nl + 1);
@@ -834,6 +855,7 @@ int kss_register(kss_ctx* c, const double* src_sub, int64_t nss, const double* t
     } else if (res->E_d_init > 0.0005) {
         res->used_angle_list = 1;  // empty angle list: the reference would index out of range; keep the best grid pose
     }
+    lap("judge + candidate ICPs");
     for (int k = 0; k < 3; ++k) res->angle[k] = chosen[k];
     res->final_fitness = rfinal.fitness;
     res->icp_iterations = rfinal.iterations;
@@ -862,6 +884,7 @@ int kss_register(kss_ctx* c, const double* src_sub, int64_t nss, const double* t
         if (rc != KSS_OK) return rc;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    lap("transform of the full cloud + copy");
 #undef RCHK
     return KSS_OK;
 }

@@ -255,7 +255,9 @@ static int stage_plan(kss_ctx* c, const IcpPlan& pl) {
     KCHK(ensure_pinned(c, c->h_state, c->h_state_cap, (size_t)pl.npairs * sizeof(PairState)));
     KCHK(ensure_pub(c, pl.npairs));
     c->tables_staged = false;
-    if (!pl.grid) KCHK(stage_tables(c, pl));   // the fused cell-list path needs them only if a query falls back
+    // (the fused cell-list path needs the tables only if a query falls back, the candidate kernels not at all: nn_pass stages
+    // them the first time its sweep + reduce form runs)
+    if (!pl.grid && !pl.shared_target) KCHK(stage_tables(c, pl));
     return KSS_OK;
 }
 
@@ -967,6 +969,7 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
             }
         }
     }
+    KCHK(stage_tables(c, pl));
     {
         ProfScope ps(c, KSS_K_NN_SWEEP);
         launch_nn_sweep(c->stream, pl.S, fma, (const NNWork*)c->nn_work.p, (int)pl.nn.size(), d_state,

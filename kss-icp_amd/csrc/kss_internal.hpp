@@ -287,6 +287,8 @@ void launch_row_sums(hipStream_t st, const double* d_partials, int n_rows, int n
 
 void launch_pose_apply(hipStream_t st, const double* d_in, int64_t n, const kss_pose& pose,
                        const double cs[6], double* d_out);
+constexpr int POSE_MANY = 32;
+void launch_pose_apply_many(hipStream_t st, const double* d_in, int64_t n, const kss_pose& pose, const double (*cs)[6], int count, double* d_out);
 void launch_transform_apply_f64(hipStream_t st, const float T[16], const double* d_in, int64_t n, double* d_out);
 
 void launch_transform_apply_f32(hipStream_t st, const float T[16], const float* d_in, int64_t n, float* d_out);

@@ -1132,6 +1132,37 @@ void launch_pose_apply(hipStream_t st, const double* d_in, int64_t n, const kss_
     hipLaunchKernelGGL(pose_apply_kernel, dim3(stream_blocks(n)), dim3(256), 0, st, d_in, n, a, d_out);
 }
 
+// the same pose with up to POSE_MANY different Euler angles, one output cloud per angle (the candidate poses of a
+// registration: one launch instead of one per candidate); same arithmetic per point as pose_apply_kernel
+struct PoseManyArgs { double shift[3], center[3], scale; double cs[POSE_MANY][6]; };
+__global__ __launch_bounds__(256) void pose_apply_many_kernel(const double* __restrict__ in, int64_t n, PoseManyArgs a, double* __restrict__ out) {
+    const int q = blockIdx.y;
+    double* __restrict__ o = out + (int64_t)q * n * 3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double v[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double s = in[3 * i + k] + a.shift[k];
+            v[k] = a.center[k] + (s - a.center[k]) * a.scale;
+        }
+        euler_rotate(v[0], v[1], v[2], a.cs[q][0], a.cs[q][1], a.cs[q][2], a.cs[q][3], a.cs[q][4], a.cs[q][5]);
+        o[3 * i] = v[0]; o[3 * i + 1] = v[1]; o[3 * i + 2] = v[2];
+    }
+}
+
+void launch_pose_apply_many(hipStream_t st, const double* d_in, int64_t n, const kss_pose& pose, const double (*cs)[6], int count, double* d_out) {
+    if (n <= 0) return;
+    for (int q0 = 0; q0 < count; q0 += POSE_MANY) {
+        const int m = std::min(POSE_MANY, count - q0);
+        PoseManyArgs a;
+        for (int k = 0; k < 3; ++k) { a.shift[k] = pose.shift[k]; a.center[k] = pose.center[k]; }
+        a.scale = pose.scale;
+        for (int q = 0; q < m; ++q)
+            for (int k = 0; k < 6; ++k) a.cs[q][k] = cs[q0 + q][k];
+        hipLaunchKernelGGL(pose_apply_many_kernel, dim3(stream_blocks(n), m), dim3(256), 0, st, d_in, n, a, d_out + (int64_t)q0 * n * 3);
+    }
+}
+
 struct M34 { float m[12]; };
 
 __global__ __launch_bounds__(256) void transform_apply_f64_kernel(const double* __restrict__ in, int64_t n, M34 T,
