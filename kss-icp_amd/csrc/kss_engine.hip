@@ -250,7 +250,7 @@ static int stage_plan(kss_ctx* c, const IcpPlan& pl) {
     KCHK(ensure(c, c->red_work, pl.red.size() * sizeof(RedWork)));
     KCHK(ensure(c, c->pair_red, pl.pred.size() * sizeof(PairRed)));
     KCHK(ensure(c, c->state, (size_t)pl.npairs * sizeof(PairState)));
-    KCHK(ensure_zeroed(c, c->pair_ticket, (size_t)std::max(pl.npairs, PUB_PAIRS) * sizeof(int32_t)));   // zero at rest (kss_ctx.hpp)
+    KCHK(ensure_zeroed(c, c->pair_ticket, (size_t)2 * std::max(pl.npairs, PUB_PAIRS) * sizeof(int32_t)));   // zero at rest (kss_ctx.hpp); second half: the candidate-resident kernel's exit counts
     KCHK(ensure_pinned(c, c->h_sums, c->h_sums_cap, (size_t)pl.npairs * NSUMS * sizeof(double)));
     KCHK(ensure_pinned(c, c->h_state, c->h_state_cap, (size_t)pl.npairs * sizeof(PairState)));
     KCHK(ensure_pub(c, pl.npairs));
@@ -462,7 +462,7 @@ static int grid_setup_batch(kss_ctx* c, IcpPlan& pl) {
 // there is no separate completion flag and no write-acknowledge round trip between "sums stored" and "flag stored"
 // on the device.
 static int ensure_pub(kss_ctx* c, int npairs) {
-    const size_t want = (size_t)std::max(npairs, PUB_PAIRS) * NSUMS * 16;
+    const size_t want = (size_t)std::max(npairs, PUB_PAIRS) * (NSUMS + 1) * 16;   // (+1: the resident engines' exit flag of the pair, behind the launch's slots)
     if (c->h_seq && want <= c->h_seq_bytes) return KSS_OK;
     if (c->h_seq) {   // grow: nothing may still be writing the old slots
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1149,6 +1149,7 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
         ra.src0 = (const float4*)c->src0.p;
         ra.gate = gate;
         ra.pub = c->h_seq_dev;
+        ra.exit_flags = c->h_seq_dev + (size_t)2 * NSUMS * np;
         ra.max_passes = max_passes;
         number_launch();
         ra.seq0 = a.seq0; ra.stamp0 = a.stamp0;
@@ -1209,6 +1210,8 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
         ca.pair_ticket = (int32_t*)c->pair_ticket.p;
         ca.gate = gate;
         ca.pub = c->h_seq_dev;
+        ca.exit_flags = c->h_seq_dev + (size_t)2 * NSUMS * np;
+        ca.exit_ticket = (int32_t*)c->pair_ticket.p + std::max(np, PUB_PAIRS);
         number_launch();
         ca.seq0 = a.seq0; ca.stamp0 = a.stamp0;
         ca.gate_polls = gate_polls; ca.max_passes = max_passes;
@@ -1244,6 +1247,7 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
     const int judge = cand ? c->spec_judge : -1;
     const double judge_threshold = c->spec_threshold;
     std::atomic<long long> units{0};
+    std::atomic<int> query_said{0};
     const unsigned long long* h_seq = c->h_seq;
     // test hooks: the n-th record first arrives with a granule whose words do not fit its check word (what a torn 16-byte store
     // would look like), the right one 200 us later; the n-th answer is held back for 300 ms (a stalled host thread: with a small
@@ -1275,6 +1279,7 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
         for (int p = t; p < np; p += nt) ++remaining;
         long idle = 0, grace = 0;
         double s[NSUMS];
+        auto last_progress = std::chrono::steady_clock::now();
         long long my_units = 0;
         // (the calling thread stays until EVERY pair is done: it is the one that asks HIP whether the kernel is still there)
         while ((remaining > 0 || (t == 0 && pairs_left.load(std::memory_order_relaxed) > 0)) && !failed.load(std::memory_order_relaxed)) {
@@ -1332,13 +1337,30 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
                     h.phase = PH_DONE; --remaining; pairs_left.fetch_sub(1, std::memory_order_relaxed);
                 }
             }
-            if (progress) { idle = 0; grace = 0; continue; }
+            if (progress) { idle = 0; grace = 0; if (t == 0) last_progress = std::chrono::steady_clock::now(); continue; }
             __builtin_ia32_pause();
+            if ((idle & 255) == 255) std::this_thread::yield();   // (more spinning threads than cores: let the others run)
             if (++idle % 4096 == 0) {
                 // nothing for a while: has the kernel gone?  (Only the calling thread talks to HIP.)  A workgroup that was not
                 // answered within its bounded poll has left; its pair will never publish.  After the kernel has ended every
                 // result is in host memory already: a thread that still finds nothing for ~10 ms of polling gives up.
-                if (t == 0 && !kernel_done.load() && hipStreamQuery(c->stream) != hipErrorNotReady) kernel_done.store(1);
+                if (t == 0 && !kernel_done.load()) {
+                    // every pair's workgroups have stored their exit flag (no HIP call here: one can wait on locks that other
+                    // threads of the process hold for as long as THEIR kernels run -- and this thread has pairs to answer);
+                    // after two seconds of nothing, HIP is asked all the same: a faulted kernel sets no flags
+                    bool gone = true;
+                    const unsigned long long* fl = h_seq + (size_t)2 * NSUMS * np;
+                    for (int p = 0; p < np && gone; ++p) {
+                        const unsigned long long w0 = __atomic_load_n(&fl[2 * p], __ATOMIC_ACQUIRE), w1 = __atomic_load_n(&fl[2 * p + 1], __ATOMIC_RELAXED);
+                        gone = (unsigned)w0 == a.stamp0 && (unsigned)(w0 >> 32) == (unsigned)p && (unsigned)(w1 >> 32) == kss_mix3((unsigned)w0, (unsigned)(w0 >> 32), (unsigned)w1);
+                    }
+                    if (gone) kernel_done.store(1);
+                    else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - last_progress).count() > 2.0) {
+                        const hipError_t q = hipStreamQuery(c->stream);
+                        if (q != hipErrorNotReady) { query_said.store((int)q); kernel_done.store(1); }
+                        last_progress = std::chrono::steady_clock::now();
+                    }
+                }
                 if (kernel_done.load() && ++grace > 64) failed.store(1);
             }
         }
@@ -1350,9 +1372,10 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
         if (const char* e = getenv("KSS_HOST_THREADS")) { const int u = atoi(e); if (u >= 1 && u <= 64) v = u; }
         return v;
     }();
-    // (a candidate batch is a handful of pairs in lockstep, each pass a few microseconds: a thread per candidate, so that no
-    // answer queues behind another candidate's SVD; a large batch has pairs in every phase at any time: eight pairs a thread)
-    static const int cand_div = getenv("KSS_CAND_PAIRS_PER_THREAD") ? std::max(1, atoi(getenv("KSS_CAND_PAIRS_PER_THREAD"))) : 1;
+    // (eight pairs a thread: one, two, four and eight candidates per thread were measured alike on a registration's 15 -- an
+    // answer is a microsecond of host work -- and several registrations at once, kss_register_batch, must not bring more
+    // spinning threads than the machine has cores)
+    static const int cand_div = getenv("KSS_CAND_PAIRS_PER_THREAD") ? std::max(1, atoi(getenv("KSS_CAND_PAIRS_PER_THREAD"))) : 8;
     const int nthreads = std::max(1, std::min(res_threads, cand ? (np + cand_div - 1) / cand_div : (np + 7) / 8));
     c->pool.run_threads(nthreads, serve);
     if (failed.load()) {
@@ -1363,7 +1386,26 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
             if (H[p].phase != PH_DONE) send(p, nullptr, 0, 2, true);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (cand) { c->ws_dirty = true; KCHK(restore_zero_at_rest(c)); }
-        std::fprintf(stderr, "[kss] the pair-resident kernel left before every pair was finished (a stalled host thread?); running the launch-per-pass engine\n");
+        {
+            int unfinished = 0, k_min = 1 << 30, k_max = 0;
+            for (int p = 0; p < np; ++p)
+                if (H[p].phase != PH_DONE) { ++unfinished; k_min = std::min(k_min, H[p].k); k_max = std::max(k_max, H[p].k); }
+            std::fprintf(stderr, "[kss] the pair-resident kernel left before every pair was finished (a stalled host thread?); running the launch-per-pass engine"
+                                 " [%s, %d of %d pairs unfinished, waiting for passes %d..%d, %d host threads, stream query: %s]\n",
+                         cand ? "candidates" : "cell lists", unfinished, np, k_min, k_max, nthreads, hipGetErrorName((hipError_t)query_said.load()));
+            if (getenv("KSS_DEBUG_RES")) {   // what each unfinished pair was waiting for, and what is there
+                std::vector<int32_t> tk((size_t)np, -1);
+                if (cand) hipMemcpy(tk.data(), c->pair_ticket.p, (size_t)np * sizeof(int32_t), hipMemcpyDeviceToHost);
+                for (int p = 0; p < np; ++p) {
+                    if (H[p].phase == PH_DONE) continue;
+                    const unsigned long long want = a.seq0 + (unsigned long long)H[p].k;
+                    std::fprintf(stderr, "[kss]   pair %d: phase %d, waiting for the sums of pass %d (seq %llu), ticket %d; slots hold seq:", p, H[p].phase, H[p].k, want & 0xffffffffull, tk[p]);
+                    const unsigned long long* sl = h_seq + (size_t)2 * NSUMS * p;
+                    for (int k = 0; k < NSUMS; ++k) std::fprintf(stderr, " %llu", sl[2 * k + 1] & 0xffffffffull);
+                    std::fprintf(stderr, "\n");
+                }
+            }
+        }
         return KSS_OK;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));   // every workgroup has left (its last act was the publication just consumed)

@@ -137,6 +137,15 @@ constexpr int RES_LDS_MAX = 160 * 1024 - 256;   // dynamic LDS of a workgroup (t
 // gate stamps: every launch owns 4096; stamp0 + k opens pass k (k <= 4002), stamp0 + RES_STAMP_ANY is accepted at ANY pass --
 // the host's order to stop, which may overwrite a record some workgroups have not read yet
 constexpr unsigned RES_STAMP_ANY = 4095u;
+// "this pair's workgroups have all left": the host learns that a resident kernel is gone from these flags, not from HIP (a
+// HIP call of a serving thread can wait on locks other threads hold for as long as THEIR kernels run)
+__device__ __forceinline__ void res_store_exit_flag(unsigned long long* flags, int pair, unsigned stamp0) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 o;
+    o.x = stamp0; o.y = (unsigned)pair; o.z = 0u; o.w = kss_mix3(o.x, o.y, o.z);
+    unsigned long long* dst = flags + 2 * (int64_t)pair;
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(o) : "memory");
+}
 struct ResArgs {
     const GridPairDev* pairs;                   // per-pair table (cell grid, segments, rows)
     const int32_t* cell_start;                  // exclusive prefix of the cell counts (global positions in `sorted`)
@@ -151,6 +160,7 @@ struct ResArgs {
     int32_t gate_polls, max_passes, full_always;
     int32_t ntc, tabc;                          // LDS capacities of this launch: targets (multiple of 64), table entries (multiple of 8)
     int32_t* idx_out; float* d2_out;            // fitness pass: per-source correspondences (null: not wanted)
+    unsigned long long* exit_flags;             // host-mapped, one 16-byte granule per pair: {stamp0, pair, 0, check} stored when the pair's workgroup leaves
     unsigned long long* stamps;                 // diagnostics (null in production)
 };
 size_t resident_lds_bytes(int ntc, int tabc);
@@ -269,6 +279,8 @@ struct CandArgs {
     unsigned int stamp0;
     int32_t gate_polls, max_passes;
     int32_t* idx_out; float* d2_out;            // fitness pass: per-source correspondences (null: not wanted)
+    int32_t* exit_ticket;                       // zero at rest: a candidate's workgroups count themselves out ...
+    unsigned long long* exit_flags;             // ... and the last one stores {stamp0, pair, 0, check} into the candidate's host-mapped granule
     unsigned long long* stamps;                 // diagnostics (null in production): 16 per candidate, written by its workgroup 0
 };
 int cand_resident_capacity(bool fma, int nt_pad);   // workgroups the device keeps resident at once (0: cannot run)

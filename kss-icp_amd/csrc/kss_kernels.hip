@@ -655,6 +655,15 @@ __global__ __launch_bounds__(256) void cand_resident_kernel(const CandArgs a) {
 #define KSS_CSTAMP(k) do { if (stamping) a.stamps[(size_t)pair * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define KSS_CLAP(k) do { if (stamping) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); if (pass > 0) a.stamps[(size_t)pair * 16 + (k)] += now_ - t_last; t_last = now_; } } while (0)
     KSS_CSTAMP(0);
+    // leaving: the candidate's workgroups count themselves out; the last one tells the host (every exit is uniform over the workgroup)
+    auto leave = [&]() {
+        if (tid == 0) {
+            if (atomicAdd(&a.exit_ticket[pair], 1) == a.wpp - 1) {
+                __hip_atomic_store(&a.exit_ticket[pair], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                res_store_exit_flag(a.exit_flags, pair, a.stamp0);
+            }
+        }
+    };
     cand_stage(cand_tile, a.tgt, nt_pad, chunk);
     // tile j of this workgroup = tile wg + j * wpp of the candidate: 32 sources, eight lanes each
     float px[CAND_TPW], py[CAND_TPW], pz[CAND_TPW];
@@ -695,12 +704,12 @@ __global__ __launch_bounds__(256) void cand_resident_kernel(const CandArgs a) {
                 if (tid == 0) s_ctl[0] = ok ? 1 : 0;
             }
             __syncthreads();
-            if (!s_ctl[0]) { KSS_CSTAMP(15); return; }   // nobody answered: leave (the host's wait reports it)
+            if (!s_ctl[0]) { KSS_CSTAMP(15); leave(); return; }   // nobody answered: leave (the host's wait reports it)
 #pragma unroll
             for (int k = 0; k < 12; ++k) m[k] = __int_as_float(__builtin_amdgcn_readfirstlane(s_ps[k]));
             apply = __builtin_amdgcn_readfirstlane(s_ps[13]);
             mode = __builtin_amdgcn_readfirstlane(s_ps[14]);
-            if (mode >= 2) { KSS_CSTAMP(15); return; }
+            if (mode >= 2) { KSS_CSTAMP(15); leave(); return; }
         }
         KSS_CLAP(8);
         const bool fit = mode == 1;
@@ -769,6 +778,7 @@ __global__ __launch_bounds__(256) void cand_resident_kernel(const CandArgs a) {
         if (fit) break;
     }
     KSS_CSTAMP(15);
+    leave();
 #undef KSS_CSTAMP
 #undef KSS_CLAP
 }

@@ -374,12 +374,12 @@ __global__ __launch_bounds__(RES_THREADS, 1) void resident_icp_kernel(const ResA
                 if (tid == 0) s_ctl[1] = ok ? 1 : 0;
             }
             __syncthreads();
-            if (!s_ctl[1]) return;         // nobody answered: leave (the host's wait reports it)
+            if (!s_ctl[1]) { if (tid == 0) res_store_exit_flag(a.exit_flags, pi, a.stamp0); return; }   // nobody answered: leave (the host's wait reports it)
 #pragma unroll
             for (int k = 0; k < 12; ++k) m[k] = __int_as_float(__builtin_amdgcn_readfirstlane(s_ps[k]));   // (uniform: scalar registers)
             apply = __builtin_amdgcn_readfirstlane(s_ps[13]);
             mode = __builtin_amdgcn_readfirstlane(s_ps[14]);
-            if (mode >= 2) return;
+            if (mode >= 2) { if (tid == 0) res_store_exit_flag(a.exit_flags, pi, a.stamp0); return; }
         }
         KSS_RLAP(pass > 0 ? 8 : 6);
         const bool fit = mode == 1;
@@ -647,9 +647,10 @@ __global__ __launch_bounds__(RES_THREADS, 1) void resident_icp_kernel(const ResA
             asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(o) : "memory");
         }
         KSS_RLAP(pass > 0 ? 12 : 6);
-        if (fit) { KSS_RSTAMP(15); return; }   // the fitness pass is the last one
+        if (fit) { KSS_RSTAMP(15); break; }    // the fitness pass is the last one
         __syncthreads();                   // (rowv and the queue are rewritten by the next pass)
     }
+    if (tid == 0) res_store_exit_flag(a.exit_flags, pi, a.stamp0);
 #undef KSS_RSTAMP
 #undef KSS_RLAP
 }

@@ -96,3 +96,35 @@ def test_many_registrations_in_a_row_leave_nothing_behind(ctx, pkg):
         for k in ("R", "t", "T_icp", "pointAlign"):
             assert np.array_equal(np.asarray(r[k]), np.asarray(f[k])), k
         assert r["icp_iterations"] == f["icp_iterations"] and r["E_d_init"] == f["E_d_init"] and r["final_fitness"] == f["final_fitness"]
+
+
+def test_many_workers_never_stall_each_other():
+    """kss_register_batch with more workers than the device can keep resident launches for: every launch reserves its
+    workgroups out of the device's capacity (the rest take more tiles per workgroup or the launch-per-pass form), no serving
+    thread calls HIP while it has pairs to answer, and a kernel that is gone is recognised by its exit flags.  Round 3 saw a
+    registration in ~200 lose a second to a workgroup nobody answered before that: the message must not appear, and the
+    records must equal the one-worker run."""
+    code = r"""
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as g
+pkg = g.load_package(); S = pkg.synth; ctx = pkg.Context(0)
+npairs, n = 48, 6000
+cl = []
+for i in range(npairs):
+    s, t = S.make_pair(400 + i, n, R=S.rot_axis_angle([0.3, 0.1 + 0.01 * i, 1.0], np.deg2rad(5.0 + 5.0 * (i %% 30))), scale=1.0 + 0.02 * (i %% 7), shape="bumpy")
+    cl.append((s.astype(np.float64), t.astype(np.float64)))
+src_all = np.concatenate([c[0] for c in cl]); tgt_all = np.concatenate([c[1] for c in cl])
+off = np.arange(npairs + 1, dtype=np.int64) * n
+out = []
+for w in (1, 8, 16, 8, 16, 12, 16):
+    r = ctx.register_batch(src_all, off, tgt_all, off, workers=w)
+    out.append([[list(x.R), list(x.t), x.icp_iterations, x.angle_index, x.final_fitness] for x in r])
+print("RESULT" + json.dumps(out))
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "left before every pair" not in r.stderr, r.stderr
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT")][0][6:])
+    for k in range(1, len(res)):
+        assert res[k] == res[0], k

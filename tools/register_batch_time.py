@@ -15,7 +15,7 @@ src_all = np.concatenate([c[0] for c in cl]); tgt_all = np.concatenate([c[1] for
 off = np.arange(npairs + 1, dtype=np.int64) * n
 ctx.register_batch(src_all[:2 * n], off[:3], tgt_all[:2 * n], off[:3])
 base = None
-for w in (1, 2, 4, 8, 16):
+for w in [int(x) for x in sys.argv[1:]] or (1, 2, 4, 8, 16):
     t0 = time.perf_counter(); r = ctx.register_batch(src_all, off, tgt_all, off, workers=w); dt = time.perf_counter() - t0
     base = base or dt
     print("%2d workers: %d registrations of %dx%d in %.1f ms = %.0f registrations/s (x%.2f), mean fitness %.2e" %
