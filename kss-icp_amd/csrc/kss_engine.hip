@@ -1339,7 +1339,7 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
             }
             if (progress) { idle = 0; grace = 0; if (t == 0) last_progress = std::chrono::steady_clock::now(); continue; }
             __builtin_ia32_pause();
-            if ((idle & 255) == 255) std::this_thread::yield();   // (more spinning threads than cores: let the others run)
+            if (idle > 16384 && (idle & 1023) == 1023) std::this_thread::yield();   // (nothing for ~a millisecond and maybe more spinning threads than cores: let the others run; sooner, the call costs a large batch's answers their latency: C3 7.5 -> 8.2 ms)
             if (++idle % 4096 == 0) {
                 // nothing for a while: has the kernel gone?  (Only the calling thread talks to HIP.)  A workgroup that was not
                 // answered within its bounded poll has left; its pair will never publish.  After the kernel has ended every

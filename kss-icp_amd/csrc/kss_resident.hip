@@ -647,7 +647,7 @@ __global__ __launch_bounds__(RES_THREADS, 1) void resident_icp_kernel(const ResA
             asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(o) : "memory");
         }
         KSS_RLAP(pass > 0 ? 12 : 6);
-        if (fit) { KSS_RSTAMP(15); break; }    // the fitness pass is the last one
+        if (fit) { KSS_RSTAMP(15); if (tid == 0) res_store_exit_flag(a.exit_flags, pi, a.stamp0); return; }   // the fitness pass is the last one
         __syncthreads();                   // (rowv and the queue are rewritten by the next pass)
     }
     if (tid == 0) res_store_exit_flag(a.exit_flags, pi, a.stamp0);
