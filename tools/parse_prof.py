@@ -15,7 +15,7 @@ import os
 import sys
 from collections import defaultdict
 
-OURS = ("nn_", "corr_", "finalize", "pack_", "preshape", "rot_", "pose_", "transform", "grid_", "gridb_", "cell_", "row_", "sum_", "fps_", "resident_")
+OURS = ("nn_", "corr_", "finalize", "pack_", "preshape", "rot_", "pose_", "transform", "grid_", "gridb_", "cell_", "row_", "sum_", "fps_", "resident_", "cand_", "aivs_")
 
 
 def short(name):
@@ -87,7 +87,7 @@ def main():
     if sq:
         lines += ["", "## SQ counters (separate pass), per launch averages", ""]
         for k in sorted(sq):
-            if not k.startswith(("nn_", "corr_", "grid_", "gridb_", "cell_", "resident_")):
+            if not k.startswith(("nn_", "corr_", "grid_", "gridb_", "cell_", "resident_", "cand_")):
                 continue
             lines.append("`%s`:" % k)
             for c, v in sorted(sq[k].items()):
