@@ -170,18 +170,179 @@ __device__ __forceinline__ int aivs_neighbor_boxes(const AivsGrid& g, int boxInd
     return m;
 }
 
-// ---- one colour of AIVS_Voroni_OpenMP_KNN: one wave per box ------------------------------------------------------
-__global__ __launch_bounds__(64) void aivs_fps_kernel(const double* __restrict__ P, AivsGrid g, int ox, int oy, int oz,
-                                                      const int32_t* __restrict__ start, const int32_t* __restrict__ members,
-                                                      const int32_t* __restrict__ center_pos, const int32_t* __restrict__ sim_num,
-                                                      uint8_t* __restrict__ labelG, double* __restrict__ mind,
-                                                      int32_t* __restrict__ simiT, int32_t* __restrict__ n_samples) {
-    // blockIdx -> the box (i, j, k) of this colour class: i = 2*bx + ox (1-based, ox in {1, 2}) etc.
-    const int hx = (g.nx - ox) / 2 + 1, hy = (g.ny - oy) / 2 + 1;
-    const int bi = blockIdx.x % hx, bj = (blockIdx.x / hx) % hy, bk = blockIdx.x / (hx * hy);
-    const int i = 2 * bi + ox, j = 2 * bj + oy, k = 2 * bk + oz;
-    if (i > g.nx || j > g.ny || k > g.nz) return;
-    const int b = i + g.nx * (j - 1) + g.nx * g.ny * (k - 1);
+
+// ---- the fast form of one box's farthest-point sampling: one wave, own points in registers (four per lane), the sampled
+// neighbours' coordinates in LDS.  Same float arithmetic and the same "first maximum in scan order" rule as the general
+// path below.  The 26 neighbour boxes are scanned as ONE flattened list (their member ranges are fetched at once: three
+// dependent memory round trips instead of 26 x 3).  Returns false -- having written nothing -- when more than `cap`
+// neighbour samples are in reach; the caller then takes the general path.
+__device__ __forceinline__ int aivs_dpp_xor(int v, int d) {   // lane ^ d for d = 8, 4, 2, 1 (inside a row of 16 lanes)
+    if (d == 8) return __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, false);
+    if (d == 4) { const int r = __builtin_amdgcn_mov_dpp(v, 0x104, 0xf, 0x5, false); return __builtin_amdgcn_update_dpp(r, v, 0x114, 0xf, 0xa, false); }
+    if (d == 2) return __builtin_amdgcn_mov_dpp(v, 0x4e, 0xf, 0xf, false);
+    return __builtin_amdgcn_mov_dpp(v, 0xb1, 0xf, 0xf, false);
+}
+__device__ __forceinline__ bool aivs_fps_fast(const double* __restrict__ P, const AivsGrid& g, int b, int lo, int m, int simNum, const double (&pc)[3], double R,
+                                              const int (&nbr)[26], int nn, const int32_t* __restrict__ start, const int32_t* __restrict__ members,
+                                              const int32_t* __restrict__ center_pos, uint8_t* __restrict__ labelG, int32_t* __restrict__ simiT,
+                                              int32_t* __restrict__ n_samples, float* l2x, float* l2y, float* l2z, int32_t* seg, int cap) {
+    const int lane = threadIdx.x;
+    // own points (their loads are in flight while the neighbours are scanned): slot s of a lane is point k2 = lane + 64 s (ascending k2 per lane, as the serial scan)
+    int me[4];
+    float fx[4], fy[4], fz[4], md[4];
+    bool live[4];                         // label 1: an own point not sampled yet
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int k2 = lane + 64 * s;
+        me[s] = -1; fx[s] = fy[s] = fz[s] = 0.f; md[s] = 0.f; live[s] = false;
+        if (k2 < m) {
+            me[s] = members[lo + k2];
+            fx[s] = (float)P[3 * (int64_t)me[s]]; fy[s] = (float)P[3 * (int64_t)me[s] + 1]; fz[s] = (float)P[3 * (int64_t)me[s] + 2];
+            live[s] = true;
+        }
+    }
+    // the neighbours' member ranges, all at once: lane q holds box q's range; seg[q] = first flattened index of box q
+    int s0 = 0, cnt = 0;
+    if (lane < nn) { s0 = start[nbr[lane]]; cnt = start[nbr[lane] + 1] - s0; }
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane < nn) seg[lane] = incl - cnt;
+    const int total = __shfl(incl, 31, 64);
+    if (lane == 0) seg[27] = 0;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    int n_l2 = 0;
+    for (int f0 = 0; f0 < total; f0 += 64) {
+        const int f = f0 + lane;
+        bool hit = false;
+        float hx = 0.f, hy = 0.f, hz = 0.f;
+        // the box whose range holds flattened index f (ranges in box order; the search lands behind empty boxes); the shuffle
+        // runs with every lane active: a permute reads nothing from a lane that is masked off
+        int q = 0;
+        {
+            const int fc = f < total ? f : 0;
+#pragma unroll
+            for (int step = 16; step > 0; step >>= 1)
+                if (q + step < nn && seg[q + step] <= fc) q += step;
+        }
+        const int bs = __shfl(s0, q, 64);
+        if (f < total) {
+            const int pi = members[bs + (f - seg[q])];
+            const double x = P[3 * (int64_t)pi], y = P[3 * (int64_t)pi + 1], z = P[3 * (int64_t)pi + 2];
+            hit = x <= pc[0] + R && x >= pc[0] - R && y <= pc[1] + R && y >= pc[1] - R && z <= pc[2] + R && z >= pc[2] - R && labelG[pi] == 0;
+            hx = (float)x; hy = (float)y; hz = (float)z;
+        }
+        const unsigned long long mask = __ballot(hit);
+        if (hit) {
+            const int slot = n_l2 + __popcll(mask & ((1ull << lane) - 1ull));
+            if (slot < cap) { l2x[slot] = hx; l2y[slot] = hy; l2z[slot] = hz; }
+        }
+        n_l2 += __popcll(mask);
+    }
+    if (n_l2 > cap) return false;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    const bool any_l2 = n_l2 > 0;
+    const int cpos = center_pos[b];
+    const int seed_pos = (!any_l2 && cpos >= 0 && cpos < m) ? cpos : -1;   // addJ: seed the box centre only if no neighbour sample
+    auto dist = [](float ax, float ay, float az, float bx, float by, float bz) {
+        const float dx = ax - bx, dy = ay - by, dz = az - bz;
+        return sqrtf((dx * dx + dy * dy) + dz * dz);
+    };
+    // the seed's coordinates (uniform): lane seed_pos & 63, slot seed_pos >> 6
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    int seed_pt = -1;
+    if (seed_pos >= 0) {
+        const int sl = seed_pos & 63, ss = seed_pos >> 6;
+        const float cx = ss == 0 ? fx[0] : ss == 1 ? fx[1] : ss == 2 ? fx[2] : fx[3];
+        const float cy = ss == 0 ? fy[0] : ss == 1 ? fy[1] : ss == 2 ? fy[2] : fy[3];
+        const float cz = ss == 0 ? fz[0] : ss == 1 ? fz[1] : ss == 2 ? fz[2] : fz[3];
+        const int cm = ss == 0 ? me[0] : ss == 1 ? me[1] : ss == 2 ? me[2] : me[3];
+        sx = __shfl(cx, sl, 64); sy = __shfl(cy, sl, 64); sz = __shfl(cz, sl, 64); seed_pt = __shfl(cm, sl, 64);
+    }
+    // initial min-distance of every own point to the seed / the sampled neighbours (9999 with neither)
+    // (one LDS read of a neighbour per FOUR evaluations; a minimum does not depend on the order of its arguments)
+    {
+        float best[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) best[s] = seed_pt >= 0 ? dist(fx[s], fy[s], fz[s], sx, sy, sz) : __builtin_inff();
+#pragma unroll 4
+        for (int l = 0; l < n_l2; ++l) {
+            const float qx = l2x[l], qy = l2y[l], qz = l2z[l];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float d = dist(fx[s], fy[s], fz[s], qx, qy, qz);
+                if (d < best[s]) best[s] = d;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k2 = lane + 64 * s;
+            if (k2 >= m) continue;
+            md[s] = k2 == seed_pos ? 0.f : (best[s] == __builtin_inff() ? 9999.0f : best[s]);
+        }
+    }
+    int sample_index = 0;
+    if (seed_pos >= 0) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (lane + 64 * s == seed_pos) { simiT[lo] = seed_pt; labelG[seed_pt] = 0; live[s] = false; }
+        sample_index = 1;
+    }
+    // farthest-point loop: first maximum of the min-distances over the still-unsampled own points (serial scan order)
+    while (sample_index < simNum) {
+        float bv = 0.f;
+        int bk2 = 0x7fffffff;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (live[s] && md[s] > bv) { bv = md[s]; bk2 = lane + 64 * s; }   // ascending k2 per lane: first maximum kept
+#pragma unroll
+        for (int off = 32; off >= 16; off >>= 1) {
+            const float ov = __shfl_xor(bv, off, 64);
+            const int ok = __shfl_xor(bk2, off, 64);
+            if (ov > bv || (ov == bv && ok < bk2)) { bv = ov; bk2 = ok; }
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            const float ov = __int_as_float(aivs_dpp_xor(__float_as_int(bv), off));
+            const int ok = aivs_dpp_xor(bk2, off);
+            if (ov > bv || (ov == bv && ok < bk2)) { bv = ov; bk2 = ok; }
+        }
+        bk2 = __builtin_amdgcn_readfirstlane(bk2);
+        if (bk2 == 0x7fffffff) break;   // nothing left (indexSelect == -1)
+        const int sl = bk2 & 63, ss = bk2 >> 6;
+        const float cx = ss == 0 ? fx[0] : ss == 1 ? fx[1] : ss == 2 ? fx[2] : fx[3];
+        const float cy = ss == 0 ? fy[0] : ss == 1 ? fy[1] : ss == 2 ? fy[2] : fy[3];
+        const float cz = ss == 0 ? fz[0] : ss == 1 ? fz[1] : ss == 2 ? fz[2] : fz[3];
+        const int cm = ss == 0 ? me[0] : ss == 1 ? me[1] : ss == 2 ? me[2] : me[3];
+        const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cx), sl)), qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cy), sl)),
+                    qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cz), sl));
+        const int sel = __builtin_amdgcn_readlane(cm, sl);
+        if (lane == 0) { labelG[sel] = 0; simiT[lo + sample_index] = sel; }
+        ++sample_index;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k2 = lane + 64 * s;
+            if (k2 == bk2) { md[s] = 0.f; live[s] = false; }
+            else if (live[s]) {
+                const float d = dist(fx[s], fy[s], fz[s], qx, qy, qz);
+                if (d < md[s]) md[s] = d;
+            }
+        }
+    }
+    if (lane == 0) n_samples[b] = sample_index;
+    return true;
+}
+
+// ---- AIVS_Voroni_OpenMP_KNN for one box: one wave ---------------------------------------------------------------------
+__device__ __forceinline__ void aivs_fps_box(const double* __restrict__ P, const AivsGrid& g, int b, const int32_t* __restrict__ start,
+                                             const int32_t* __restrict__ members, const int32_t* __restrict__ center_pos,
+                                             const int32_t* __restrict__ sim_num, uint8_t* __restrict__ labelG, double* __restrict__ mind,
+                                             int32_t* __restrict__ simiT, int32_t* __restrict__ n_samples) {
     const int lo = start[b], m = start[b + 1] - lo;
     const int simNum = sim_num[b];
     if (m == 0 || simNum == 0) return;
@@ -197,6 +358,12 @@ __global__ __launch_bounds__(64) void aivs_fps_kernel(const double* __restrict__
     // order is irrelevant (only a minimum over them is taken).  More than L2_CAP hits fall back to re-scanning.
     constexpr int L2_CAP = 512;
     __shared__ int32_t l2[L2_CAP];
+    // The usual box -- up to 256 own points, up to L2_CAP sampled neighbours in reach -- runs entirely out of registers and
+    // LDS (aivs_fps_fast below: same arithmetic, same selection order); anything larger takes the general path after it.
+    __shared__ float l2x[L2_CAP], l2y[L2_CAP], l2z[L2_CAP];
+    __shared__ int32_t seg[28];
+    if (m <= 4 * 64 && aivs_fps_fast(P, g, b, lo, m, simNum, pc, R, nbr, nn, start, members, center_pos, labelG, simiT, n_samples, l2x, l2y, l2z, seg, L2_CAP))
+        return;
     int n_l2 = 0;
     for (int q = 0; q < nn; ++q) {
         const int s0 = start[nbr[q]], s1 = start[nbr[q] + 1];
@@ -291,6 +458,22 @@ __global__ __launch_bounds__(64) void aivs_fps_kernel(const double* __restrict__
     if (lane == 0) n_samples[b] = sample_index;
 }
 
+// one colour per launch.  (All eight colours in ONE launch -- a box waiting on per-box flags for its neighbours of earlier
+// colours -- was built in round 3 and removed: 243 us against 8 x 21, and 4.7 against 3.0 ms at 100k points: the waiting waves
+// hold the slots the boxes they wait for need, and spin on the L2.)
+__global__ __launch_bounds__(64) void aivs_fps_kernel(const double* __restrict__ P, AivsGrid g, int ox, int oy, int oz,
+                                                      const int32_t* __restrict__ start, const int32_t* __restrict__ members,
+                                                      const int32_t* __restrict__ center_pos, const int32_t* __restrict__ sim_num,
+                                                      uint8_t* __restrict__ labelG, double* __restrict__ mind,
+                                                      int32_t* __restrict__ simiT, int32_t* __restrict__ n_samples) {
+    // blockIdx -> the box (i, j, k) of this colour class: i = 2*bx + ox (1-based, ox in {1, 2}) etc.
+    const int hx = (g.nx - ox) / 2 + 1, hy = (g.ny - oy) / 2 + 1;
+    const int bi = blockIdx.x % hx, bj = (blockIdx.x / hx) % hy, bk = blockIdx.x / (hx * hy);
+    const int i = 2 * bi + ox, j = 2 * bj + oy, k = 2 * bk + oz;
+    if (i > g.nx || j > g.ny || k > g.nz) return;
+    aivs_fps_box(P, g, i + g.nx * (j - 1) + g.nx * g.ny * (k - 1), start, members, center_pos, sim_num, labelG, mind, simiT, n_samples);
+}
+
 // ---- accurate cut: K = 3 self-kNN among the samples (brute force; ties -> lower index) -----------------------------
 __device__ __forceinline__ void top3_insert(float d, int j, float (&bd)[3], int (&bi)[3]) {
     // ascending by (distance, index): equal distances keep the lower index first
@@ -324,6 +507,65 @@ __global__ __launch_bounds__(64) void aivs_knn3_kernel(const double* __restrict_
         for (int l = 0; l < 64; ++l)
             for (int k = 0; k < 3; ++k)
                 if (si[l][k] != 0x7fffffff) top3_insert(sd[l][k], si[l][k], md, mi);
+        nn1[i] = mi[1];
+        d1[i] = sqrtf(md[1]);
+        d2[i] = sqrtf(md[2]);
+    }
+}
+
+// The same from a packed copy of the samples' float coordinates (aivs_sample_coords_kernel): a step of the walk is three
+// coalesced loads that depend on nothing, four steps in flight -- the kernel above goes through samples[j] and then P[]: two
+// dependent round trips per step, 1.5 us each -- and the 64 x 3 candidates of a wave are merged by three rounds of a
+// wave-wide minimum on (distance, index) instead of one lane inserting 192 entries.  The three nearest under a strict total
+// order do not depend on the order of evaluation: same results.
+__global__ __launch_bounds__(256) void aivs_sample_coords_kernel(const double* __restrict__ P, const int32_t* __restrict__ samples, int ns, float* __restrict__ co) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ns) return;
+    const int pj = samples[j];
+    co[j] = (float)P[3 * (int64_t)pj]; co[ns + j] = (float)P[3 * (int64_t)pj + 1]; co[2 * ns + j] = (float)P[3 * (int64_t)pj + 2];
+}
+__global__ __launch_bounds__(256) void aivs_knn3_packed_kernel(const float* __restrict__ co, int ns, int32_t* __restrict__ nn1, float* __restrict__ d1, float* __restrict__ d2) {
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= ns) return;   // uniform per wave
+    const float* __restrict__ sx = co;
+    const float* __restrict__ sy = co + ns;
+    const float* __restrict__ sz = co + 2 * ns;
+    const float ax = sx[i], ay = sy[i], az = sz[i];
+    float bd[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    int bi[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+    for (int j0 = lane; j0 < ns; j0 += 256) {
+        float x[4], y[4], z[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = min(j0 + 64 * u, ns - 1);
+            x[u] = sx[j]; y[u] = sy[j]; z[u] = sz[j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 64 * u;
+            if (j < ns) {
+                const float dx = ax - x[u], dy = ay - y[u], dz = az - z[u];
+                top3_insert((dx * dx + dy * dy) + dz * dz, j, bd, bi);
+            }
+        }
+    }
+    // three rounds: the smallest head of the 64 sorted lists, popped from the list it came from
+    float md[3];
+    int mi[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float v = bd[0];
+        int k = bi[0];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(v, off, 64);
+            const int ok = __shfl_xor(k, off, 64);
+            if (ov < v || (ov == v && ok < k)) { v = ov; k = ok; }
+        }
+        md[r] = v; mi[r] = k;
+        if (bi[0] == k && k != 0x7fffffff) { bd[0] = bd[1]; bi[0] = bi[1]; bd[1] = bd[2]; bi[1] = bi[2]; bd[2] = __builtin_inff(); bi[2] = 0x7fffffff; }
+    }
+    if (lane == 0) {
         nn1[i] = mi[1];
         d1[i] = sqrtf(md[1]);
         d2[i] = sqrtf(md[2]);
@@ -378,7 +620,7 @@ int aivs_device(hipStream_t st, const double* d_xyz, int n, int point_num, std::
             *d_nn1 = nullptr, *d_bad = nullptr;
     uint8_t* d_label = nullptr;
     double* d_mind = nullptr;
-    float *d_d1 = nullptr, *d_d2 = nullptr;
+    float *d_d1 = nullptr, *d_d2 = nullptr, *d_sco = nullptr;
     std::vector<double> hb(64 * 6);
     std::vector<int32_t> samples;
     AivsGrid g;
@@ -429,12 +671,12 @@ int aivs_device(hipStream_t st, const double* d_xyz, int n, int point_num, std::
     }
     {
         const size_t N = (size_t)n, B = (size_t)nb1 + 2;
-        const size_t total = 8 * 256 + (N * 4) * 5 + (B * 4) * 7 + N + N * 8 + 256 /*bad*/ + (N * 4) * 2 /*samples, nn1*/ + (N * 4) * 2 /*d1, d2*/;
+        const size_t total = 32 * 256 /* every region is rounded up to 256 bytes */ + (N * 4) * 5 + (B * 4) * 7 + N + N * 8 + 256 /*bad*/ + (N * 4) * 2 /*samples, nn1*/ + (N * 4) * 2 /*d1, d2*/ + N * 12 /*sample coordinates*/;
         pool = (char*)scratch(total);   // the earlier small region is dead: its contents were copied to the host already
         pool_off = 0;
         if (!pool) { err = "aivs: out of device memory"; rc = KSS_ERR_NOMEM; goto done; }
         d_box_of = (int32_t*)carve(N * 4); d_tmp = (int32_t*)carve(N * 4); d_members = (int32_t*)carve(N * 4);
-        d_simiT = (int32_t*)carve(N * 4); d_samples = (int32_t*)carve(N * 4);
+        d_simiT = (int32_t*)carve(N * 4); d_samples = (int32_t*)carve(N * 4); d_sco = (float*)carve(N * 12);
         d_counts = (int32_t*)carve(B * 4); d_start = (int32_t*)carve(B * 4); d_cursor = (int32_t*)carve(B * 4);
         d_center = (int32_t*)carve(B * 4); d_sim = (int32_t*)carve(B * 4); d_nsamp = (int32_t*)carve(B * 4); d_soff = (int32_t*)carve(B * 4);
         d_label = (uint8_t*)carve(N); d_mind = (double*)carve(N * 8); d_bad = (int32_t*)carve(256);
@@ -479,7 +721,8 @@ int aivs_device(hipStream_t st, const double* d_xyz, int n, int point_num, std::
         int64_t dTiff = (int64_t)ns - point_num;
         if (dTiff > 0 && ns >= 3) {
             // AIVS_AccurateCut_Optimization :848-957: greedy removal of one end of the closest live pair (host: O(dTiff * ns))
-            hipLaunchKernelGGL(aivs_knn3_kernel, dim3(ns), dim3(64), 0, st, d_xyz, d_samples, ns, d_nn1, d_d1, d_d2);
+            hipLaunchKernelGGL(aivs_sample_coords_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, d_xyz, d_samples, ns, d_sco);
+            hipLaunchKernelGGL(aivs_knn3_packed_kernel, dim3((ns + 3) / 4), dim3(256), 0, st, (const float*)d_sco, ns, d_nn1, d_d1, d_d2);
             std::vector<int32_t> nn1((size_t)ns);
             std::vector<float> d1((size_t)ns), d2((size_t)ns);
             AIVS_HIP(hipMemcpyAsync(nn1.data(), d_nn1, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost, st));
