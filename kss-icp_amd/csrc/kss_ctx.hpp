@@ -94,6 +94,9 @@ struct kss_ctx {
     // fitness is known and does not exceed spec_threshold the candidates are told to stop (their results are not used).
     // spec_ran: the batch ran that way (otherwise the caller takes the sequential route); spec_cancelled: candidates were stopped
     int spec_judge = -1; double spec_threshold = 0.0; bool spec_ran = false, spec_cancelled = false;
+    // a resident launch that had to be given up (a workgroup nobody answered in time: another process on the GPU, a starved host)
+    // keeps its engine off for this context for a while: the next calls go straight to the launch-per-pass form
+    std::chrono::steady_clock::time_point res_backoff[2] = {};
     unsigned long long seq = 0;
     void* h_state = nullptr; size_t h_state_cap = 0;
 

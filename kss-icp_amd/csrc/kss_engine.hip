@@ -1114,6 +1114,7 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
     static const bool want_cand = getenv("KSS_CAND_RESIDENT") == nullptr || atoi(getenv("KSS_CAND_RESIDENT")) != 0;
     if (!(cand ? want_cand : want) || P.allreduce || P.max_iterations < 1 || P.max_iterations > 4000) return KSS_OK;
     if (cand ? (pl.grid || pl.gridb || !pl.shared_target || pl.src_in_cell_order || pl.g[0].tgt_pad > 8192) : !pl.gridb) return KSS_OK;
+    if (std::chrono::steady_clock::now() < c->res_backoff[cand ? 1 : 0]) return KSS_OK;   // given up recently: see below
     const int np = pl.npairs;
     // what the serving loop needs to know about the launch, whichever kernel it is
     struct { unsigned long long seq0 = 0; unsigned stamp0 = 0; int32_t* idx_out = nullptr; float* d2_out = nullptr; unsigned long long* stamps = nullptr; } a;
@@ -1386,11 +1387,14 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
             if (H[p].phase != PH_DONE) send(p, nullptr, 0, 2, true);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (cand) { c->ws_dirty = true; KCHK(restore_zero_at_rest(c)); }
+        static const int backoff_s = getenv("KSS_RES_BACKOFF_S") ? atoi(getenv("KSS_RES_BACKOFF_S")) : 30;
+        c->res_backoff[cand ? 1 : 0] = std::chrono::steady_clock::now() + std::chrono::seconds(backoff_s);   // not again for a while: each failure costs the polls' bound (~1 s)
         {
             int unfinished = 0, k_min = 1 << 30, k_max = 0;
             for (int p = 0; p < np; ++p)
                 if (H[p].phase != PH_DONE) { ++unfinished; k_min = std::min(k_min, H[p].k); k_max = std::max(k_max, H[p].k); }
             std::fprintf(stderr, "[kss] the pair-resident kernel left before every pair was finished (a stalled host thread?); running the launch-per-pass engine"
+                                 " (and for the next 30 s on this context)"
                                  " [%s, %d of %d pairs unfinished, waiting for passes %d..%d, %d host threads, stream query: %s]\n",
                          cand ? "candidates" : "cell lists", unfinished, np, k_min, k_max, nthreads, hipGetErrorName((hipError_t)query_said.load()));
             if (getenv("KSS_DEBUG_RES")) {   // what each unfinished pair was waiting for, and what is there
