@@ -710,10 +710,14 @@ static PassArgs pass_args(kss_ctx* c, const IcpPlan& pl, const float4* d_in, flo
         a.row_pair = (const int32_t*)c->g_rowpair.p;
     } else {
         a.pair0 = pl.gpairs[0];
-        // rows as tagged granules + a designated reducer instead of drain + ticket: only when every workgroup is resident at
-        // once (one per CU), so the reducer never polls for a workgroup that cannot start.  KSS_TAGGED_ROWS=0: A/B switch.
+        // rows as tagged granules + a designated reducer instead of drain + ticket.  Only the reducer waits -- for rows of
+        // workgroups that nothing keeps from starting (it holds one slot of the chip) -- so the form does not need the launch
+        // to be resident at once; the CHAIN built on it does (below).  At 1954 rows it takes the store-acknowledge wait and the
+        // ticket round trip (2 of 9 us) off every workgroup's life and most of the last workgroup's 1954-row total off the
+        // tail.  KSS_TAGGED_ROWS=0: A/B switch; KSS_TAGGED_ROWS_MAX: rows up to which the form is used (default: any).
         static const bool tagged = getenv("KSS_TAGGED_ROWS") == nullptr || atoi(getenv("KSS_TAGGED_ROWS")) != 0;
-        a.tagged_rows = tagged && pl.total_rows <= resident_rows_limit(c) ? 1 : 0;
+        static const int tagged_max = getenv("KSS_TAGGED_ROWS_MAX") ? atoi(getenv("KSS_TAGGED_ROWS_MAX")) : (1 << 30);
+        a.tagged_rows = tagged && pl.total_rows <= std::max(tagged_max, resident_rows_limit(c)) ? 1 : 0;
     }
     return a;
 }
@@ -781,7 +785,8 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
         // chain is bracketed as a whole instead.
         static const bool want_chain = getenv("KSS_CHAIN") == nullptr || atoi(getenv("KSS_CHAIN")) != 0;
         int len = 1;
-        if (G.want_next && !G.pending && plain_args && gated_available(c) && want_chain && c->gate_bar && (a.tagged_rows || pl.total_rows == 1))
+        if (G.want_next && !G.pending && plain_args && gated_available(c) && want_chain && c->gate_bar &&
+            ((a.tagged_rows && pl.total_rows <= resident_rows_limit(c)) || pl.total_rows == 1))   // (every workgroup of a chain waits at its gates: resident at once)
             len = std::max(1, std::min(G.max_steps, 1 << 16));
         if (G.want_next && !G.pending && plain_args && gated_available(c) && (len > 1 || !next_sampled)) {
             if (c->prof > 1 && len == 1) ++c->prof_tick[KSS_K_GRID_NN];

@@ -545,6 +545,33 @@ print("RESULT" + json.dumps(out))
     assert res["lost"] == res["default"] and res["lost_late"] == res["default"]
 
 
+def test_large_pair_rows_tagged_or_ticketed_same_bits(pkg):
+    """Pairs with more rows than compute units (300k points: 586 rows) hand their rows over as tagged granules to a polling
+    reducer since round 3 (before: store + ticket, the last workgroup adds 586 rows); the two forms, gated or not, must give
+    the same registration bit for bit -- the additions are the same in the same order."""
+    import subprocess, sys, json
+    code = r"""
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as g
+pkg = g.load_package(); S = pkg.synth; ctx = pkg.Context(0)
+src, tgt = S.make_pair(93, 300000, R=S.rot_axis_angle([0.2, 0.1, 1.0], np.deg2rad(6.0)), t=(0.01, 0.0, -0.01), shape="bumpy")
+out = []
+for kw in (dict(max_iterations=7, fixed_iterations=1), dict()):
+    r = ctx.icp(src, tgt, ctx.icp_params(nn_mode=pkg.NN_GRID, **kw))
+    out.append([r["T"].tolist(), r["iterations"], r["fitness"], r["last_mse"]])
+print("RESULT" + json.dumps(out))
+""" % ROOT
+    res = {}
+    for name, extra in {"default": {}, "ticket": {"KSS_TAGGED_ROWS_MAX": "256"}, "ticket_all": {"KSS_TAGGED_ROWS": "0"},
+                        "ungated": {"KSS_GATED": "0"}, "ungated_ticket": {"KSS_GATED": "0", "KSS_TAGGED_ROWS_MAX": "256"}}.items():
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, **extra))
+        assert r.returncode == 0, name + r.stdout + r.stderr
+        res[name] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT")][0][6:])
+    for name in res:
+        assert res[name] == res["default"], name
+
+
 def test_a_new_context_never_takes_an_old_contexts_rows(pkg):
     """Rows handed over as {bits, launch number} granules are accepted on the number alone: a context that gets
     a destroyed context's workspace block back must not take its rows for its own.  Launch numbers are unique per process
