@@ -921,25 +921,29 @@ __device__ __forceinline__ void pre_sum_scalar(const T* __restrict__ xyz, int64_
     }
 }
 
-// f32 fast path: the cloud is read as a flat array of float4 (16 B per lane, fully coalesced).  float4 j holds flat
-// floats 4j..4j+3; flat float f belongs to coordinate f % 3, and 4 == 1 (mod 3), so element e of float4 j is
-// coordinate (j + e) % 3: the sum pass needs no regrouping at all.
+// f32 fast path: the cloud is read as a flat array of float4.  A lane takes THREE consecutive float4 = 12 floats = exactly
+// four points per trip (48 contiguous bytes per lane, 3 KB per wave, three loads in flight) -- the mapping of the radius pass
+// below.  (Round 3; one float4 per lane and trip before: both clouds of C4 38 -> 34 us per call.  Built on it, measured and
+// removed: both passes in ONE launch, the points kept in registers and the launches' boundary replaced by a wait for the
+// centroid -- 57 us: 490 workgroups spinning on one record at three waves per SIMD cost more than the second launch.)
+struct PreGroup { float4 a, b, c; };
+__device__ __forceinline__ void pre_sum_group(const PreGroup& g, double (&acc)[3]) {
+    acc[0] += (double)g.a.x; acc[1] += (double)g.a.y; acc[2] += (double)g.a.z;
+    acc[0] += (double)g.a.w; acc[1] += (double)g.b.x; acc[2] += (double)g.b.y;
+    acc[0] += (double)g.b.z; acc[1] += (double)g.b.w; acc[2] += (double)g.c.x;
+    acc[0] += (double)g.c.y; acc[1] += (double)g.c.z; acc[2] += (double)g.c.w;
+}
 __device__ __forceinline__ void pre_sum_f32v(const float* __restrict__ xyz, int64_t n, int lb, int nb, double (&acc)[3]) {
     const float4* __restrict__ v = (const float4*)xyz;
-    const int64_t nfloats = 3 * n, nf4 = nfloats / 4;
-    const int64_t j0 = (int64_t)lb * 256 + threadIdx.x, stride = (int64_t)nb * 256;
-    int m = (int)(j0 % 3);                         // j mod 3, carried along (a 64-bit modulo per trip cost more than the loads)
-    const int mstep = (int)(stride % 3);
-#pragma unroll 4
-    for (int64_t j = j0; j < nf4; j += stride, m = m + mstep >= 3 ? m + mstep - 3 : m + mstep) {
-        const float4 q = v[j];
-        const double e0 = (double)q.x, e1 = (double)q.y, e2 = (double)q.z, e3 = (double)q.w;
-        if (m == 0) { acc[0] += e0; acc[1] += e1; acc[2] += e2; acc[0] += e3; }
-        else if (m == 1) { acc[1] += e0; acc[2] += e1; acc[0] += e2; acc[1] += e3; }
-        else { acc[2] += e0; acc[0] += e1; acc[1] += e2; acc[2] += e3; }
+    const int64_t ngroups = n / 4;
+#pragma unroll 2
+    for (int64_t q = (int64_t)lb * 256 + threadIdx.x; q < ngroups; q += (int64_t)nb * 256) {
+        PreGroup g;
+        g.a = v[3 * q]; g.b = v[3 * q + 1]; g.c = v[3 * q + 2];
+        pre_sum_group(g, acc);
     }
-    if (lb == 0 && threadIdx.x == 0)
-        for (int64_t f = nf4 * 4; f < nfloats; ++f) acc[f % 3] += (double)xyz[f];   // < 4 trailing floats
+    if (lb == 0 && threadIdx.x == 0)   // the last n % 4 points
+        for (int64_t k = 4 * ngroups; k < n; ++k) { acc[0] += (double)xyz[3 * k]; acc[1] += (double)xyz[3 * k + 1]; acc[2] += (double)xyz[3 * k + 2]; }
 }
 
 template <typename T>
