@@ -377,11 +377,18 @@ def secondary_legs(pkg, ctx, torch, np, legs=("c3", "c4", "stream")):
                      "ms_per_batch": dt * 1e3, "pair_iterations_per_sec": npairs * iters / dt, "registrations_per_sec": npairs / dt,
                      "correspondences_per_sec": npairs * n * (iters + 1) / dt, "cell_list_build_ms": bms,
                      "result_iterations": int(res[0].iterations)}
-        if rn:   # the pair-resident engine: ONE launch runs every pass of every pair (kss_resident.hip)
+        if rn:   # the pair-resident engine: every pass of every pair in ONE launch, or -- more pairs than the device runs at
+            # once -- in two (passes 0-2 of every pair, then the rest, longest pairs first: kss_engine.hip, resident_loop)
             passes = iters + 1
-            pass_eq = rms / passes                       # the launch's time per pass of the whole batch
+            lpb = max(1, int(round(rn / float(reps))))   # launches per batch
+            rms = rms * lpb                              # kernel time per batch (the launches of a batch follow each other)
+            pass_eq = rms / passes                       # ... per pass of the whole batch
             tr = read_traffic("resident_icp")
-            out["c3"].update({"kernel": "resident_icp_kernel", "avg_launch_ms": rms, "launches": rn, "pair_passes_per_launch": runits / rn if rn else None,
+            if tr:
+                tr = tr * lpb                            # (the counters are averaged per launch)
+            out["c3"].update({"kernel": "resident_icp_kernel", "avg_launch_ms": rms, "launches": rn, "launches_per_batch": lpb,
+                              "avg_launch_ms_is": "the kernel time of one batch (sum over its launches)",
+                              "pair_passes_per_launch": runits / rn * lpb if rn else None,
                               "ms_per_pass_of_the_batch": pass_eq,
                               "bound": "VALU / LDS latency inside one CU per pair (targets and cell table in LDS, sources in registers: a pass moves no "
                                        "source or target through HBM; the canonical f64 sum tree is ~60 % of a pass's instructions)",

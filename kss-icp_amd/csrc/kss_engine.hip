@@ -1142,13 +1142,29 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
         }
         return KSS_OK;
     };
+    // A batch of more pairs than the device runs at once ends with a tail: 1024 uneven registrations on 256 compute units take
+    // 6.5 ms for 4.8 ms of work per unit (a tenth of C3's pairs keep hundreds of searches per pass going and run twice as long;
+    // whichever of them starts last is the kernel's end).  Such a batch runs as TWO launches: every pair's passes 0 .. split_at - 1
+    // (default: the first pass alone, where every source searches -- the same work for every pair), then the rest with the pairs
+    // in the order of DECREASING cost as the first launch predicts it -- longest first, the classic rule for this scheduling
+    // problem.  The predictor: the mean squared distance of the pair's first correspondences (the host has it from pass 0: a
+    // pair that starts far away is still moving, and searching, twenty passes later); with more passes in the first launch,
+    // the searches they asked for.  Measured at C3 (ms per batch): one launch 7.39; split after pass 0: 6.53, after pass 1:
+    // 6.59, 2: 6.83, 3: 7.05, 5: 7.15, 7: 7.63.  Between the launches a pair's registers rest in memory (20 bytes per source).
+    // Same passes, same host protocol, same bits.  KSS_RESIDENT_SPLIT=0: one launch (A/B); =k: split after pass k - 1.
+    static const int split_env = getenv("KSS_RESIDENT_SPLIT") ? atoi(getenv("KSS_RESIDENT_SPLIT")) : 1;
+    int split_at = 0;
+    ResArgs ra;
+    std::memset(&ra, 0, sizeof ra);
     if (!cand) {
         int ntc = 0, tabc = 0;
         if (!resident_capacities(pl, &ntc, &tabc)) return KSS_OK;
         gate = resident_gate(c, np);
         if (!gate) return KSS_OK;
-        ResArgs ra;
-        std::memset(&ra, 0, sizeof ra);
+        if (split_env > 0 && np >= 2 * resident_rows_limit(c) && P.max_iterations >= split_env + 4 && !stamps_on &&
+            ensure(c, c->res_pos, (size_t)pl.total_src * sizeof(float4)) == KSS_OK && ensure(c, c->res_wc, (size_t)pl.total_src * sizeof(unsigned)) == KSS_OK &&
+            ensure(c, c->res_perm, (size_t)np * sizeof(int32_t)) == KSS_OK)
+            split_at = split_env;
         ra.pairs = (const GridPairDev*)c->g_pairs.p;
         ra.cell_start = (const int32_t*)c->g_start.p + 1;
         ra.sorted = (const float4*)c->g_sorted.p;
@@ -1159,6 +1175,9 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
         ra.max_passes = max_passes;
         number_launch();
         ra.seq0 = a.seq0; ra.stamp0 = a.stamp0;
+        ra.exit_tag = a.stamp0;
+        ra.split_at = split_at;
+        ra.st_pos = (float4*)c->res_pos.p; ra.st_wc = (unsigned*)c->res_wc.p;
         ra.max_d2 = P.max_corr_dist * P.max_corr_dist;
         static const float skin = getenv("KSS_SKIN") ? (float)atof(getenv("KSS_SKIN")) : 0.25f;
         ra.skin = skin;
@@ -1236,7 +1255,7 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
 
     // ---- per-pair host state (what icp_loop keeps in its vectors) ----
     enum { PH_ITER = 0, PH_FIT = 1, PH_DONE = 2 };
-    struct PairHost { Convergence cv; float fin[16]; int iters = 0, converged = 0, state = 0, k = 0, phase = PH_ITER, cancelled = 0; double last_mse = 0.0, fitness = 0.0; };
+    struct PairHost { Convergence cv; float fin[16]; int iters = 0, converged = 0, state = 0, k = 0, phase = PH_ITER, cancelled = 0, parked = 0; double last_mse = 0.0, fitness = 0.0; };
     std::vector<PairHost> H((size_t)np);
     for (int p = 0; p < np; ++p) {
         Convergence& cv = H[p].cv;
@@ -1250,6 +1269,9 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
     }
     if (P.trace_n) *P.trace_n = 0;
     std::atomic<int> failed{0}, kernel_done{0}, pairs_left{np}, cancel_all{0};
+    int split_now = split_at;                  // > 0 while the first launch of a split batch is being served
+    unsigned exit_tag_now = a.stamp0;
+    std::vector<char> in_launch((size_t)np, 1);
     const int judge = cand ? c->spec_judge : -1;
     const double judge_threshold = c->spec_threshold;
     std::atomic<long long> units{0};
@@ -1282,7 +1304,8 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
     };
     auto serve = [&](int t, int nt) {
         int remaining = 0;
-        for (int p = t; p < np; p += nt) ++remaining;
+        for (int p = t; p < np; p += nt)
+            if (H[p].phase != PH_DONE && !H[p].parked) ++remaining;
         long idle = 0, grace = 0;
         double s[NSUMS];
         auto last_progress = std::chrono::steady_clock::now();
@@ -1293,7 +1316,7 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
             const bool cancelling = judge >= 0 && cancel_all.load(std::memory_order_relaxed) != 0;
             for (int p = t; p < np; p += nt) {
                 PairHost& h = H[p];
-                if (h.phase == PH_DONE) continue;
+                if (h.phase == PH_DONE || h.parked) continue;
                 if (cancelling && p != judge) {
                     // the judge was good enough: this candidate's result will not be looked at.  Its workgroups are told to stop at
                     // whatever gate they reach next (some may be inside a pass the others will never join: the tickets are cleared
@@ -1342,6 +1365,11 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
                     send(p, nullptr, 0, 2);
                     h.phase = PH_DONE; --remaining; pairs_left.fetch_sub(1, std::memory_order_relaxed);
                 }
+                // the first launch of a split batch: the pair's workgroup left after pass split_now - 1; the record just written
+                // is what the pair's workgroup of the SECOND launch finds at its first gate
+                if (split_now > 0 && h.phase != PH_DONE && h.k == split_now) {
+                    h.parked = 1; --remaining; pairs_left.fetch_sub(1, std::memory_order_relaxed);
+                }
             }
             if (progress) { idle = 0; grace = 0; if (t == 0) last_progress = std::chrono::steady_clock::now(); continue; }
             __builtin_ia32_pause();
@@ -1357,8 +1385,9 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
                     bool gone = true;
                     const unsigned long long* fl = h_seq + (size_t)2 * NSUMS * np;
                     for (int p = 0; p < np && gone; ++p) {
+                        if (!in_launch[p]) continue;
                         const unsigned long long w0 = __atomic_load_n(&fl[2 * p], __ATOMIC_ACQUIRE), w1 = __atomic_load_n(&fl[2 * p + 1], __ATOMIC_RELAXED);
-                        gone = (unsigned)w0 == a.stamp0 && (unsigned)(w0 >> 32) == (unsigned)p && (unsigned)(w1 >> 32) == kss_mix3((unsigned)w0, (unsigned)(w0 >> 32), (unsigned)w1);
+                        gone = (unsigned)w0 == exit_tag_now && (unsigned)(w0 >> 32) == (unsigned)p && (unsigned)(w1 >> 32) == kss_mix3((unsigned)w0, (unsigned)(w0 >> 32), (unsigned)w1);
                     }
                     if (gone) kernel_done.store(1);
                     else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - last_progress).count() > 2.0) {
@@ -1384,6 +1413,39 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
     static const int cand_div = getenv("KSS_CAND_PAIRS_PER_THREAD") ? std::max(1, atoi(getenv("KSS_CAND_PAIRS_PER_THREAD"))) : 8;
     const int nthreads = std::max(1, std::min(res_threads, cand ? (np + cand_div - 1) / cand_div : (np + 7) / 8));
     c->pool.run_threads(nthreads, serve);
+    if (split_at > 0 && !failed.load()) {
+        // ---- the second launch of a split batch: the parked pairs, longest first ----
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // every workgroup of the first launch has left (its registers are in memory)
+        // cost predictor: the searches the pair asked for in passes 1 .. split_at - 1 (its exit flag carries the count); with
+        // only pass 0 in the first launch, the mean squared distance of its first correspondences (KSS_RESIDENT_SPLIT_KEY=mse)
+        static const bool key_mse = getenv("KSS_RESIDENT_SPLIT_KEY") != nullptr && std::string(getenv("KSS_RESIDENT_SPLIT_KEY")) == "mse";
+        std::vector<std::pair<double, int>> order;
+        const unsigned long long* fl = h_seq + (size_t)2 * NSUMS * np;
+        for (int p = 0; p < np; ++p) {
+            in_launch[p] = 0;
+            if (!H[p].parked) continue;
+            order.emplace_back(key_mse || split_at < 2 ? H[p].last_mse : (double)(unsigned)(fl[2 * p + 1] & 0xffffffffull), p);
+        }
+        std::stable_sort(order.begin(), order.end(), [](const std::pair<double, int>& x, const std::pair<double, int>& y) { return x.first > y.first; });
+        const int np2 = (int)order.size();
+        if (np2 > 0) {
+            std::vector<int32_t> perm((size_t)np2);
+            for (int i = 0; i < np2; ++i) { perm[i] = order[i].second; in_launch[order[i].second] = 1; H[order[i].second].parked = 0; }
+            HIPCHK(c, hipMemcpyAsync(c->res_perm.p, perm.data(), (size_t)np2 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));   // (pageable source)
+            ra.perm = (const int32_t*)c->res_perm.p;
+            ra.first_pass = split_at; ra.split_at = 0;
+            ra.exit_tag = a.stamp0 + 1u;
+            split_now = 0; exit_tag_now = ra.exit_tag;
+            kernel_done.store(0); pairs_left.store(np2);
+            {
+                ProfScope ps(c, KSS_K_RESIDENT, true);
+                std::string lerr;
+                if (launch_resident(c->stream, P.nn_fma != 0, np2, ra, lerr) != KSS_OK) return set_err(c, KSS_ERR_HIP, "resident: the second launch of a split batch failed");
+            }
+            c->pool.run_threads(std::max(1, std::min(res_threads, (np2 + 7) / 8)), serve);
+        }
+    }
     if (failed.load()) {
         // let every workgroup that still waits (or has not started yet) leave, then report: the caller starts over on the
         // launch-per-pass engine (the resident kernel has written nothing but its result slots -- and, for candidates, the

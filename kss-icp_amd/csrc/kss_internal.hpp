@@ -139,10 +139,10 @@ constexpr int RES_LDS_MAX = 160 * 1024 - 256;   // dynamic LDS of a workgroup (t
 constexpr unsigned RES_STAMP_ANY = 4095u;
 // "this pair's workgroups have all left": the host learns that a resident kernel is gone from these flags, not from HIP (a
 // HIP call of a serving thread can wait on locks other threads hold for as long as THEIR kernels run)
-__device__ __forceinline__ void res_store_exit_flag(unsigned long long* flags, int pair, unsigned stamp0) {
+__device__ __forceinline__ void res_store_exit_flag(unsigned long long* flags, int pair, unsigned tag, unsigned note = 0u) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     u32x4 o;
-    o.x = stamp0; o.y = (unsigned)pair; o.z = 0u; o.w = kss_mix3(o.x, o.y, o.z);
+    o.x = tag; o.y = (unsigned)pair; o.z = note; o.w = kss_mix3(o.x, o.y, o.z);
     unsigned long long* dst = flags + 2 * (int64_t)pair;
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(o) : "memory");
 }
@@ -160,7 +160,14 @@ struct ResArgs {
     int32_t gate_polls, max_passes, full_always;
     int32_t ntc, tabc;                          // LDS capacities of this launch: targets (multiple of 64), table entries (multiple of 8)
     int32_t* idx_out; float* d2_out;            // fitness pass: per-source correspondences (null: not wanted)
-    unsigned long long* exit_flags;             // host-mapped, one 16-byte granule per pair: {stamp0, pair, 0, check} stored when the pair's workgroup leaves
+    unsigned long long* exit_flags;             // host-mapped, one 16-byte granule per pair: {exit_tag, pair, searches asked for, check} stored when the pair's workgroup leaves
+    unsigned int exit_tag;                      // what the flag carries (the two launches of a split batch tell theirs apart)
+    // A batch of more pairs than the device runs at once is run as TWO launches (kss_engine.hip, resident_loop): every pair's
+    // passes [0, split_at) first, then the rest in the order of decreasing cost, predicted from the searches the first passes
+    // asked for.  Between the launches a pair's registers rest in memory: position + skip room, candidates.
+    const int32_t* perm;                        // workgroup -> pair (null: identity)
+    int32_t first_pass, split_at;               // this launch runs passes [first_pass, split_at) (split_at 0: to the end)
+    float4* st_pos; unsigned int* st_wc;        // per source (cell order): {x, y, z, room}, {winner | runner-up << 16}
     unsigned long long* stamps;                 // diagnostics (null in production)
 };
 size_t resident_lds_bytes(int ntc, int tabc);

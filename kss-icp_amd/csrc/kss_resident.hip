@@ -245,7 +245,7 @@ __global__ __launch_bounds__(RES_THREADS, 1) void resident_icp_kernel(const ResA
     __shared__ int s_ctl[4];      // [0] requests queued this round, [1] the gate was answered
     __shared__ int s_ps[16];      // the gate record (PairState layout)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = tid >> 9;
-    const int pi = blockIdx.x;
+    const int pi = a.perm ? a.perm[blockIdx.x] : (int)blockIdx.x;
     const GridPairDev pr = a.pairs[pi];
     const GridParams& gp = pr.gp;
     const int nt = pr.tgt_n, ns = pr.src_n, n_rows = pr.n_rows;
@@ -297,10 +297,17 @@ __global__ __launch_bounds__(RES_THREADS, 1) void resident_icp_kernel(const ResA
         wc[j] = 0xffffffffu;
         const int s = j * RES_THREADS + tid;
         if (s < ns) {
-            const float4 v = a.src0[pr.src_base + s];
-            px[j] = v.x; py[j] = v.y; pz[j] = v.z;
+            if (a.first_pass > 0) {   // the second launch of a split batch: where the first one left this source
+                const float4 v = a.st_pos[pr.src_base + s];
+                px[j] = v.x; py[j] = v.y; pz[j] = v.z; room[j] = v.w;
+                wc[j] = a.st_wc[pr.src_base + s];
+            } else {
+                const float4 v = a.src0[pr.src_base + s];
+                px[j] = v.x; py[j] = v.y; pz[j] = v.z;
+            }
         }
     }
+    if (tid == 0) s_ctl[2] = 0;   // searches asked for in the passes >= 1 of this launch (kept in LDS: a register for it costs this kernel 180 spills)
     __syncthreads();
     KSS_RSTAMP(1);
     if (a.stamps && tid == 0) t_last = __builtin_amdgcn_s_memrealtime();
@@ -348,7 +355,7 @@ __global__ __launch_bounds__(RES_THREADS, 1) void resident_icp_kernel(const ResA
 #pragma unroll
     for (int k = 0; k < 12; ++k) m[k] = 0.f;
     int apply = 0, mode = 0;      // mode 0: a regular pass; 1: the getFitnessScore() pass (the last one); 2: stop
-    for (int pass = 0; pass < a.max_passes; ++pass) {
+    for (int pass = a.first_pass; pass < a.max_passes; ++pass) {
         // (the lane number goes through an opaque move once per pass: otherwise the compiler hoists every slot's addresses --
         // ten 64-bit source addresses, the LDS addresses of the sums -- out of this loop and spills them)
         int tv = tid;
@@ -374,12 +381,12 @@ __global__ __launch_bounds__(RES_THREADS, 1) void resident_icp_kernel(const ResA
                 if (tid == 0) s_ctl[1] = ok ? 1 : 0;
             }
             __syncthreads();
-            if (!s_ctl[1]) { if (tid == 0) res_store_exit_flag(a.exit_flags, pi, a.stamp0); return; }   // nobody answered: leave (the host's wait reports it)
+            if (!s_ctl[1]) { if (tid == 0) res_store_exit_flag(a.exit_flags, pi, a.exit_tag, (unsigned)s_ctl[2]); return; }   // nobody answered: leave (the host's wait reports it)
 #pragma unroll
             for (int k = 0; k < 12; ++k) m[k] = __int_as_float(__builtin_amdgcn_readfirstlane(s_ps[k]));   // (uniform: scalar registers)
             apply = __builtin_amdgcn_readfirstlane(s_ps[13]);
             mode = __builtin_amdgcn_readfirstlane(s_ps[14]);
-            if (mode >= 2) { if (tid == 0) res_store_exit_flag(a.exit_flags, pi, a.stamp0); return; }
+            if (mode >= 2) { if (tid == 0) res_store_exit_flag(a.exit_flags, pi, a.exit_tag, (unsigned)s_ctl[2]); return; }
         }
         KSS_RLAP(pass > 0 ? 8 : 6);
         const bool fit = mode == 1;
@@ -463,10 +470,11 @@ __global__ __launch_bounds__(RES_THREADS, 1) void resident_icp_kernel(const ResA
         // ---- phase B: the searches.  Queue entries are served sixteen lanes each (64 per round of the workgroup); what did
         // not fit is queued again -- or, when that is most of the cloud (the first pass of a registration: every source
         // searches), searched by its own lane, ten searches per lane with every lane busy ----
-        for (;;) {
+        for (bool first_round = true;; first_round = false) {
             __syncthreads();               // the requests are in
             if (pass > 0) KSS_RLAP(2);
             const int total = s_ctl[0];
+            if (first_round && pass > 0 && tid == 0) s_ctl[2] += total;
             // most of the cloud searches (the first pass): nobody serves the queue -- the lanes whose requests went there take
             // them back (the query, the radius are still in their registers) and every lane searches its own slots
             const bool dense = total > 5 * RES_NQ;
@@ -554,6 +562,7 @@ __global__ __launch_bounds__(RES_THREADS, 1) void resident_icp_kernel(const ResA
         // is row 2j + h: lane t of the row is lane t of grid_pass_kernel's workgroup ----
         {
         const int nslot = (ns + RES_THREADS - 1) / RES_THREADS;
+        const bool leaving = a.split_at > 0 && pass + 1 == a.split_at;   // uniform
         auto slot_c = [&](auto kc, int j) {
             constexpr int K = decltype(kc)::value;
             const int jj = j % RES_G;
@@ -564,6 +573,12 @@ __global__ __launch_bounds__(RES_THREADS, 1) void resident_icp_kernel(const ResA
                 const unsigned w1 = wc[K] & 0xffffu;
                 const bool have = s < ns && w1 != 0xffffu;
                 const float qx = px[K], qy = py[K], qz = pz[K];
+                // the last pass of the first launch of a split batch: this slot's registers rest in memory until the second one
+                // (here, where the slot is at hand -- a block of its own at the end of the pass cost 60 spilled registers)
+                if (leaving && s < ns) {
+                    a.st_pos[pr.src_base + s] = make_float4(qx, qy, qz, room[K]);
+                    a.st_wc[pr.src_base + s] = wc[K];
+                }
                 float wx = 0.f, wy = 0.f, wz = 0.f, d2 = 0.f;
                 if (have) {
                     const float* t = t3 + 3 * w1;
@@ -647,10 +662,14 @@ __global__ __launch_bounds__(RES_THREADS, 1) void resident_icp_kernel(const ResA
             asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(o) : "memory");
         }
         KSS_RLAP(pass > 0 ? 12 : 6);
-        if (fit) { KSS_RSTAMP(15); if (tid == 0) res_store_exit_flag(a.exit_flags, pi, a.stamp0); return; }   // the fitness pass is the last one
+        if (fit || (a.split_at > 0 && pass + 1 == a.split_at)) {   // the fitness pass is the last one; so is pass split_at - 1 of a split batch's first launch
+            KSS_RSTAMP(15);
+            if (tid == 0) res_store_exit_flag(a.exit_flags, pi, a.exit_tag, (unsigned)s_ctl[2]);
+            return;
+        }
         __syncthreads();                   // (rowv and the queue are rewritten by the next pass)
     }
-    if (tid == 0) res_store_exit_flag(a.exit_flags, pi, a.stamp0);
+    if (tid == 0) res_store_exit_flag(a.exit_flags, pi, a.exit_tag, (unsigned)s_ctl[2]);
 #undef KSS_RSTAMP
 #undef KSS_RLAP
 }

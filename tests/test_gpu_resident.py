@@ -119,3 +119,47 @@ def test_a_pair_too_large_for_a_cu_sends_the_batch_to_the_other_engine(ctx, pkg)
     for i, (s, t) in enumerate(pairs):
         one = ctx.icp(s, t, ctx.icp_params(nn_mode=pkg.NN_GRID))
         assert np.array_equal(res[i].matrix(), one["T"]) and res[i].fitness == one["fitness"] and res[i].iterations == one["iterations"]
+
+
+_SPLIT_CODE = r"""
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as g
+pkg = g.load_package(); S = pkg.synth; ctx = pkg.Context(0)
+rng = np.random.default_rng(17)
+pairs = []
+for i in range(640):
+    nt = int(rng.integers(300, 2200)); ns = int(rng.integers(200, 2200))
+    R = S.rot_axis_angle(rng.normal(size=3), np.deg2rad(float(rng.uniform(0.5, 16.0))))
+    pairs.append(S.make_pair(1900 + i, nt, R=R, t=tuple(rng.normal(scale=0.01, size=3)), shape="bumpy" if i %% 3 else "sphere", n_src=min(ns, nt)))
+pairs[7] = (pairs[7][0][:1].copy(), pairs[7][1])                          # one source point
+s = pairs[9][0].copy(); s[3] = np.nan; pairs[9] = (s, pairs[9][1])        # a non-finite source
+pairs[11] = (pairs[11][0] + np.float32(40.0), pairs[11][1])               # nothing within reach of max_corr_dist: no correspondences
+pairs[13] = (pairs[13][1][:500].copy(), pairs[13][1])                     # already aligned: converges at once
+src_all = np.concatenate([p[0] for p in pairs]); tgt_all = np.concatenate([p[1] for p in pairs])
+so = np.concatenate([[0], np.cumsum([len(p[0]) for p in pairs])]).astype(np.int64)
+to = np.concatenate([[0], np.cumsum([len(p[1]) for p in pairs])]).astype(np.int64)
+out = []
+for kw in (dict(), dict(max_iterations=9, fixed_iterations=1), dict(max_iterations=12, compute_fitness=0, max_corr_dist=0.5)):
+    res = ctx.icp_batch(src_all, so, tgt_all, to, ctx.icp_params(nn_mode=pkg.NN_GRID, **kw))
+    out.append([[list(r.T), r.iterations, r.state, r.converged, r.fitness, r.last_mse] for r in res])
+print("RESULT" + json.dumps(out))
+"""
+
+
+def test_split_batch_equals_one_launch():
+    """More pairs than the device runs at once (640 ragged pairs on 256 compute units): the batch runs as two launches, every
+    pair's first pass, then the rest longest-first, the pairs' registers resting in memory in between.  Same records as ONE
+    launch (KSS_RESIDENT_SPLIT=0), as a split after passes 1 and 3, and as the launch-per-pass engine, bit for bit -- with pairs
+    that end before, at and after the split, pairs without correspondences, and the fitness pass on either side of it."""
+    def run(env):
+        r = subprocess.run([sys.executable, "-c", _SPLIT_CODE % ROOT], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stdout + r.stderr
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT")][0][6:]), r.stderr
+    base, err = run({})
+    assert "launch-per-pass" not in err
+    for env in ({"KSS_RESIDENT_SPLIT": "0"}, {"KSS_RESIDENT_SPLIT": "2"}, {"KSS_RESIDENT_SPLIT": "4"}, {"KSS_RESIDENT_SPLIT": "4", "KSS_RESIDENT_SPLIT_KEY": "mse"},
+                {"KSS_RESIDENT": "0"}):
+        got, err = run(env)
+        assert got == base, env
+        assert "launch-per-pass" not in err, env
