@@ -1161,7 +1161,7 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
         if (!resident_capacities(pl, &ntc, &tabc)) return KSS_OK;
         gate = resident_gate(c, np);
         if (!gate) return KSS_OK;
-        if (split_env > 0 && np >= 2 * resident_rows_limit(c) && P.max_iterations >= split_env + 4 && !stamps_on &&
+        if (split_env > 0 && np >= 2 * resident_rows_limit(c) && P.max_iterations >= split_env + 4 &&
             ensure(c, c->res_pos, (size_t)pl.total_src * sizeof(float4)) == KSS_OK && ensure(c, c->res_wc, (size_t)pl.total_src * sizeof(unsigned)) == KSS_OK &&
             ensure(c, c->res_perm, (size_t)np * sizeof(int32_t)) == KSS_OK)
             split_at = split_env;
@@ -1436,6 +1436,7 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
             ra.perm = (const int32_t*)c->res_perm.p;
             ra.first_pass = split_at; ra.split_at = 0;
             ra.exit_tag = a.stamp0 + 1u;
+            if (stamps_on) HIPCHK(c, hipMemsetAsync(c->g_stamps.p, 0, (size_t)np * 16 * sizeof(unsigned long long), c->stream));   // (the timeline of the SECOND launch)
             split_now = 0; exit_tag_now = ra.exit_tag;
             kernel_done.store(0); pairs_left.store(np2);
             {
