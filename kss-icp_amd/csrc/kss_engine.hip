@@ -1145,14 +1145,17 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
     // A batch of more pairs than the device runs at once ends with a tail: 1024 uneven registrations on 256 compute units take
     // 6.5 ms for 4.8 ms of work per unit (a tenth of C3's pairs keep hundreds of searches per pass going and run twice as long;
     // whichever of them starts last is the kernel's end).  Such a batch runs as TWO launches: every pair's passes 0 .. split_at - 1
-    // (default: the first pass alone, where every source searches -- the same work for every pair), then the rest with the pairs
-    // in the order of DECREASING cost as the first launch predicts it -- longest first, the classic rule for this scheduling
-    // problem.  The predictor: the mean squared distance of the pair's first correspondences (the host has it from pass 0: a
-    // pair that starts far away is still moving, and searching, twenty passes later); with more passes in the first launch,
-    // the searches they asked for.  Measured at C3 (ms per batch): one launch 7.39; split after pass 0: 6.53, after pass 1:
-    // 6.59, 2: 6.83, 3: 7.05, 5: 7.15, 7: 7.63.  Between the launches a pair's registers rest in memory (20 bytes per source).
+    // (default: passes 0 and 1 -- the first, where every source searches, is the same work for every pair), then the rest with
+    // the pairs in the order of DECREASING cost as the first launch predicts it -- longest first, the classic rule for this
+    // scheduling problem.  The predictor: the searches the pair asked for in pass 1 (its exit flag carries the count): a pair
+    // that is still moving then keeps moving, and searching, for the passes to come.  (With pass 0 alone in the first launch the
+    // host orders by the mean squared distance of the first correspondences instead: on C3 as good -- 6.53 vs 6.59 ms -- but by
+    // accident: that distance saturates at the point spacing, the long pairs are those rotated by 2-4 degrees, one to two
+    // spacings, which creep for all twenty passes, and they merely end up in the middle of that order.  The size of the first
+    // ICP step predicts nothing: 7.4.)  Measured at C3 (ms per batch): one launch 7.39-7.45; split after pass 0: 6.51-6.64,
+    // after pass 1: 6.59-6.66, 2: 6.83, 3: 7.05, 5: 7.15, 7: 7.63.  Between the launches a pair's registers rest in memory (20 bytes per source).
     // Same passes, same host protocol, same bits.  KSS_RESIDENT_SPLIT=0: one launch (A/B); =k: split after pass k - 1.
-    static const int split_env = getenv("KSS_RESIDENT_SPLIT") ? atoi(getenv("KSS_RESIDENT_SPLIT")) : 1;
+    static const int split_env = getenv("KSS_RESIDENT_SPLIT") ? atoi(getenv("KSS_RESIDENT_SPLIT")) : 2;
     int split_at = 0;
     ResArgs ra;
     std::memset(&ra, 0, sizeof ra);
@@ -1255,7 +1258,7 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
 
     // ---- per-pair host state (what icp_loop keeps in its vectors) ----
     enum { PH_ITER = 0, PH_FIT = 1, PH_DONE = 2 };
-    struct PairHost { Convergence cv; float fin[16]; int iters = 0, converged = 0, state = 0, k = 0, phase = PH_ITER, cancelled = 0, parked = 0; double last_mse = 0.0, fitness = 0.0; };
+    struct PairHost { Convergence cv; float fin[16]; int iters = 0, converged = 0, state = 0, k = 0, phase = PH_ITER, cancelled = 0, parked = 0; double last_mse = 0.0, fitness = 0.0, step0 = 0.0; };
     std::vector<PairHost> H((size_t)np);
     for (int p = 0; p < np; ++p) {
         Convergence& cv = H[p].cv;
@@ -1345,6 +1348,7 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
                     ++h.iters;
                     const double mse = s[16] / s[0];
                     h.last_mse = mse;
+                    if (h.iters == 1) h.step0 = (3.0 - ((double)tk[0] + (double)tk[5] + (double)tk[10])) + std::sqrt((double)tk[3] * tk[3] + (double)tk[7] * tk[7] + (double)tk[11] * tk[11]);   // how far the first step went: 2 (1 - cos angle) + |t|
                     if (p == 0 && P.trace_n && *P.trace_n < P.trace_cap) {
                         if (P.trace_sums) std::memcpy(P.trace_sums + (size_t)(*P.trace_n) * NSUMS, s, NSUMS * sizeof(double));
                         if (P.trace_Tk) std::memcpy(P.trace_Tk + (size_t)(*P.trace_n) * 16, tk, 16 * sizeof(float));
@@ -1424,7 +1428,8 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
         for (int p = 0; p < np; ++p) {
             in_launch[p] = 0;
             if (!H[p].parked) continue;
-            order.emplace_back(key_mse || split_at < 2 ? H[p].last_mse : (double)(unsigned)(fl[2 * p + 1] & 0xffffffffull), p);
+            static const bool key_step = getenv("KSS_RESIDENT_SPLIT_KEY") != nullptr && std::string(getenv("KSS_RESIDENT_SPLIT_KEY")) == "step";
+            order.emplace_back(key_step ? H[p].step0 : key_mse || split_at < 2 ? H[p].last_mse : (double)(unsigned)(fl[2 * p + 1] & 0xffffffffull), p);
         }
         std::stable_sort(order.begin(), order.end(), [](const std::pair<double, int>& x, const std::pair<double, int>& y) { return x.first > y.first; });
         const int np2 = (int)order.size();

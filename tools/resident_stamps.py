@@ -55,6 +55,13 @@ for lo, hi in ((0, 256), (256, 512), (512, 768), (768, 1024)):
         lo, hi, (st[sel, 0].min() - t0) / 100.0, (st[sel, 0].max() - t0) / 100.0, np.median(life[sel]), life[sel].max(),
         np.median(st[sel, 8] / np.maximum(passes[sel] - 1, 1)) / 100.0, (st[sel, 8] / np.maximum(passes[sel] - 1, 1)).max() / 100.0,
         np.median(st[sel, 10] / np.maximum(passes[sel] - 1, 1)) / 100.0))
+# which pairs are the long ones?  (C3's pairs differ in their rotation angle, U(0, 15 deg), and in their random points)
+ang = np.array([15.0 * S.u01(4000 + i, 4)[0] for i in range(len(st))])
+rq_all = st[:, 14] / passes
+for lo, hi in ((0, 1), (1, 2), (2, 4), (4, 8), (8, 12), (12, 15)):
+    sel = (ang >= lo) & (ang < hi)
+    if sel.any():
+        print("angle %2d..%2d deg: %4d pairs, lifetime median %6.0f us, requests per pass median %5.0f" % (lo, hi, sel.sum(), np.median(life[sel]), np.median(rq_all[sel])))
 worst = np.argsort(-life)[:5]
 for w in worst:
-    print("slow pair: lifetime %.0f us: gate %.0f A %.0f B %.0f C %.0f pub %.0f pass0-B %.0f pass0-rest %.0f" % (life[w], st[w, 8] / 100.0, st[w, 9] / 100.0, st[w, 10] / 100.0, st[w, 11] / 100.0, st[w, 12] / 100.0, st[w, 13] / 100.0, st[w, 6] / 100.0))
+    print("slow pair %d (angle %.2f deg): lifetime %.0f us: gate %.0f A %.0f B %.0f C %.0f pub %.0f pass0-B %.0f pass0-rest %.0f" % (w, ang[w], life[w], st[w, 8] / 100.0, st[w, 9] / 100.0, st[w, 10] / 100.0, st[w, 11] / 100.0, st[w, 12] / 100.0, st[w, 13] / 100.0, st[w, 6] / 100.0))
