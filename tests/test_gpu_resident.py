@@ -163,3 +163,8 @@ def test_split_batch_equals_one_launch():
         got, err = run(env)
         assert got == base, env
         assert "launch-per-pass" not in err, env
+    # an answer held back in the first launch (the 300th) and in the second (the 2500th): the call starts over on the other engine
+    for stall in ("300", "2500"):
+        got, err = run({"KSS_TEST_RES_STALL": stall, "KSS_GATE_POLLS": "3000"})
+        assert got == base, stall
+        assert "launch-per-pass" in err, stall
