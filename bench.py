@@ -254,7 +254,7 @@ def register_leg(pkg, ctx, np, cpu=True):
 
         def gpu():
             if sub:
-                t_, _ = ctx.downsample_aivs(tgt, m); s_, _ = ctx.downsample_aivs(src, m)      # target first, as the reference
+                (t_, _), (s_, _) = ctx.downsample_aivs_pair(tgt, m, src, m)      # both clouds at once (KSS_ICP.hpp:71-81 does the target, then the source; independent)
             else:
                 s_, t_ = src, tgt
             return s_, t_, ctx.register(s_, t_, src, 8.0, 1000)

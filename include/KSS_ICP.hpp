@@ -40,8 +40,8 @@ public:
     }
 
     void KSSICP_Registration(int iter) {
-        const std::vector<std::vector<double>> pointCloudT = downsample(pointTarget, pNumber);   // :71-75
-        const std::vector<std::vector<double>> pointCloudS = downsample(pointSource, pNumber);   // :77-81
+        std::vector<std::vector<double>> pointCloudT, pointCloudS;                               // :71-75 (target), :77-81 (source)
+        downsample_both(pointTarget, pointSource, pNumber, pointCloudT, pointCloudS);
         std::cout << "initRegistration start." << std::endl;
         std::vector<double> s = kss_host::pack(pointCloudS), t = kss_host::pack(pointCloudT), f = kss_host::pack(pointSource);
         std::vector<double> align(f.size());
@@ -129,6 +129,21 @@ private:
         }
         out.resize((size_t)k * 3);
         return kss_host::unpack(out);
+    }
+
+    // the two down-samplings of :71-81 do not depend on each other: one call, both clouds at once (kss_downsample_aivs_pair)
+    static void downsample_both(const std::vector<std::vector<double>>& a, const std::vector<std::vector<double>>& b, int m,
+                                std::vector<std::vector<double>>& out_a, std::vector<std::vector<double>>& out_b) {
+        if (m <= 0 || a.empty() || b.empty()) { out_a = downsample(a, m); out_b = downsample(b, m); return; }
+        std::vector<double> ia = kss_host::pack(a), ib = kss_host::pack(b), oa(ia.size()), ob(ib.size());
+        int64_t ka = 0, kb = 0;
+        int rc[2] = {KSS_OK, KSS_OK};
+        kss_host::Runtime::check(kss_downsample_aivs_pair(kss_host::Runtime::ctx(), ia.data(), (int64_t)a.size(), m, oa.data(), (int64_t)a.size(), &ka, nullptr,
+                                                          ib.data(), (int64_t)b.size(), m, ob.data(), (int64_t)b.size(), &kb, nullptr, rc), "kss_downsample_aivs_pair");
+        if (rc[0] != KSS_OK) out_a = downsample(a, m);     // (the one-cloud path handles a degenerate cloud and reports anything else)
+        else { oa.resize((size_t)ka * 3); out_a = kss_host::unpack(oa); }
+        if (rc[1] != KSS_OK) out_b = downsample(b, m);
+        else { ob.resize((size_t)kb * 3); out_b = kss_host::unpack(ob); }
     }
 
     static void print_matrix(const float* T) {

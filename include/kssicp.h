@@ -257,6 +257,16 @@ int kss_downsample_fps(kss_ctx *ctx, const double *xyz, int64_t n, int64_t m, do
 int kss_downsample_aivs(kss_ctx *ctx, const double *xyz, int64_t n, int64_t point_num, double *out, int64_t capacity,
                         int64_t *n_out, int32_t *out_idx);
 
+/* Both clouds of a registration at once (KSS_ICP.hpp:71-81 down-samples the target, then the source; the two do not depend
+ * on each other): cloud 1 runs on a worker context of ctx, on a thread of its own, while the calling thread does cloud 0.
+ * AIVS on a few thousand points is a chain of ~20 small launches and four host syncs -- two of them overlap almost
+ * completely.  Same selections as two kss_downsample_aivs calls.  rc[k] receives cloud k's status (the codes of
+ * kss_downsample_aivs: a degenerate cloud is KSS_ERR_ARG for that cloud only); the return value is KSS_OK unless an argument
+ * is bad or the worker context cannot be created. */
+int kss_downsample_aivs_pair(kss_ctx *ctx, const double *xyz0, int64_t n0, int64_t point_num0, double *out0, int64_t capacity0,
+                             int64_t *n_out0, int32_t *out_idx0, const double *xyz1, int64_t n1, int64_t point_num1, double *out1,
+                             int64_t capacity1, int64_t *n_out1, int32_t *out_idx1, int rc[2]);
+
 /* ---- (8f #3) octree down-sampler: PCL_octree::PCL_Octree_Simplification_WithOutNormal, Method_Octree.hpp:77-165 ----
  * resolution = mean distance of the first 1000 points to their kn-th nearest point (kn = 2 below 80000 points, else
  * 7 * (n / 80000) capped at 35); occupied voxels of a pcl::octree::OctreePointCloudSearch of that resolution (PCL

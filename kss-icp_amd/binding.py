@@ -25,7 +25,7 @@ SYMBOLS = [
     "kss_nn", "kss_nn_dev", "kss_cov", "kss_cov_dev", "kss_rigid_from_sums", "kss_rotation_search",
     "kss_rotation_search_dev", "kss_grid_angles", "kss_rotation_candidates", "kss_icp_default_params", "kss_icp",
     "kss_icp_dev", "kss_icp_batch", "kss_icp_batch_dev", "kss_transform_apply", "kss_transform_apply_dev",
-    "kss_pcr_qm", "kss_register", "kss_register_batch", "kss_gather_results", "kss_rccl_allreduce_sum", "kss_transform_apply_f32", "kss_downsample_fps", "kss_downsample_aivs", "kss_downsample_octree", "kss_knn", "kss_knn_dev", "kss_normals", "kss_normals_orient",
+    "kss_pcr_qm", "kss_register", "kss_register_batch", "kss_gather_results", "kss_rccl_allreduce_sum", "kss_transform_apply_f32", "kss_downsample_fps", "kss_downsample_aivs", "kss_downsample_aivs_pair", "kss_downsample_octree", "kss_knn", "kss_knn_dev", "kss_normals", "kss_normals_orient",
 ]
 
 
@@ -154,6 +154,7 @@ def load_library():
     L.kss_transform_apply_f32.argtypes = [vp, vp, vp, i64, vp]
     L.kss_downsample_fps.argtypes = [vp, vp, i64, i64, vp, vp]
     L.kss_downsample_aivs.argtypes = [vp, vp, i64, i64, vp, i64, C.POINTER(i64), vp]
+    L.kss_downsample_aivs_pair.argtypes = [vp, vp, i64, i64, vp, i64, C.POINTER(i64), vp, vp, i64, i64, vp, i64, C.POINTER(i64), vp, C.POINTER(C.c_int)]
     for n in ("kss_knn", "kss_knn_dev"):
         getattr(L, n).argtypes = [vp, vp, i64, vp, i64, C.c_int, vp, vp]
     L.kss_normals.argtypes = [vp, vp, i64, C.c_int, vp]
@@ -438,6 +439,19 @@ class Context:
         k = C.c_int64(0)
         self._chk(self.L.kss_downsample_aivs(self.h, _p(a), len(a), int(point_num), _p(out), len(a), C.byref(k), _p(idx)), "kss_downsample_aivs")
         return out[:k.value].copy(), idx[:k.value].copy()
+
+    def downsample_aivs_pair(self, pts0, point_num0, pts1, point_num1):
+        """Both clouds of a registration at once (the second on a worker context): ((points, indices), (points, indices))."""
+        a, b = _f64(pts0), _f64(pts1)
+        oa, ob = np.empty_like(a), np.empty_like(b)
+        ia, ib = np.empty(len(a), np.int32), np.empty(len(b), np.int32)
+        ka, kb = C.c_int64(0), C.c_int64(0)
+        rc = (C.c_int * 2)(0, 0)
+        self._chk(self.L.kss_downsample_aivs_pair(self.h, _p(a), len(a), int(point_num0), _p(oa), len(a), C.byref(ka), _p(ia),
+                                                  _p(b), len(b), int(point_num1), _p(ob), len(b), C.byref(kb), _p(ib), rc), "kss_downsample_aivs_pair")
+        for k in range(2):
+            self._chk(rc[k], "kss_downsample_aivs_pair (cloud %d)" % k)
+        return (oa[:ka.value].copy(), ia[:ka.value].copy()), (ob[:kb.value].copy(), ib[:kb.value].copy())
 
     def normals_orient(self, pts, normals):
         a = _f64(pts); nrm = _f64(normals).copy()

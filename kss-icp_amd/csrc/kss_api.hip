@@ -577,6 +577,28 @@ int kss_downsample_aivs(kss_ctx* c, const double* xyz, int64_t n, int64_t point_
     return KSS_OK;
 }
 
+int kss_downsample_aivs_pair(kss_ctx* c, const double* xyz0, int64_t n0, int64_t point_num0, double* out0, int64_t capacity0, int64_t* n_out0,
+                             int32_t* out_idx0, const double* xyz1, int64_t n1, int64_t point_num1, double* out1, int64_t capacity1,
+                             int64_t* n_out1, int32_t* out_idx1, int rc[2]) {
+    if (!c || !rc) return set_err(c, KSS_ERR_ARG, "downsample_aivs_pair: null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->workers.empty()) {   // (worker contexts live as long as the parent: kss_register_batch shares them)
+        kss_ctx* w = nullptr;
+        const int wrc = kss_ctx_create(c->device, &w);
+        if (wrc != KSS_OK) return set_err(c, wrc, "downsample_aivs_pair: cannot create a worker context");
+        w->nn_mode = c->nn_mode;
+        c->workers.push_back(w);
+    }
+    kss_ctx* w = c->workers[0];
+    rc[0] = rc[1] = KSS_OK;
+    // (a thread of its own: ~50 us per call; the context's pool -- woken through a condition variable -- was measured at 1.9 ms per pair of clouds against 0.65)
+    std::thread other([&] { hipSetDevice(w->device); rc[1] = kss_downsample_aivs(w, xyz1, n1, point_num1, out1, capacity1, n_out1, out_idx1); });
+    rc[0] = kss_downsample_aivs(c, xyz0, n0, point_num0, out0, capacity0, n_out0, out_idx0);
+    other.join();
+    if (rc[1] != KSS_OK && rc[0] == KSS_OK) c->err = w->err;   // (kss_last_error(ctx) then speaks of the cloud that failed)
+    return KSS_OK;
+}
+
 // ---- octree down-sampler (Method_Octree.hpp:77-165) ----------------------------------------------------
 int kss_downsample_octree(kss_ctx* c, const double* xyz, int64_t n, int32_t* out_idx, int64_t capacity, int64_t* n_out,
                           double* resolution_out) {

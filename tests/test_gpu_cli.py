@@ -195,8 +195,16 @@ def test_aivs_matches_oracle(ctx, O, pkg, ref_pairs):
         assert np.array_equal(idx, ref), (len(P), m, len(idx), len(ref))
         assert np.array_equal(out, np.asarray(P, dtype=np.float64)[ref])
         assert len(set(idx.tolist())) == len(idx)
+    # both clouds of a registration in one call (the second on a worker context, concurrently): the same selections
+    for (P0, m0), (P1, m1) in zip(cases[0::2], cases[1::2]):
+        (o0, i0), (o1, i1) = ctx.downsample_aivs_pair(P0, m0, P1, m1)
+        assert np.array_equal(i0, O.aivs(P0, m0)) and np.array_equal(i1, O.aivs(P1, m1)), (len(P0), len(P1))
+        assert np.array_equal(o0, np.asarray(P0, dtype=np.float64)[i0]) and np.array_equal(o1, np.asarray(P1, dtype=np.float64)[i1])
     # clouds the reference cannot voxelise are rejected, not mis-sampled
     flat = S.bumpy(12, 500).copy(); flat[:, 2] = 0.25
+    with pytest.raises(pkg.KssError) as e2:
+        ctx.downsample_aivs_pair(S.bumpy(5, 2000), 1000, flat, 100)      # (the second cloud's status is reported as its own)
+    assert e2.value.status == -1
     with pytest.raises(pkg.KssError) as e:
         ctx.downsample_aivs(flat, 100)
     assert e.value.status == -1

@@ -27,6 +27,9 @@ def tm(f, reps=5):
     return (time.perf_counter() - t) / reps * 1e3, out
 ta, (s, _) = tm(lambda: ctx.downsample_aivs(S, m))
 tb, (t, _) = tm(lambda: ctx.downsample_aivs(T, m))
+tp, ((s2, _), (t2, _)) = tm(lambda: ctx.downsample_aivs_pair(S, m, T, m))
+assert np.array_equal(s, s2) and np.array_equal(t, t2)
+print("AIVS of both clouds in one call (second cloud on a worker context): %.2f ms" % tp)
 tr, r = tm(lambda: ctx.register(s, t, S, 8.0, 1000))
 tn, _ = tm(lambda: ctx.register(s, t, None, 8.0, 1000)) if False else (0.0, None)
 print("AIVS source %.2f ms, AIVS target %.2f ms, kss_register %.2f ms (judge ICP %d iterations, E_d_init %.2e, used list %d)" %
