@@ -65,7 +65,7 @@ int kss_ctx_destroy(kss_ctx* c) {
     DevBuf* bufs[] = {&c->tgt4, &c->src0, &c->cur[0], &c->cur[1], &c->keys, &c->partials, &c->sums, &c->nn_work,
                       &c->red_work, &c->pair_red, &c->state, &c->cs, &c->scratch_a, &c->scratch_b, &c->scratch_c,
                       &c->stage_src, &c->stage_tgt, &c->stage_idx, &c->stage_d2, &c->stage_out, &c->g_counts, &c->g_start,
-                      &c->g_cursor, &c->g_bsums, &c->g_sorted, &c->g_list, &c->g_count, &c->g_bbox, &c->g_partials, &c->g_start2, &c->g_pairs, &c->g_stamps, &c->g_pos, &c->g_nnst, &c->res_pos, &c->res_wc, &c->res_perm, &c->pack_seg, &c->reg_s, &c->reg_t, &c->reg_p, &c->reg_all, &c->reg_f, &c->reg_g, &c->oct_pts, &c->oct_cen, &c->oct_a, &c->oct_b, &c->oct_tmp, &c->pair_ticket, &c->pre_partials, &c->pre_state, &c->g_rowpair, &c->g_gate};
+                      &c->g_cursor, &c->g_bsums, &c->g_sorted, &c->g_list, &c->g_count, &c->g_bbox, &c->g_partials, &c->g_start2, &c->g_pairs, &c->g_stamps, &c->g_pos, &c->g_nnst, &c->res_pos, &c->res_wc, &c->res_perm, &c->cand_tags, &c->pack_seg, &c->reg_s, &c->reg_t, &c->reg_p, &c->reg_all, &c->reg_f, &c->reg_g, &c->oct_pts, &c->oct_cen, &c->oct_a, &c->oct_b, &c->oct_tmp, &c->pair_ticket, &c->pre_partials, &c->pre_state, &c->g_rowpair, &c->g_gate};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (c->h_sums) hipHostFree(c->h_sums);
@@ -865,6 +865,13 @@ int kss_register(kss_ctx* c, const double* src_sub, int64_t nss, const double* t
             for (int i = 0; i <= nl; ++i) so[i] = (int64_t)i * nss;
             rr.resize(nl);
             RCHK(icp_run_dev(c, dAll.p, so.data(), dT.p, to, nl, true, KSS_F64, &ip, rr.data()));
+        }
+        if (getenv("KSS_DEBUG_CANDS")) {   // every candidate's record (a diagnostic of run-to-run differences)
+            char head[64]; std::snprintf(head, sizeof head, "[kss] ctx %p candidates:", (void*)c);
+            std::string line = head;
+            char buf[96];
+            for (int i = 0; i < nl; ++i) { std::snprintf(buf, sizeof buf, " %d:(%d,%d,%.17g)", i, rr[i].iterations, rr[i].state, rr[i].fitness); line += buf; }
+            std::fprintf(stderr, "%s | judge (%d,%d,%.17g) spec %d\n", line.c_str(), r0.iterations, r0.state, r0.fitness, have_cands ? 1 : 0);
         }
         double Q = 9999; int angleIndex = 0;
         for (int i = 0; i < nl; ++i) {

@@ -47,7 +47,7 @@ struct kss_ctx {
     // grow-only device workspace
     DevBuf tgt4, src0, cur[2], keys, partials, sums, nn_work, red_work, pair_red, state, cs, scratch_a,
         scratch_b, scratch_c, stage_src, stage_tgt, stage_idx, stage_d2, stage_out, g_counts, g_start, g_cursor,
-        g_bsums, g_sorted, g_list, g_count, g_bbox, g_partials, g_start2, g_pairs, g_stamps, g_pos, g_nnst, res_pos, res_wc, res_perm, pack_seg, reg_s, reg_t, reg_p, reg_all, reg_f, reg_g, oct_pts, oct_cen, oct_a, oct_b, oct_tmp, pair_ticket, pre_partials, pre_state, g_rowpair, g_gate;
+        g_bsums, g_sorted, g_list, g_count, g_bbox, g_partials, g_start2, g_pairs, g_stamps, g_pos, g_nnst, res_pos, res_wc, res_perm, cand_tags, pack_seg, reg_s, reg_t, reg_p, reg_all, reg_f, reg_g, oct_pts, oct_cen, oct_a, oct_b, oct_tmp, pair_ticket, pre_partials, pre_state, g_rowpair, g_gate;
     HostPool pool;   // per-pair host work of batched iterations
     std::vector<kss_ctx*> workers;   // contexts of kss_register_batch's worker threads (same device, own streams)
     std::vector<unsigned long long> last_stamps;

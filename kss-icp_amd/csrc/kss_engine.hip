@@ -959,12 +959,13 @@ static int nn_pass(kss_ctx* c, const IcpPlan& pl, bool fma, const float4* d_in, 
         bool same = true;
         for (int p = 1; p < pl.npairs; ++p) same = same && pl.g[p].ns == pl.g[0].ns && pl.g[p].src_base == (int64_t)p * pl.g[0].ns;
         const int bpp = cand_pass_blocks_per_pair(pl.g[0].ns);
-        if (same && ensure_zeroed(c, c->partials, (size_t)pl.npairs * bpp * NSUMS * sizeof(double)) == KSS_OK) {
+        if (same && ensure_zeroed(c, c->partials, (size_t)pl.npairs * bpp * NSUMS * sizeof(double)) == KSS_OK &&
+            ensure_zeroed(c, c->cand_tags, (size_t)pl.npairs * bpp * sizeof(unsigned)) == KSS_OK) {
             bool launched;
             {
                 ProfScope ps(c, KSS_K_NN_SWEEP);
                 launched = launch_cand_pass(c->stream, fma, pl.npairs, d_state, d_in, d_out, (const float4*)c->tgt4.p + pl.g[0].tgt_base, pl.g[0].tgt_pad,
-                                            (int)pl.g[0].ns, max_d2, (double*)c->partials.p, (int32_t*)c->pair_ticket.p, c->h_seq_dev, c->seq + 1, d_idx_out, d_d2_out);
+                                            (int)pl.g[0].ns, max_d2, (double*)c->partials.p, (unsigned*)c->cand_tags.p, c->h_seq_dev, c->seq + 1, d_idx_out, d_d2_out);
             }
             if (launched) {
                 ++c->seq;
@@ -1235,7 +1236,8 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
         ca.bpp = bpp; ca.tpw = tpw; ca.wpp = (bpp + tpw - 1) / tpw;
         ca.max_d2 = P.max_corr_dist * P.max_corr_dist;
         ca.partials = (double*)c->partials.p;
-        ca.pair_ticket = (int32_t*)c->pair_ticket.p;
+        KCHK(ensure_zeroed(c, c->cand_tags, (size_t)np * bpp * sizeof(unsigned)));   // (zeroed when (re)allocated: no tag of the block's earlier owner; pass numbers start at 1)
+        ca.row_tag = (unsigned*)c->cand_tags.p;
         ca.gate = gate;
         ca.pub = c->h_seq_dev;
         ca.exit_flags = c->h_seq_dev + (size_t)2 * NSUMS * np;
@@ -1486,8 +1488,6 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
         return KSS_OK;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));   // every workgroup has left (its last act was the publication just consumed)
-    if (cand && cancel_all.load() != 0)           // stopped candidates may have left a pass half drawn
-        HIPCHK(c, hipMemsetAsync(c->pair_ticket.p, 0, (size_t)np * sizeof(int32_t), c->stream));
     if (c->prof > 0) { c->prof_n[KSS_K_RESIDENT_PASS] += units.load(); }
     for (int p = 0; p < np; ++p) {
         kss_icp_result& r = results[p];

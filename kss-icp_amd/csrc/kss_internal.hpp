@@ -265,7 +265,7 @@ void launch_corr_reduce_publish(hipStream_t st, const RedWork* d_work, int n_wor
 size_t cand_pass_lds_bytes(int nt_pad);
 int cand_pass_blocks_per_pair(int64_t ns);
 bool launch_cand_pass(hipStream_t st, bool fma, int npairs, const PairState* d_state, const float4* d_src_in, float4* d_src_out, const float4* d_tgt,
-                      int nt_pad, int ns, double max_d2, double* d_partials, int32_t* d_pair_ticket, unsigned long long* d_pub, unsigned long long seq,
+                      int nt_pad, int ns, double max_d2, double* d_partials, unsigned int* d_row_tag, unsigned long long* d_pub, unsigned long long seq,
                       int32_t* d_idx_out, float* d_d2_out);
 // ... and the same batch with every workgroup RESIDENT for the whole registration (cand_resident_kernel): the target is staged
 // once, the sources stay in registers, and between passes a candidate's workgroups wait at its gate record for the transform
@@ -279,7 +279,7 @@ struct CandArgs {
     int32_t bpp, wpp, tpw;                      // tiles per candidate, workgroups per candidate, tiles per workgroup (<= CAND_TPW)
     double max_d2;
     double* partials;                           // one row of NSUMS per tile
-    int32_t* pair_ticket;                       // zero at rest
+    unsigned int* row_tag;                      // one word per tile: the launch-and-pass number its row belongs to (no counter to keep zero at rest)
     const unsigned int* gate;                   // per candidate 32 words the host stores into through the BAR
     unsigned long long* pub;                    // host-mapped result slots
     unsigned long long seq0;

@@ -519,6 +519,39 @@ __device__ __forceinline__ double cand_block_sum(double (&v)[NSUMS], double (*sh
     return out;
 }
 
+// Row hand-over of the candidate kernels WITHOUT a counter.  Every tile's row carries a tag -- the launch-and-pass number, stored
+// after the row's twenty values have been acknowledged -- and the candidate's workgroup 0 waits until every tile of the
+// candidate shows the tag of THIS pass before it adds the rows up.  (Round 3 handed rows over with one ticket per workgroup on
+// a per-candidate counter that had to be zero at rest.  With eight registrations in flight on contexts of their own, a debug
+// build counted tickets beyond the candidate's workgroups and rows of another pass in launches that ended normally: one
+// registration in ten then differed from its solitary run, some grossly.  Where the extra tickets came from was not found in
+// the time left; a tag cannot be left over, and a row of another pass cannot be added.)  Returns whether this workgroup adds
+// the candidate's rows up (false also when a row never came: bounded; the host's wait reports it).
+// stop_rec / stop_tag (resident kernel): the candidate's gate record; a stop order "at whatever pass" may have taken some of the
+// candidate's workgroups away before this pass, so a waiting lane looks at the record every 32 polls and gives up when it reads one.
+__device__ __forceinline__ bool cand_rows_ready(unsigned int* __restrict__ row_tag, int row0, int nrows, unsigned tag, bool reducer, int polls, int* s_flag,
+                                                const unsigned int* stop_rec = nullptr, unsigned stop_tag = 0) {
+    if (!reducer) return false;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x;
+    if (tid == 0) *s_flag = 1;
+    __syncthreads();
+    for (int r = tid; r < nrows; r += 256) {
+        int n = 0;
+        while (__hip_atomic_load(&row_tag[row0 + r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++n > polls) { *s_flag = 0; break; }
+            if (stop_rec && (n & 31) == 0) {
+                u32x4 v;
+                asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(stop_rec) : "memory");
+                if (v.w - kss_mix3(v.x, v.y, v.z) == stop_tag) { *s_flag = 0; break; }
+            }
+        }
+    }
+    __syncthreads();
+    return *s_flag != 0;
+}
+
 // A candidate's last workgroup: the column sums of its rows in a fixed order (lane (g, c) adds rows g, g + 12, ..., then the
 // 12 group totals in group order) and the publication of the 20 sums as checked {bits, launch number} granules.
 __device__ __forceinline__ void cand_rows_publish(const double* __restrict__ partials, int row0, int nrows, double (*shg)[NSUMS],
@@ -557,7 +590,7 @@ __device__ __forceinline__ void cand_rows_publish(const double* __restrict__ par
 template <bool FMA>
 __global__ __launch_bounds__(256) void cand_pass_kernel(const PairState* __restrict__ state, const float4* __restrict__ src_in, float4* __restrict__ src_out,
                                                         const float4* __restrict__ tgt, int nt_pad, int ns, int blocks_per_pair, double max_d2,
-                                                        double* __restrict__ partials, int32_t* __restrict__ pair_ticket,
+                                                        double* __restrict__ partials, unsigned int* __restrict__ row_tag,
                                                         unsigned long long* __restrict__ pub, unsigned long long seq,
                                                         int32_t* __restrict__ idx_out, float* __restrict__ d2_out) {
     extern __shared__ float4 cand_tile[];
@@ -602,27 +635,25 @@ __global__ __launch_bounds__(256) void cand_pass_kernel(const PairState* __restr
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    if (tid == 0) s_last = atomicAdd(&pair_ticket[pair], 1) == blocks_per_pair - 1;
-    __syncthreads();
-    if (!s_last) return;
+    if (tid == 0) __hip_atomic_store(&row_tag[row0 + blk], (unsigned)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (!cand_rows_ready(row_tag, row0, blocks_per_pair, (unsigned)seq, blk == blocks_per_pair - 1, 1 << 22, &s_last)) return;   // (the candidate's LAST workgroup waits: every other one was dispatched before it)
     __shared__ double shg[ROWSUM_GROUPS][NSUMS];
     cand_rows_publish(partials, row0, blocks_per_pair, shg, pub, pair, seq);
-    if (tid == 0) pair_ticket[pair] = 0;   // re-arm for the next pass (stream order makes it visible)
 }
 
 size_t cand_pass_lds_bytes(int nt_pad) { return (size_t)(16 * (((nt_pad + 15) / 16 + 7) / 8 * 8) + 24) * sizeof(float4); }   // 16 padded slices at stride chunk + 1, eight points of look-ahead
 int cand_pass_blocks_per_pair(int64_t ns) { return (int)((ns + CAND_SRC - 1) / CAND_SRC); }
 // false: the device refused the LDS size (the caller runs sweep + reduce)
 bool launch_cand_pass(hipStream_t st, bool fma, int npairs, const PairState* d_state, const float4* d_src_in, float4* d_src_out, const float4* d_tgt,
-                      int nt_pad, int ns, double max_d2, double* d_partials, int32_t* d_pair_ticket, unsigned long long* d_pub, unsigned long long seq,
+                      int nt_pad, int ns, double max_d2, double* d_partials, unsigned int* d_row_tag, unsigned long long* d_pub, unsigned long long seq,
                       int32_t* d_idx_out, float* d_d2_out) {
     const size_t bytes = cand_pass_lds_bytes(nt_pad);
     const void* fn = fma ? reinterpret_cast<const void*>(&cand_pass_kernel<true>) : reinterpret_cast<const void*>(&cand_pass_kernel<false>);
     if (bytes > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
     const int bpp = cand_pass_blocks_per_pair(ns);
     const dim3 grid((unsigned)(npairs * bpp)), block(256);
-    if (fma) hipLaunchKernelGGL(cand_pass_kernel<true>, grid, block, bytes, st, d_state, d_src_in, d_src_out, d_tgt, nt_pad, ns, bpp, max_d2, d_partials, d_pair_ticket, d_pub, seq, d_idx_out, d_d2_out);
-    else hipLaunchKernelGGL(cand_pass_kernel<false>, grid, block, bytes, st, d_state, d_src_in, d_src_out, d_tgt, nt_pad, ns, bpp, max_d2, d_partials, d_pair_ticket, d_pub, seq, d_idx_out, d_d2_out);
+    if (fma) hipLaunchKernelGGL(cand_pass_kernel<true>, grid, block, bytes, st, d_state, d_src_in, d_src_out, d_tgt, nt_pad, ns, bpp, max_d2, d_partials, d_row_tag, d_pub, seq, d_idx_out, d_d2_out);
+    else hipLaunchKernelGGL(cand_pass_kernel<false>, grid, block, bytes, st, d_state, d_src_in, d_src_out, d_tgt, nt_pad, ns, bpp, max_d2, d_partials, d_row_tag, d_pub, seq, d_idx_out, d_d2_out);
     return true;
 }
 
@@ -762,17 +793,17 @@ __global__ __launch_bounds__(256) void cand_resident_kernel(const CandArgs a) {
         if (tid < NSUMS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         KSS_CLAP(10);
-        if (tid == 0) {
-            const int last = atomicAdd(&a.pair_ticket[pair], 1) == a.wpp - 1;
-            if (last) {   // re-armed BEFORE the publication: the next pass's tickets are drawn only after the host has answered it
-                __hip_atomic_store(&a.pair_ticket[pair], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        {
+            const unsigned tag = (unsigned)(a.seq0 + (unsigned long long)pass);
+            if (tid < CAND_TPW) {          // this workgroup's tiles: their rows are out
+                const int blk = wg + tid * a.wpp;
+                if (tid < a.tpw && blk < a.bpp) __hip_atomic_store(&a.row_tag[row0 + blk], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             }
-            s_ctl[1] = last;
+            const bool sum_it = cand_rows_ready(a.row_tag, row0, a.bpp, tag, wg == 0, a.gate_polls, &s_ctl[1], a.gate + (size_t)pair * 32, a.stamp0 + RES_STAMP_ANY);
+            KSS_CLAP(11);
+            if (sum_it) cand_rows_publish(a.partials, row0, a.bpp, shg, a.pub, pair, a.seq0 + (unsigned long long)pass);
+            else if (wg == 0) { KSS_CSTAMP(15); leave(); return; }   // stopped, or a row never came (bounded wait; the host's wait reports it)
         }
-        __syncthreads();
-        KSS_CLAP(11);
-        if (s_ctl[1]) cand_rows_publish(a.partials, row0, a.bpp, shg, a.pub, pair, a.seq0 + (unsigned long long)pass);
         KSS_CLAP(12);
         if (stamping) a.stamps[(size_t)pair * 16 + 7] = (unsigned long long)(pass + 1);
         if (fit) break;

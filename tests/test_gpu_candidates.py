@@ -75,8 +75,8 @@ def test_every_form_of_the_candidate_batch_gives_the_same_registration():
 
 
 def test_many_registrations_in_a_row_leave_nothing_behind(ctx, pkg):
-    """Stopped candidates may leave a pass half drawn (tickets taken by some of a candidate's workgroups only): the tickets are
-    cleared after such a launch.  Alternating registrations whose candidates are stopped, run to the end, stopped ... on ONE
+    """Stopped candidates may leave a pass half done (rows of some of a candidate's workgroups only): rows carry the number of
+    their launch and pass, so nothing of it can be taken for a later registration's.  Alternating registrations whose candidates are stopped, run to the end, stopped ... on ONE
     context must each equal the same registration on a fresh context."""
     S = pkg.synth
     R30 = S.rot_axis_angle([0.3, 0.2, 1.0], np.deg2rad(30.0))
