@@ -128,3 +128,15 @@ print("RESULT" + json.dumps(out))
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT")][0][6:])
     for k in range(1, len(res)):
         assert res[k] == res[0], k
+
+
+def test_registrations_under_load_equal_the_solitary_one():
+    """One context registers the same pair 300 times while five threads register other pairs on contexts of their own
+    (tools/load_repro.py).  Round 3: with rows handed over by per-candidate ticket counters, one registration in ten differed
+    from the solitary result under exactly this load; rows are now handed over by launch-and-pass tags.
+    Every registration must give the solitary run's bits."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "load_repro.py"), "300", "register", "5"], capture_output=True, text=True,
+                       timeout=600, env=dict(os.environ))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "300 registrations, 0 differed" in r.stdout, r.stdout[-2000:]
+    assert "left before every pair" not in r.stderr, r.stderr[-2000:]
