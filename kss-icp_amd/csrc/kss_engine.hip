@@ -250,7 +250,7 @@ static int stage_plan(kss_ctx* c, const IcpPlan& pl) {
     KCHK(ensure(c, c->red_work, pl.red.size() * sizeof(RedWork)));
     KCHK(ensure(c, c->pair_red, pl.pred.size() * sizeof(PairRed)));
     KCHK(ensure(c, c->state, (size_t)pl.npairs * sizeof(PairState)));
-    KCHK(ensure_zeroed(c, c->pair_ticket, (size_t)2 * std::max(pl.npairs, PUB_PAIRS) * sizeof(int32_t)));   // zero at rest (kss_ctx.hpp); second half: the candidate-resident kernel's exit counts
+    KCHK(ensure_zeroed(c, c->pair_ticket, (size_t)std::max(pl.npairs, PUB_PAIRS) * sizeof(int32_t)));   // zero at rest (kss_ctx.hpp)
     KCHK(ensure_pinned(c, c->h_sums, c->h_sums_cap, (size_t)pl.npairs * NSUMS * sizeof(double)));
     KCHK(ensure_pinned(c, c->h_state, c->h_state_cap, (size_t)pl.npairs * sizeof(PairState)));
     KCHK(ensure_pub(c, pl.npairs));
@@ -1241,7 +1241,6 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
         ca.gate = gate;
         ca.pub = c->h_seq_dev;
         ca.exit_flags = c->h_seq_dev + (size_t)2 * NSUMS * np;
-        ca.exit_ticket = (int32_t*)c->pair_ticket.p + std::max(np, PUB_PAIRS);
         number_launch();
         ca.seq0 = a.seq0; ca.stamp0 = a.stamp0;
         ca.gate_polls = gate_polls; ca.max_passes = max_passes;
@@ -1456,8 +1455,8 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
     }
     if (failed.load()) {
         // let every workgroup that still waits (or has not started yet) leave, then report: the caller starts over on the
-        // launch-per-pass engine (the resident kernel has written nothing but its result slots -- and, for candidates, the
-        // tickets and rows the launch-per-pass form uses: re-armed here)
+        // launch-per-pass engine (the resident kernel has written nothing but its result slots -- and, for candidates, rows
+        // and row tags that carry this launch's numbers)
         for (int p = 0; p < np; ++p)
             if (H[p].phase != PH_DONE) send(p, nullptr, 0, 2, true);
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1473,12 +1472,10 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
                                  " [%s, %d of %d pairs unfinished, waiting for passes %d..%d, %d host threads, stream query: %s]\n",
                          cand ? "candidates" : "cell lists", unfinished, np, k_min, k_max, nthreads, hipGetErrorName((hipError_t)query_said.load()));
             if (getenv("KSS_DEBUG_RES")) {   // what each unfinished pair was waiting for, and what is there
-                std::vector<int32_t> tk((size_t)np, -1);
-                if (cand) hipMemcpy(tk.data(), c->pair_ticket.p, (size_t)np * sizeof(int32_t), hipMemcpyDeviceToHost);
                 for (int p = 0; p < np; ++p) {
                     if (H[p].phase == PH_DONE) continue;
                     const unsigned long long want = a.seq0 + (unsigned long long)H[p].k;
-                    std::fprintf(stderr, "[kss]   pair %d: phase %d, waiting for the sums of pass %d (seq %llu), ticket %d; slots hold seq:", p, H[p].phase, H[p].k, want & 0xffffffffull, tk[p]);
+                    std::fprintf(stderr, "[kss]   pair %d: phase %d, waiting for the sums of pass %d (seq %llu); slots hold seq:", p, H[p].phase, H[p].k, want & 0xffffffffull);
                     const unsigned long long* sl = h_seq + (size_t)2 * NSUMS * p;
                     for (int k = 0; k < NSUMS; ++k) std::fprintf(stderr, " %llu", sl[2 * k + 1] & 0xffffffffull);
                     std::fprintf(stderr, "\n");

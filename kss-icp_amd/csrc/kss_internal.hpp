@@ -286,7 +286,6 @@ struct CandArgs {
     unsigned int stamp0;
     int32_t gate_polls, max_passes;
     int32_t* idx_out; float* d2_out;            // fitness pass: per-source correspondences (null: not wanted)
-    int32_t* exit_ticket;                       // zero at rest: a candidate's workgroups count themselves out ...
     unsigned long long* exit_flags;             // ... and the last one stores {stamp0, pair, 0, check} into the candidate's host-mapped granule
     unsigned long long* stamps;                 // diagnostics (null in production): 16 per candidate, written by its workgroup 0
 };

@@ -673,27 +673,24 @@ __global__ __launch_bounds__(256) void cand_resident_kernel(const CandArgs a) {
     __shared__ double sh[4][NSUMS];
     __shared__ double shg[ROWSUM_GROUPS][NSUMS];
     __shared__ int s_ps[16];
-    __shared__ int s_ctl[2];      // [0] the gate was answered, [1] this workgroup drew the candidate's last ticket
+    __shared__ int s_ctl[2];      // [0] the gate was answered, [1] every row of the candidate has come (workgroup 0)
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const int pair = (int)blockIdx.x / a.wpp, wg = (int)blockIdx.x % a.wpp;
     const int tid = threadIdx.x, sub = tid & 7;
     const int nt_pad = a.nt_pad, ns = a.ns;
     const int chunk = cand_chunk(nt_pad);
     // diagnostic timeline (100 MHz s_memrealtime), by workgroup 0 of each candidate: [0] start, [1] target staged, [15] end; sums
-    // over the passes >= 1 of {8 gate wait, 9 sweeps, 10 sums + rows, 11 ticket, 12 the candidate's total + publication}; 7 passes
+    // over the passes >= 1 of {8 gate wait, 9 sweeps, 10 sums + rows, 11 tags + workgroup 0's wait for every row, 12 the candidate's total + publication}; 7 passes
     unsigned long long t_last = 0;
     const bool stamping = a.stamps != nullptr && wg == 0 && tid == 0;
 #define KSS_CSTAMP(k) do { if (stamping) a.stamps[(size_t)pair * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define KSS_CLAP(k) do { if (stamping) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); if (pass > 0) a.stamps[(size_t)pair * 16 + (k)] += now_ - t_last; t_last = now_; } } while (0)
     KSS_CSTAMP(0);
-    // leaving: the candidate's workgroups count themselves out; the last one tells the host (every exit is uniform over the workgroup)
+    // leaving (every exit is uniform over the workgroup): the candidate's workgroup 0 -- the one that publishes its sums -- tells
+    // the host that nothing more will come for this candidate.  (No count of the workgroups that have left: like the row
+    // tickets it would have to be zero at rest, see cand_rows_ready.)
     auto leave = [&]() {
-        if (tid == 0) {
-            if (atomicAdd(&a.exit_ticket[pair], 1) == a.wpp - 1) {
-                __hip_atomic_store(&a.exit_ticket[pair], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                res_store_exit_flag(a.exit_flags, pair, a.stamp0);
-            }
-        }
+        if (wg == 0 && tid == 0) res_store_exit_flag(a.exit_flags, pair, a.stamp0);
     };
     cand_stage(cand_tile, a.tgt, nt_pad, chunk);
     // tile j of this workgroup = tile wg + j * wpp of the candidate: 32 sources, eight lanes each

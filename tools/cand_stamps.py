@@ -28,7 +28,7 @@ print("kss_register %.3f ms (with stamps); candidates %d; stamped records %d" % 
 t00 = st[:, 0].min()
 for p in range(len(st)):
     v = st[p]; n = max(int(v[7]) - 1, 1)
-    print("candidate %2d: passes %3d, lifetime %7.1f us (staged after %.1f); per pass: gate %5.2f sweep %5.2f sums+rows %5.2f ticket %5.2f total+publish %5.2f = %5.2f us" % (
+    print("candidate %2d: passes %3d, lifetime %7.1f us (staged after %.1f); per pass: gate %5.2f sweep %5.2f sums+rows %5.2f tags+wait %5.2f total+publish %5.2f = %5.2f us" % (
         p, v[7], (v[15] - v[0]) / 100.0, (v[1] - v[0]) / 100.0, v[8] / n / 100.0, v[9] / n / 100.0, v[10] / n / 100.0, v[11] / n / 100.0, v[12] / n / 100.0,
         (v[8] + v[9] + v[10] + v[11] + v[12]) / n / 100.0))
 print("kernel span %.1f us" % ((st[:, 15].max() - t00) / 100.0))
