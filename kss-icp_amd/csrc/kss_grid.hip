@@ -100,45 +100,58 @@ __global__ __launch_bounds__(1024) void scan_of_block_sums_kernel(int32_t* __res
 template <bool SELF>
 __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restrict__ in, int n, const int32_t* __restrict__ block_sums,
                                                          int32_t* __restrict__ out_start) {
-    // each lane scans 16 consecutive elements, wave/LDS scan of the lane totals, plus the workgroup offset
-    __shared__ int sh[256];
+    // the chunk as four slices of 1024 elements; lane t holds elements 4t .. 4t+3 of each slice (one 16-byte load per slice,
+    // consecutive lanes consecutive addresses), wave scans of the lane totals, slice / wave totals through LDS
+    // (round 3: the first form gave every lane 16 CONSECUTIVE elements -- 64 lines per load instruction -- and scanned the
+    // lane totals in eight barrier-separated steps: 14.7 us per C2 build, now 6)
+    typedef int32_t int4u __attribute__((ext_vector_type(4), aligned(4)));
+    __shared__ int sh_tot[4][4];
     __shared__ int sh_off[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int offset = 0;
     if constexpr (SELF) {
         int part = 0;
-        for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) part += block_sums[b];   // RAW chunk totals here
+        for (int b = tid; b < (int)blockIdx.x; b += 256) part += block_sums[b];   // RAW chunk totals here
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
-        if ((threadIdx.x & 63) == 0) sh_off[threadIdx.x >> 6] = part;
-        __syncthreads();
-        offset = sh_off[0] + sh_off[1] + sh_off[2] + sh_off[3];
+        if (lane == 0) sh_off[wave] = part;
     } else {
         offset = block_sums[blockIdx.x];   // already an exclusive scan
     }
-    const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * 16;
-    int v[16];
-    int s = 0;
+    const int base = blockIdx.x * SCAN_CHUNK;
+    int4u v[4];
+    int incl[4];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int i = base + k;
-        v[k] = i < n ? in[i] : 0;
-        s += v[k];
+    for (int k = 0; k < 4; ++k) {
+        const int i = base + (k * 256 + tid) * 4;
+        if (i + 3 < n) v[k] = *(const int4u*)(in + i);
+        else { v[k].x = i < n ? in[i] : 0; v[k].y = i + 1 < n ? in[i + 1] : 0; v[k].z = i + 2 < n ? in[i + 2] : 0; v[k].w = 0; }
+        int x = (v[k].x + v[k].y) + (v[k].z + v[k].w);
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(x, off, 64);
+            if (lane >= off) x += t;
+        }
+        incl[k] = x;
+        if (lane == 63) sh_tot[k][wave] = x;
     }
-    sh[threadIdx.x] = s;
     __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        int t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
-        __syncthreads();
-        sh[threadIdx.x] += t;
-        __syncthreads();
-    }
-    int run = offset + (threadIdx.x > 0 ? sh[threadIdx.x - 1] : 0);
+    if constexpr (SELF) offset = sh_off[0] + sh_off[1] + sh_off[2] + sh_off[3];
+    int run = offset;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int i = base + k;
-        if (i < n) out_start[i] = run;
-        run += v[k];
-        if (SELF && i == n - 1) out_start[n] = run;   // the total
+    for (int k = 0; k < 4; ++k) {
+        int before = 0;                 // waves in front of this one within the slice
+#pragma unroll
+        for (int w = 0; w < 4; ++w) before += w < wave ? sh_tot[k][w] : 0;
+        const int own = (v[k].x + v[k].y) + (v[k].z + v[k].w);
+        const int r0 = run + before + (incl[k] - own);
+        const int i = base + (k * 256 + tid) * 4;
+        int4u o;
+        o.x = r0; o.y = r0 + v[k].x; o.z = o.y + v[k].y; o.w = o.z + v[k].z;
+        if (i + 3 < n) *(int4u*)(out_start + i) = o;
+        else { if (i < n) out_start[i] = o.x; if (i + 1 < n) out_start[i + 1] = o.y; if (i + 2 < n) out_start[i + 2] = o.z; }
+        if (SELF && i <= n - 1 && n - 1 <= i + 3) out_start[n] = o.x + (n - 1 >= i ? v[k].x : 0) + (n - 1 >= i + 1 ? v[k].y : 0) + (n - 1 >= i + 2 ? v[k].z : 0) + (n - 1 >= i + 3 ? v[k].w : 0);   // the total
+        run += (sh_tot[k][0] + sh_tot[k][1]) + (sh_tot[k][2] + sh_tot[k][3]);
     }
 }
 
@@ -148,13 +161,18 @@ __global__ void scan_tail_kernel(const int32_t* __restrict__ counts, int32_t* __
 }
 
 // Exclusive scan of the cell counts: d_start[0 .. n] (d_start[n] = total).  rocPRIM's single-pass decoupled-look-back scan
-// (an inclusive scan written one element to the right; d_start[0] is set to 0 by its own tiny fill) runs at memory speed
-// on big tables: C4's 15.8M cells 250 -> ~40 us (one NN pass 0.64 -> 0.53 ms); on the 1.56M cells of C2 the two small
+// (an inclusive scan written one element to the right; d_start[0] is set to 0 by its own tiny fill) is used
+// on big tables (C4's 2 x 15.8M cells: own kernels 240 us, library default 127, configured below 76); on the 1.56M cells of C2 the two small
 // kernels above are as fast (0.104 vs 0.110 ms per build), so the library scan is used from 4M cells up.  d_scratch must
 // hold scan_scratch_bytes(n).  KSS_SCAN_OWN=1: always the kernels above (A/B).
+// (the library's default configuration for this architecture scans 127 us over C4's 31.6M counters -- a chain of
+// look-backs through ~8000 tiles; with 64 items per lane there are 1929 tiles and the same scan takes 76 us: tools/ab_scan.sh)
+using BigScanConfig = rocprim::scan_config<256, 64, rocprim::block_load_method::block_load_transpose, rocprim::block_store_method::block_store_transpose,
+                                           rocprim::block_scan_algorithm::reduce_then_scan>;
+
 size_t scan_scratch_bytes(int n) {
     size_t bytes = 0;
-    if (rocprim::inclusive_scan(nullptr, bytes, (const int32_t*)nullptr, (int32_t*)nullptr, (size_t)n, rocprim::plus<int32_t>(), (hipStream_t)0) != hipSuccess) bytes = 0;
+    if (rocprim::inclusive_scan<BigScanConfig>(nullptr, bytes, (const int32_t*)nullptr, (int32_t*)nullptr, (size_t)n, rocprim::plus<int32_t>(), (hipStream_t)0) != hipSuccess) bytes = 0;
     return std::max<size_t>(bytes, ((size_t)(n + SCAN_CHUNK - 1) / SCAN_CHUNK + 1) * sizeof(int32_t)) + 256;
 }
 
@@ -162,9 +180,9 @@ static void launch_scan(hipStream_t st, const int32_t* d_counts, int ncells, int
     static const bool own = getenv("KSS_SCAN_OWN") != nullptr;
     if (!own && ncells > 1024 * SCAN_CHUNK) {
         size_t bytes = 0;
-        if (rocprim::inclusive_scan(nullptr, bytes, d_counts, d_start + 1, (size_t)ncells, rocprim::plus<int32_t>(), st) == hipSuccess) {
+        if (rocprim::inclusive_scan<BigScanConfig>(nullptr, bytes, d_counts, d_start + 1, (size_t)ncells, rocprim::plus<int32_t>(), st) == hipSuccess) {
             hipMemsetAsync(d_start, 0, sizeof(int32_t), st);
-            if (rocprim::inclusive_scan((void*)d_scratch, bytes, d_counts, d_start + 1, (size_t)ncells, rocprim::plus<int32_t>(), st) == hipSuccess) return;
+            if (rocprim::inclusive_scan<BigScanConfig>((void*)d_scratch, bytes, d_counts, d_start + 1, (size_t)ncells, rocprim::plus<int32_t>(), st) == hipSuccess) return;
         }
         (void)hipGetLastError();
     }
