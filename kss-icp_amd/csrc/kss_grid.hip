@@ -1460,11 +1460,16 @@ __device__ __forceinline__ int lds_exclusive_scan(const CellCounters<HALF>& cnt,
     for (int c = lo; c < hi; ++c) {
         const int v = cnt.get(c);
         cnt.set(c, run);
-        if (store_global) store_global[c] = base + run;
         run += v;
     }
-    if (store_global && tid == 0) store_global[n] = base + total;
     __syncthreads();
+    if (store_global) {
+        // the starts go out in a pass of their own, consecutive lanes consecutive cells (stored from the loop above, each lane
+        // wrote ITS ~28 consecutive cells: 64 partly written lines per store instruction, 3.4x the table in HBM write traffic)
+        for (int c = tid; c < n; c += GB_THREADS) store_global[c] = base + cnt.get(c);
+        if (tid == 0) store_global[n] = base + total;
+        __syncthreads();   // (the caller turns the starts into cursors next)
+    }
     return total;
 }
 
