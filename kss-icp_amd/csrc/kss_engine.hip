@@ -1323,8 +1323,8 @@ static int resident_loop(kss_ctx* c, const IcpPlan& pl, const kss_icp_params& P,
                 if (h.phase == PH_DONE || h.parked) continue;
                 if (cancelling && p != judge) {
                     // the judge was good enough: this candidate's result will not be looked at.  Its workgroups are told to stop at
-                    // whatever gate they reach next (some may be inside a pass the others will never join: the tickets are cleared
-                    // after the launch); a candidate already on its last pass leaves by itself.
+                    // whatever gate they reach next (some may be inside a pass the others will never join: rows carry the number of
+                    // their launch and pass, nothing is left to clear); a candidate already on its last pass leaves by itself.
                     if (h.phase == PH_ITER) send(p, nullptr, 0, 2, true);
                     h.phase = PH_DONE; h.cancelled = 1; --remaining; pairs_left.fetch_sub(1, std::memory_order_relaxed);
                     progress = true;
