@@ -70,6 +70,7 @@ int kss_ctx_destroy(kss_ctx* c) {
         if (b->p) hipFree(b->p);
     if (c->h_sums) hipHostFree(c->h_sums);
     if (c->h_seq) hipHostFree(c->h_seq);
+    if (c->h_box) hipHostFree(c->h_box);
     if (c->h_xf) hipHostFree(c->h_xf);
     if (c->gate_bar) hipFree(c->gate_bar);
     if (c->res_gate) hipFree(c->res_gate);

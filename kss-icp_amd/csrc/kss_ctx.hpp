@@ -53,6 +53,8 @@ struct kss_ctx {
     std::vector<unsigned long long> last_stamps;
     int stamps_nblk = 0; unsigned long long stamps_seq = 0;   // KSS_GRID_STAMPS=2
     std::vector<float> h_bbox;   // bbox partials of the last single-pair target (host copy)
+    unsigned int* h_box = nullptr; unsigned int* h_box_dev = nullptr; size_t h_box_bytes = 0;   // host-mapped: the same partials as checked granules, written by the pack kernel
+    unsigned box_tag = 0; int box_rows = 0;   // tag and row count of the partials the last pack launch publishes there (0: none)
     double evals_sum = 0.0, evals_launches = 0.0;   // diagnostic runs: distance evaluations of the fused grid launches
     // pinned host staging
     void* h_sums = nullptr;  size_t h_sums_cap = 0;   // host-mapped: kernels write it through h_sums_dev

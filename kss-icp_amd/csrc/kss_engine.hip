@@ -268,9 +268,31 @@ static int pack_clouds(kss_ctx* c, const IcpPlan& pl, const void* d_src, const i
     const size_t esz = dtype == KSS_F64 ? sizeof(double) : sizeof(float);
     if (pl.grid) {   // single pair on the cell list: both clouds and the target's bbox partials in one launch
         const PairGeom& g = pl.g[0];
-        KCHK(ensure(c, c->g_bbox, (size_t)pack_pair_bbox_rows(g.tgt_pad) * 6 * sizeof(float)));
+        const int nbb = pack_pair_bbox_rows(g.tgt_pad);
+        KCHK(ensure(c, c->g_bbox, (size_t)nbb * 6 * sizeof(float)));
+        // up to 8192 partials (2M targets, 256 KB over PCIe) also go straight to host memory as checked granules (grid_setup)
+        static const bool box_host = !(getenv("KSS_BBOX_HOST") && atoi(getenv("KSS_BBOX_HOST")) == 0);
+        c->box_tag = 0; c->box_rows = 0;
+        if (box_host && nbb <= 8192) {
+            const size_t want = (size_t)nbb * 32;
+            if (want > c->h_box_bytes) {
+                if (c->h_box) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipHostFree(c->h_box)); c->h_box = nullptr; c->h_box_dev = nullptr; c->h_box_bytes = 0; }
+                void* hp = nullptr; void* dp = nullptr;
+                const size_t bytes = want + want / 2;
+                if (hipHostMalloc(&hp, bytes, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+                    std::memset(hp, 0, bytes);
+                    c->h_box = (unsigned int*)hp; c->h_box_dev = (unsigned int*)dp; c->h_box_bytes = bytes;
+                } else { if (hp) hipHostFree(hp); (void)hipGetLastError(); }
+            }
+            if (c->h_box) {
+                c->box_tag = (unsigned)(++c->seq);
+                if (c->box_tag == 0) c->box_tag = (unsigned)(++c->seq);
+                c->box_rows = nbb;
+            }
+        }
         launch_pack_pair(c->stream, dtype, (const char*)d_tgt + (size_t)tgt_off[0] * 3 * esz, g.nt, (float4*)c->tgt4.p + g.tgt_base, g.tgt_pad,
-                         (float*)c->g_bbox.p, (const char*)d_src + (size_t)src_off[0] * 3 * esz, g.ns, (float4*)c->src0.p + g.src_base);
+                         (float*)c->g_bbox.p, (const char*)d_src + (size_t)src_off[0] * 3 * esz, g.ns, (float4*)c->src0.p + g.src_base,
+                         c->box_tag ? c->h_box_dev : nullptr, c->box_tag);
         HIPCHK(c, hipGetLastError());
         return KSS_OK;
     }
@@ -330,13 +352,38 @@ static int grid_setup(kss_ctx* c, IcpPlan& pl) {
     const int nbb = pack_pair_bbox_rows(g.tgt_pad);   // one partial per 256 target slots, left by pack_clouds
     const float4* tgt = (const float4*)c->tgt4.p + g.tgt_base;
     ProfScope ps(c, KSS_K_GRID_BUILD);
-    std::vector<float>& hb = c->h_bbox;
-    hb.resize((size_t)nbb * 6);
-    HIPCHK(c, hipMemcpyAsync(hb.data(), c->g_bbox.p, hb.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int b = 0; b < nbb; ++b)
-        for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], hb[(size_t)b * 6 + k]); mx[k] = std::max(mx[k], hb[(size_t)b * 6 + 3 + k]); }
+    bool have_box = false;
+    if (c->box_tag != 0 && c->box_rows == nbb) {
+        // the pack kernel's partials as checked granules in host memory: {three floats, tag + check word}, one for the minimum
+        // and one for the maximum of every 256 target slots; a granule that is not there yet (or seen torn) is read again
+        const unsigned long long* hq = (const unsigned long long*)c->h_box;
+        const auto t0 = std::chrono::steady_clock::now();
+        int g = 0;
+        for (long spin = 0; g < 2 * nbb; ++spin) {
+            const unsigned long long w0 = __atomic_load_n(&hq[2 * g], __ATOMIC_ACQUIRE), w1 = __atomic_load_n(&hq[2 * g + 1], __ATOMIC_ACQUIRE);
+            const unsigned x = (unsigned)w0, y = (unsigned)(w0 >> 32), z = (unsigned)w1, tag = (unsigned)(w1 >> 32);
+            if (tag - kss_mix3(x, y, z) == c->box_tag) {
+                float f[3];
+                std::memcpy(&f[0], &x, 4); std::memcpy(&f[1], &y, 4); std::memcpy(&f[2], &z, 4);
+                for (int k = 0; k < 3; ++k) { if (g & 1) mx[k] = std::max(mx[k], f[k]); else mn[k] = std::min(mn[k], f[k]); }
+                ++g;
+                continue;
+            }
+            __builtin_ia32_pause();
+            if ((spin & 4095) == 4095 && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 20.0) break;   // (a faulted launch: the copy below reports it)
+        }
+        have_box = g == 2 * nbb;
+        if (!have_box) { for (int k = 0; k < 3; ++k) { mn[k] = INFINITY; mx[k] = -INFINITY; } }
+    }
+    if (!have_box) {
+        std::vector<float>& hb = c->h_bbox;
+        hb.resize((size_t)nbb * 6);
+        HIPCHK(c, hipMemcpyAsync(hb.data(), c->g_bbox.p, hb.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int b = 0; b < nbb; ++b)
+            for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], hb[(size_t)b * 6 + k]); mx[k] = std::max(mx[k], hb[(size_t)b * 6 + 3 + k]); }
+    }
     if (!(std::isfinite(mn[0]) && std::isfinite(mn[1]) && std::isfinite(mn[2]) && std::isfinite(mx[0]) && std::isfinite(mx[1]) && std::isfinite(mx[2])))
         return set_err(c, KSS_ERR_ARG, "non-finite target coordinates");
     GridParams gp;

@@ -223,7 +223,7 @@ void launch_empty(hipStream_t st);
 // single pair: target (sentinel padded, + one bbox partial row of 6 floats per 256 slots) and source in ONE launch
 int pack_pair_bbox_rows(int64_t nt_pad);
 void launch_pack_pair(hipStream_t st, int dtype, const void* d_tgt, int64_t nt, float4* d_tgt_out, int64_t nt_pad, float* d_bbox_partial,
-                      const void* d_src, int64_t ns, float4* d_src_out);
+                      const void* d_src, int64_t ns, float4* d_src_out, unsigned int* d_box_host, unsigned box_tag);
 void launch_pack_batch(hipStream_t st, const void* d_in, int dtype, const PackSeg* d_seg, int nseg, int64_t total_out, float4* d_out);
 
 void launch_nn_sweep(hipStream_t st, int S, bool fma, const NNWork* d_work, int n_work,

@@ -57,7 +57,7 @@ void launch_pack_f64_to_f4(hipStream_t st, const double* d_in, int64_t n, float4
 template <typename T>
 __global__ __launch_bounds__(256) void pack_pair_kernel(const T* __restrict__ tgt, int64_t nt, float4* __restrict__ tgt_out, int64_t nt_pad,
                                                         int nb_t, float* __restrict__ bbox_partial, const T* __restrict__ src, int64_t ns,
-                                                        float4* __restrict__ src_out) {
+                                                        float4* __restrict__ src_out, unsigned int* __restrict__ box_host, unsigned box_tag) {
     if ((int)blockIdx.x >= nb_t) {
         const int64_t i = (int64_t)(blockIdx.x - nb_t) * 256 + threadIdx.x;
         if (i < ns) src_out[i] = make_float4((float)src[3 * i], (float)src[3 * i + 1], (float)src[3 * i + 2], 0.f);
@@ -86,24 +86,38 @@ __global__ __launch_bounds__(256) void pack_pair_kernel(const T* __restrict__ tg
     if (lane == 0)
         for (int k = 0; k < 3; ++k) { sh[wave][k] = mn[k]; sh[wave][3 + k] = mx[k]; }
     __syncthreads();
-    if (threadIdx.x < 6) {
-        float v = sh[0][threadIdx.x];
-        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fminf(v, sh[w][threadIdx.x]) : fmaxf(v, sh[w][threadIdx.x]);
-        bbox_partial[blockIdx.x * 6 + threadIdx.x] = v;
+    if (threadIdx.x < 2) {   // lane 0: the block's minimum, lane 1: its maximum
+        const int o = 3 * (int)threadIdx.x;
+        float v[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            v[k] = sh[0][o + k];
+            for (int w = 1; w < 4; ++w) v[k] = threadIdx.x == 0 ? fminf(v[k], sh[w][o + k]) : fmaxf(v[k], sh[w][o + k]);
+            bbox_partial[blockIdx.x * 6 + o + k] = v[k];
+        }
+        if (box_host) {
+            // ... and straight into host memory as a checked 16-byte granule {three floats, launch tag + check word}: the host
+            // sizes the cell grid from the box, and a copy + stream synchronisation cost it ~10 us per registration
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 g;
+            g.x = __float_as_uint(v[0]); g.y = __float_as_uint(v[1]); g.z = __float_as_uint(v[2]); g.w = box_tag + kss_mix3(g.x, g.y, g.z);
+            unsigned int* dst = box_host + ((size_t)blockIdx.x * 2 + threadIdx.x) * 4;
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(g) : "memory");
+        }
     }
 }
 
 int pack_pair_bbox_rows(int64_t nt_pad) { return (int)((nt_pad + 255) / 256); }
 
 void launch_pack_pair(hipStream_t st, int dtype, const void* d_tgt, int64_t nt, float4* d_tgt_out, int64_t nt_pad, float* d_bbox_partial,
-                      const void* d_src, int64_t ns, float4* d_src_out) {
+                      const void* d_src, int64_t ns, float4* d_src_out, unsigned int* d_box_host, unsigned box_tag) {
     const int nb_t = pack_pair_bbox_rows(nt_pad), nb_s = (int)((ns + 255) / 256);
     if (dtype == KSS_F64)
         hipLaunchKernelGGL(pack_pair_kernel<double>, dim3(nb_t + nb_s), dim3(256), 0, st, (const double*)d_tgt, nt, d_tgt_out, nt_pad, nb_t,
-                           d_bbox_partial, (const double*)d_src, ns, d_src_out);
+                           d_bbox_partial, (const double*)d_src, ns, d_src_out, d_box_host, box_tag);
     else
         hipLaunchKernelGGL(pack_pair_kernel<float>, dim3(nb_t + nb_s), dim3(256), 0, st, (const float*)d_tgt, nt, d_tgt_out, nt_pad, nb_t,
-                           d_bbox_partial, (const float*)d_src, ns, d_src_out);
+                           d_bbox_partial, (const float*)d_src, ns, d_src_out, d_box_host, box_tag);
 }
 
 // empty launch: calibrates what a HIP event pair adds around a short kernel (kss_profile_event_overhead)
