@@ -58,11 +58,14 @@ constexpr int SCAN_CHUNK = 4096;   // 256 threads x 16
 
 __global__ __launch_bounds__(256) void scan_block_sums_kernel(const int32_t* __restrict__ in, int n, int32_t* __restrict__ block_sums) {
     __shared__ int sh[4];
+    typedef int32_t int4u __attribute__((ext_vector_type(4), aligned(4)));
     const int base = blockIdx.x * SCAN_CHUNK;
     int s = 0;
-    for (int k = threadIdx.x; k < SCAN_CHUNK; k += 256) {
-        const int i = base + k;
-        if (i < n) s += in[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {   // 16-byte loads, consecutive lanes consecutive addresses (4-byte loads: 2.9 TB/s on C4's table)
+        const int i = base + (k * 256 + (int)threadIdx.x) * 4;
+        if (i + 3 < n) { const int4u v = *(const int4u*)(in + i); s += (v.x + v.y) + (v.z + v.w); }
+        else { if (i < n) s += in[i]; if (i + 1 < n) s += in[i + 1]; if (i + 2 < n) s += in[i + 2]; }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
@@ -71,22 +74,25 @@ __global__ __launch_bounds__(256) void scan_block_sums_kernel(const int32_t* __r
     if (threadIdx.x == 0) block_sums[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-// single workgroup: exclusive scan of up to 1024*16 block sums, in place
+// single workgroup: exclusive scan of the chunk totals, in place (each lane a run of consecutive totals, wave scans of the
+// lane sums, the sixteen wave totals through LDS)
 __global__ __launch_bounds__(1024) void scan_of_block_sums_kernel(int32_t* __restrict__ block_sums, int nb) {
-    __shared__ int sh[1024];
+    __shared__ int wave_tot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per = (nb + 1023) / 1024;
-    const int lo = threadIdx.x * per, hi = min(nb, lo + per);
+    const int lo = min(tid * per, nb), hi = min(nb, lo + per);
     int s = 0;
     for (int i = lo; i < hi; ++i) s += block_sums[i];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan over the 1024 partials
-        int v = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
-        __syncthreads();
-        sh[threadIdx.x] += v;
-        __syncthreads();
+    int incl = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
     }
-    int run = threadIdx.x > 0 ? sh[threadIdx.x - 1] : 0;
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int run = incl - s;
+    for (int w = 0; w < 16; ++w) run += w < wave ? wave_tot[w] : 0;
     for (int i = lo; i < hi; ++i) {
         const int v = block_sums[i];
         block_sums[i] = run;
@@ -150,23 +156,17 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restri
         o.x = r0; o.y = r0 + v[k].x; o.z = o.y + v[k].y; o.w = o.z + v[k].z;
         if (i + 3 < n) *(int4u*)(out_start + i) = o;
         else { if (i < n) out_start[i] = o.x; if (i + 1 < n) out_start[i + 1] = o.y; if (i + 2 < n) out_start[i + 2] = o.z; }
-        if (SELF && i <= n - 1 && n - 1 <= i + 3) out_start[n] = o.x + (n - 1 >= i ? v[k].x : 0) + (n - 1 >= i + 1 ? v[k].y : 0) + (n - 1 >= i + 2 ? v[k].z : 0) + (n - 1 >= i + 3 ? v[k].w : 0);   // the total
+        if (i <= n - 1 && n - 1 <= i + 3) out_start[n] = o.x + (n - 1 >= i ? v[k].x : 0) + (n - 1 >= i + 1 ? v[k].y : 0) + (n - 1 >= i + 2 ? v[k].z : 0) + (n - 1 >= i + 3 ? v[k].w : 0);   // the total
         run += (sh_tot[k][0] + sh_tot[k][1]) + (sh_tot[k][2] + sh_tot[k][3]);
     }
 }
 
-__global__ void scan_tail_kernel(const int32_t* __restrict__ counts, int32_t* __restrict__ start, int n) {
-    // start[n] = total = start[n-1] + counts[n-1]
-    if (threadIdx.x == 0 && blockIdx.x == 0) start[n] = start[n - 1] + counts[n - 1];
-}
-
-// Exclusive scan of the cell counts: d_start[0 .. n] (d_start[n] = total).  rocPRIM's single-pass decoupled-look-back scan
-// (an inclusive scan written one element to the right; d_start[0] is set to 0 by its own tiny fill) is used
-// on big tables (C4's 2 x 15.8M cells: own kernels 240 us, library default 127, configured below 76); on the 1.56M cells of C2 the two small
-// kernels above are as fast (0.104 vs 0.110 ms per build), so the library scan is used from 4M cells up.  d_scratch must
-// hold scan_scratch_bytes(n).  KSS_SCAN_OWN=1: always the kernels above (A/B).
-// (the library's default configuration for this architecture scans 127 us over C4's 31.6M counters -- a chain of
-// look-backs through ~8000 tiles; with 64 items per lane there are 1929 tiles and the same scan takes 76 us: tools/ab_scan.sh)
+// Exclusive scan of the cell counts: d_start[0 .. n] (d_start[n] = total): chunk totals, their scan (inside the apply kernel
+// up to 1024 chunks), apply.  On C4's 2 x 15.8M counters: 25 + 9 + 43 us = the table read twice and written once at
+// 5 TB/s.  (Round 2's kernels -- every lane 16 consecutive elements, totals read four bytes a lane -- took 240 us there and
+// rocPRIM's decoupled-look-back scan was used from 4M cells up: 127 us in its default configuration, a chain of look-backs
+// through ~8000 tiles, 76 us configured with 64 items per lane, below.  KSS_SCAN_LIB=1 selects it for an A/B:
+// tools/ab_scan.sh.)  d_scratch must hold scan_scratch_bytes(n).
 using BigScanConfig = rocprim::scan_config<256, 64, rocprim::block_load_method::block_load_transpose, rocprim::block_store_method::block_store_transpose,
                                            rocprim::block_scan_algorithm::reduce_then_scan>;
 
@@ -177,8 +177,8 @@ size_t scan_scratch_bytes(int n) {
 }
 
 static void launch_scan(hipStream_t st, const int32_t* d_counts, int ncells, int32_t* d_start, int32_t* d_scratch) {
-    static const bool own = getenv("KSS_SCAN_OWN") != nullptr;
-    if (!own && ncells > 1024 * SCAN_CHUNK) {
+    static const bool lib = getenv("KSS_SCAN_LIB") != nullptr;   // A/B: rocPRIM's look-back scan for big tables
+    if (lib && ncells > 1024 * SCAN_CHUNK) {
         size_t bytes = 0;
         if (rocprim::inclusive_scan<BigScanConfig>(nullptr, bytes, d_counts, d_start + 1, (size_t)ncells, rocprim::plus<int32_t>(), st) == hipSuccess) {
             hipMemsetAsync(d_start, 0, sizeof(int32_t), st);
@@ -193,8 +193,7 @@ static void launch_scan(hipStream_t st, const int32_t* d_counts, int ncells, int
         hipLaunchKernelGGL(scan_apply_kernel<true>, dim3(nb), dim3(256), 0, st, d_counts, ncells, d_block_sums, d_start);
     } else {
         hipLaunchKernelGGL(scan_of_block_sums_kernel, dim3(1), dim3(1024), 0, st, d_block_sums, nb);
-        hipLaunchKernelGGL(scan_apply_kernel<false>, dim3(nb), dim3(256), 0, st, d_counts, ncells, d_block_sums, d_start);
-        hipLaunchKernelGGL(scan_tail_kernel, dim3(1), dim3(64), 0, st, d_counts, d_start, ncells);
+        hipLaunchKernelGGL(scan_apply_kernel<false>, dim3(nb), dim3(256), 0, st, d_counts, ncells, d_block_sums, d_start);   // (also writes start[n])
     }
 }
 

@@ -1,11 +1,11 @@
 #!/bin/bash
-# A/B of the cell-count scan on the 1M-point pair: the configured library scan against this repository's three-phase scan
-# (KSS_SCAN_OWN=1), the scan kernels' time by rocprofv3.  (Round 3 chose the library configuration with this script and a
+# A/B of the cell-count scan on the 1M-point pair: this repository's three-phase scan against the configured library scan
+# (KSS_SCAN_LIB=1), the scan kernels' time by rocprofv3.  (Round 3 chose the library configuration with this script and a
 # temporary KSS_SCAN_CFG hook: 21 / 32 / 48 / 64 items per lane -> 110 / 89 / 81 / 76 us; the default configuration: 127.)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-for cfg in lib own; do
+for cfg in own lib; do
   rm -rf gpurun_out/pscan
-  if [ $cfg = own ]; then export KSS_SCAN_OWN=1; fi
+  if [ $cfg = lib ]; then export KSS_SCAN_LIB=1; fi
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pscan -- python3 tools/bench_configs.py c4 --grid-only > gpurun_out/pscan.txt 2>&1 || { tail -3 gpurun_out/pscan.txt; exit 1; }
   echo "cfg $cfg: $(grep -o '"nn_sweep_ms_grid": [0-9.]*' gpurun_out/pscan.txt | tail -1)"
   python3 - <<'PY'
