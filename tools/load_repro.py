@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """One context registers the same pair over and over while other threads keep the GPU busy with unrelated work on contexts of
-their own: every registration must give the same bits.  usage: load_repro.py [reps] [load: batch|sweep|register]"""
+their own: every registration must give the same bits.  usage: load_repro.py [reps] [load: batch|sweep|register] [threads]
+With KSS_DEBUG_CANDS=1 the library prints every candidate's record to stderr; the markers this script writes there
+("BASELINE ABOVE", "DIFFERING ABOVE") say which of those dumps belong to the solitary run and to a differing one."""
 import hashlib, os, sys, threading, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
