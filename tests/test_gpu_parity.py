@@ -507,7 +507,9 @@ print("RESULT" + json.dumps(out))
                 # do not fit its check word; a result slot is first stored with bits that do not fit its check word.  The
                 # receiver polls again instead of taking it for data
                 "torn_gate": {"KSS_TEST_TORN_GATE": "6"}, "torn_gate_unchained": {"KSS_TEST_TORN_GATE": "4", "KSS_CHAIN": "0"},
-                "torn_slot": {"KSS_TEST_TORN_SLOT": "4"}, "torn_slot_late": {"KSS_TEST_TORN_SLOT": "23"}}
+                "torn_slot": {"KSS_TEST_TORN_SLOT": "4"}, "torn_slot_late": {"KSS_TEST_TORN_SLOT": "23"},
+                # the set-up's two forms: the target's bounding box by copy + synchronisation instead of host-memory granules
+                "box_by_copy": {"KSS_BBOX_HOST": "0"}}
     for name, extra in variants.items():
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
@@ -564,7 +566,9 @@ print("RESULT" + json.dumps(out))
 """ % ROOT
     res = {}
     for name, extra in {"default": {}, "ticket": {"KSS_TAGGED_ROWS_MAX": "256"}, "ticket_all": {"KSS_TAGGED_ROWS": "0"},
-                        "ungated": {"KSS_GATED": "0"}, "ungated_ticket": {"KSS_GATED": "0", "KSS_TAGGED_ROWS_MAX": "256"}}.items():
+                        "ungated": {"KSS_GATED": "0"}, "ungated_ticket": {"KSS_GATED": "0", "KSS_TAGGED_ROWS_MAX": "256"},
+                        "library_scan": {"KSS_SCAN_LIB": "1"},   # (the cell table's scan by rocPRIM instead of kss_grid.hip's own: same starts)
+                        "box_by_copy": {"KSS_BBOX_HOST": "0"}}.items():
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, **extra))
         assert r.returncode == 0, name + r.stdout + r.stderr
         res[name] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT")][0][6:])
